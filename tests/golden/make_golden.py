@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.
+
+Nothing here imports the oracle or the product: every expected value comes
+from an INDEPENDENT route (numpy/scipy fp64, exact rational arithmetic, or
+hand evaluation of the reference's arithmetic), so the fixtures can pin the
+oracle.  The reference itself (tejeez/sxxcvr) has no tests, no vectors and no
+software FIR, and cannot be built in this image (SoapySDR + ALSA headers are
+absent), so none of these values come from a reference run.
+
+Run:  python tests/golden/make_golden.py      (rewrites the fixture files)
+"""
+import json
+import os
+from fractions import Fraction
+
+import numpy as np
+from scipy import signal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# taps: Kaiser-windowed sinc, cutoff 0.5/ratio, sum = gain, fp64 -> fp32 once
+# --------------------------------------------------------------------------
+def design(ntaps, ratio, beta=8.0, gain=1.0):
+    k = np.arange(ntaps, dtype=np.float64)
+    mid = 0.5 * (ntaps - 1)
+    fc = 0.5 / ratio
+    h = 2.0 * fc * np.sinc(2.0 * fc * (k - mid)) * signal.windows.kaiser(ntaps, beta, sym=True)
+    h *= gain / h.sum()
+    return h.astype(np.float32)
+
+
+def make_taps():
+    out = {}
+    for name, (n, r, g) in {
+        "n128_d4": (128, 4, 1.0),
+        "n256_d8": (256, 8, 1.0),
+        "n256_l8": (256, 8, 8.0),
+        "n1024_d32": (1024, 32, 1.0),
+    }.items():
+        out[name] = design(n, r, gain=g)
+    np.savez(os.path.join(HERE, "taps.npz"), **out)
+    return out
+
+
+# --------------------------------------------------------------------------
+# FIR known answers: scipy.signal.upfirdn in fp64 on fp32-representable data
+# --------------------------------------------------------------------------
+def make_fir(taps):
+    rng = np.random.default_rng(0x51255)
+    n = 1536
+    x = (rng.integers(-(2 ** 23), 2 ** 23, size=n) / 2.0 ** 23
+         + 1j * rng.integers(-(2 ** 23), 2 ** 23, size=n) / 2.0 ** 23).astype(np.complex64)
+    out = {"x": x}
+    for name, d in (("n128_d4", 4), ("n256_d8", 8), ("n1024_d32", 32)):
+        h = taps[name].astype(np.float64)
+        y = signal.upfirdn(h, x.astype(np.complex128), up=1, down=d)[: (n + d - 1) // d]
+        out["decim_" + name] = y
+    h = taps["n256_l8"].astype(np.float64)
+    xs = x[:256]
+    out["interp_n256_l8"] = signal.upfirdn(h, xs.astype(np.complex128), up=8, down=1)[: 256 * 8]
+    # impulse + step edge cases (exact answers: the taps themselves / their prefix sums)
+    np.savez(os.path.join(HERE, "fir_kat.npz"), **out)
+
+
+# --------------------------------------------------------------------------
+# time: exact round-half-away of ticks*1e9/rate and ns*rate/1e9
+# --------------------------------------------------------------------------
+def rnd(fr):
+    s = 1 if fr >= 0 else -1
+    fr = abs(fr)
+    q = fr.numerator // fr.denominator
+    if 2 * (fr - q) >= 1:
+        q += 1
+    return s * q
+
+
+def make_time():
+    clocks = [32.0e6, 38.4e6]
+    divs = [1536, 768, 512, 256, 128, 64]            # SoapySX.cpp:196-208
+    ticks = [0, 1, 255, 256, 768, 1792, 65536, 75000, 10 ** 9 + 7, 123456789012]
+    rows = []
+    for c in clocks:
+        for d in divs:
+            rate = c / d                                  # SoapySX.cpp:1205
+            fr = Fraction(rate)                           # the double, exactly
+            for t in ticks:
+                ns = rnd(Fraction(t) * 10 ** 9 / fr)
+                back = rnd(Fraction(ns) * fr / 10 ** 9)
+                rows.append({"rate": rate, "ticks": t, "ns": ns, "ticks_back": back})
+    hand = [  # round(256e9 / rate): SURVEY.md section 8 a-T
+        {"rate": 600000.0, "ticks": 256, "ns": 426667},
+        {"rate": 75000.0, "ticks": 256, "ns": 3413333},
+        {"rate": 75000.0, "ticks": 512, "ns": 6826667},
+        {"rate": 32.0e6 / 768, "ticks": 256, "ns": 6144000},
+        # example/linear_repeater.py:40-43: 768 samples at 75 kS/s = 10.24 ms
+        {"rate": 75000.0, "ticks": 768, "ns": 10240000},
+    ]
+    with open(os.path.join(HERE, "time_kat.json"), "w") as f:
+        json.dump({"exact": rows, "hand": hand}, f, indent=0)
+
+
+# --------------------------------------------------------------------------
+# conversion: numpy float32 route + hand-evaluated edge values
+# --------------------------------------------------------------------------
+def conv_tx_numpy(x, thr2):
+    f = x.view(np.float32).astype(np.float32)
+    c = np.minimum(f, np.float32(1.0))                   # std::min(f, 1.0f)
+    c = np.maximum(c, np.float32(-1.0))
+    v = (c * np.float32(2147483648.0)).astype(np.float64)
+    v = np.trunc(v)
+    v = np.where(np.isnan(v), 0.0, v)
+    v = np.clip(v, -2147483648.0, 2147483647.0).astype(np.int64)   # saturating (ARM) definition
+    v = (v & ~3).astype(np.int64)
+    fi, fq = f[0::2], f[1::2]
+    mag = (fi * fi).astype(np.float32) + (fq * fq).astype(np.float32)
+    ptt = mag.astype(np.float32) >= np.float32(thr2)
+    v[0::2] |= np.where(ptt, 3, 0)
+    return v.astype(np.int64)
+
+
+def make_conv():
+    rng = np.random.default_rng(1255)
+    s32 = rng.integers(-(2 ** 31), 2 ** 31, size=512, dtype=np.int64).astype(np.int32)
+    s32[:6] = [2 ** 31 - 1, 0x7FFFFF80, -(2 ** 31), 1, 0, -1]
+    rx = (s32.astype(np.float32) * np.float32(2.0 ** -31)).astype(np.float32)
+    tx_in = (rng.uniform(-1.2, 1.2, size=256) + 1j * rng.uniform(-1.2, 1.2, size=256)).astype(np.complex64)
+    tx_in[:8] = [0.5 + 0j, -0.25 + 0j, 1.0 + 1.0j, -1.0 - 1.0j, 2.0 - 3.0j, 1e-4 + 1e-4j, 0j, 0.001 + 0j]
+    thr = np.float32(1.0e-3)
+    thr2 = np.float32(thr * thr)                          # SoapySX.cpp:767-773
+    tx = conv_tx_numpy(tx_in, thr2)
+    hand = {
+        # exactly ldexpf((float)x, -31)
+        "rx": [[2 ** 31 - 1, 1.0], [0x7FFFFF80, float.fromhex("0x1.fffffep-1")], [-(2 ** 31), -1.0],
+               [1, 2.0 ** -31], [0, 0.0]],
+        # SURVEY.md section 8 a-4 (threshold 1e-3): 0.5 -> 0x40000000|3, -0.25 -> 0xE0000000|3,
+        # +1.0 saturates (build-defined, ARM behaviour) -> 0x7FFFFFFC, -1.0 -> 0x80000000
+        "tx": [[0.5, 0.0, 0x40000003, 0], [-0.25, 0.0, 0xE0000003 - 2 ** 32, 0],
+               [1.0, 1.0, 0x7FFFFFFF, 0x7FFFFFFC], [-1.0, -1.0, -(2 ** 31) + 3, -(2 ** 31)],
+               [1e-4, 1e-4, 214748 & ~3, 214748 & ~3]],
+    }
+    np.savez(os.path.join(HERE, "convert_kat.npz"), s32=s32, rx=rx, tx_in=tx_in, tx=tx.astype(np.int32),
+             thr2=np.array([thr2], dtype=np.float32))
+    with open(os.path.join(HERE, "convert_hand.json"), "w") as f:
+        json.dump(hand, f)
+
+
+# --------------------------------------------------------------------------
+# stream rules: hand-evaluated traces of SoapySX.cpp:897-966 / :989-1104
+# --------------------------------------------------------------------------
+def make_stream():
+    R = 75000.0
+    rx = [
+        # normal blocking reads of one period: timeNs = position/rate, flags = HAS_TIME (SX.cpp:950-953)
+        {"pos": 0, "avail": 256, "period": 256, "buffer": 65536, "n": 256, "timeout": 100000, "rate": R,
+         "exp": {"position": 256, "skipped": 0, "ret": 256, "flags": 4, "time_ns": 0}},
+        {"pos": 256, "avail": 300, "period": 256, "buffer": 65536, "n": 256, "timeout": 100000, "rate": R,
+         "exp": {"position": 512, "skipped": 0, "ret": 256, "flags": 4, "time_ns": 3413333}},
+        {"pos": 512, "avail": 256, "period": 256, "buffer": 65536, "n": 256, "timeout": 100000, "rate": R,
+         "exp": {"position": 768, "skipped": 0, "ret": 256, "flags": 4, "time_ns": 6826667}},
+        # overrun: avail 70000 > 65536 -> overwritten 4464 -> (4464//256 + 2)*256 = 4864 skipped (SX.cpp:910-927)
+        {"pos": 1000, "avail": 70000, "period": 256, "buffer": 65536, "n": 256, "timeout": 100000, "rate": R,
+         "exp": {"position": 1000 + 4864 + 256, "skipped": 4864, "ret": 256, "flags": 4,
+                 "time_ns": 78186667}},      # round((1000+4864)*1e9/75000) = 78186666.67
+        # non-blocking: clamp to avail (SX.cpp:934-942)
+        {"pos": 768, "avail": 100, "period": 256, "buffer": 65536, "n": 256, "timeout": 0, "rate": R,
+         "exp": {"position": 868, "skipped": 0, "ret": 100, "flags": 4, "time_ns": 10240000}},
+        {"pos": 768, "avail": 0, "period": 256, "buffer": 65536, "n": 256, "timeout": 0, "rate": R,
+         "exp": {"position": 768, "skipped": 0, "ret": 0, "flags": 0, "time_ns": 0}},
+        # period 1000 -> buffer 65000 (SX.cpp:464-466); avail 66001 -> overwritten 1001 -> 3 periods
+        {"pos": 0, "avail": 66001, "period": 1000, "buffer": 65000, "n": 1000, "timeout": 1, "rate": R,
+         "exp": {"position": 4000, "skipped": 3000, "ret": 1000, "flags": 4, "time_ns": 40000000}},
+    ]
+    tx = [
+        # untimed, no underrun: continue at position (SX.cpp:1024-1038)
+        {"pos": 1024, "avail": 64512, "delay": 1024, "period": 256, "n": 256, "flags": 0, "time_ns": 0,
+         "timeout": 100000, "rate": R, "exp": {"position": 1280, "skipped": 0, "ret": 256, "discarded": 0}},
+        # untimed underrun: delay -700 -> playback = pos+700 -> (700//256+2)*256 = 1024 forwarded
+        {"pos": 2048, "avail": 66236, "delay": -700, "period": 256, "n": 256, "flags": 0, "time_ns": 0,
+         "timeout": 100000, "rate": R, "exp": {"position": 2048 + 1024 + 256, "skipped": 1024, "ret": 256,
+                                               "discarded": 0}},
+        # timed: rx time 6826667 ns (pos 512) + 10.24 ms -> position 1280 exactly (linear_repeater.py:40-69)
+        {"pos": 1024, "avail": 65536 - 200, "delay": 200, "period": 256, "n": 256, "flags": 4,
+         "time_ns": 6826667 + 10240000, "timeout": 100000, "rate": R,
+         "exp": {"position": 1536, "skipped": 256, "ret": 256, "discarded": 0}},
+        # timed in the past: playback 2000-100 = 1900 > 1280 -> dropped, success reported (SX.cpp:1013-1023)
+        {"pos": 2000, "avail": 65436, "delay": 100, "period": 256, "n": 256, "flags": 4,
+         "time_ns": 6826667 + 10240000, "timeout": 100000, "rate": R,
+         "exp": {"position": 2000, "skipped": 0, "ret": 256, "discarded": 1}},
+        # timed, target behind position but not yet played: no rewind, written at position (posdiff <= 0)
+        {"pos": 1500, "avail": 65036, "delay": 500, "period": 256, "n": 256, "flags": 4,
+         "time_ns": 6826667 + 10240000, "timeout": 100000, "rate": R,
+         "exp": {"position": 1756, "skipped": 0, "ret": 256, "discarded": 0}},
+        # non-blocking clamp after a forward: local avail is reduced by the forward (SX.cpp:1072,1076-1085)
+        {"pos": 0, "avail": 300, "delay": 65236, "period": 256, "n": 256, "flags": 4,
+         "time_ns": 2666667, "timeout": 0, "rate": R,   # 200 samples
+         "exp": {"position": 300, "skipped": 200, "ret": 100, "discarded": 0}},
+    ]
+    with open(os.path.join(HERE, "stream_kat.json"), "w") as f:
+        json.dump({"rx": rx, "tx": tx}, f, indent=0)
+
+
+if __name__ == "__main__":
+    t = make_taps()
+    make_fir(t)
+    make_time()
+    make_conv()
+    make_stream()
+    print("golden fixtures written to", HERE)
