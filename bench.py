@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X resampling hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one streaming pass of the 128-tap decimate-by-4 CF32 polyphase
+FIR (sxfir_decimate through the C ABI: resampling kernel + history carry-over)
+over the rank's resident synthetic IQ block (2^28 complex samples per GPU,
+already in HBM when the timed region starts).  N = 1 runs BASELINE config 2
+(1 channel); N > 1 runs config 4's layout (8 independent channels per GPU,
+8*N in total, no data-path collective), and measures the RCCL gather of the
+decimated output to rank 0 separately (reported under "gather", never part of
+`value`: it is xGMI-link bound).
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NTAPS, DECIM = 128, 4
+SEED = 0x51255
+BYTES_PER_INPUT_SAMPLE = 8 + 8 / DECIM          # 8 B read + 2 B written
+FLOP_PER_INPUT_SAMPLE = 4 * NTAPS / DECIM
+HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0                            # measured float4 copy ceiling (same guide)
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The build's own CPU FIR (the reference has none), order-matched fp32
+    oracle, timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    oracle_lib.build()
+    cpuinfo = open("/proc/cpuinfo").read()
+    fast = (" avx2" in cpuinfo) and (" fma" in cpuinfo)
+    orc = oracle_lib.Oracle(fast=fast)
+    taps = orc.design_lowpass(NTAPS, DECIM)
+    threads = orc.max_threads()
+    model = "unknown"
+    for line in cpuinfo.splitlines():
+        if line.startswith("model name"):
+            model = line.split(":", 1)[1].strip()
+            break
+    n_probe = 1 << 20
+    x = orc.synth_iq(SEED, 0, 0, n_probe)
+    t0 = time.perf_counter()
+    orc.decim_f32(taps, DECIM, x, 2, 4, threads=1)
+    t1 = time.perf_counter() - t0
+    one_thread = n_probe / t1 / 1e6
+    t0 = time.perf_counter()
+    orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)
+    tn = time.perf_counter() - t0
+    rate = n_probe / tn
+    n = int(min(max(rate * seconds_target, n_probe), 1 << 28))
+    n -= n % 4096
+    x = orc.synth_iq(SEED, 0, 0, n)
+    t0 = time.perf_counter()
+    orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n / dt / 1e6, 2),
+        "unit": "MS/s (complex input samples)",
+        "cores": threads,
+        "kind": "port",
+        "sample": "first %d input samples of the same synthetic channel-0 stream, %d threads (OpenMP over "
+                  "output blocks), %s build; the reference has no software FIR, this is the build's own "
+                  "CPU FIR" % (n, threads, "AVX2+FMA" if fast else "portable"),
+        "one_thread_value": round(one_thread, 2),
+        "cpu_model": model,
+        "seconds": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (log2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import sxxcvr_amd
+    from sxxcvr_amd import dist as sxdist
+    from sxxcvr_amd.resampler import DECIMATE
+
+    rank, local_rank, world = sxdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    per_gpu = 1 << args.log2_samples
+    if world == 1:
+        nchan_local, total_channels = 1, 1
+        workload = "1xMI355X: 128-tap polyphase decim-by-4, 1 ch CF32 streaming (BASELINE config 2)"
+    else:
+        nchan_local, total_channels = 8, 8 * world
+        workload = ("%dxMI355X: %d independent CF32 channels sharded 8/GPU, 128-tap decim-by-4 "
+                    "(BASELINE config 4 layout)" % (world, total_channels))
+    n_in = per_gpu // nchan_local
+    lo, hi = sxdist.shard_channels(total_channels, world, rank)
+    assert hi - lo == nchan_local
+
+    taps = sxxcvr_amd.design_lowpass(NTAPS, DECIM)
+    plan = sxxcvr_amd.Resampler(DECIMATE, taps, DECIM, nchan=nchan_local, device=local_rank)
+    x = torch.empty((nchan_local, n_in), dtype=torch.complex64, device=dev)
+    sxxcvr_amd.synth_fill(x, SEED, first_channel=lo, start=0)
+    y = torch.empty((nchan_local, n_in // DECIM), dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        plan.reset()          # every step filters the same block from stream start (async memset)
+        plan.process(x, out=y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel alone, HIP events on the launch stream (not torch's event API)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    plan.reset()
+    torch.cuda.synchronize()
+    kernel_ms = plan.time_decimate_ptr(x.data_ptr(), n_in, x.stride(0) if nchan_local > 1 else n_in, y.data_ptr(),
+                                       y.stride(0) if nchan_local > 1 else n_in // DECIM, max(args.steps, 5), stream)
+    achieved = BYTES_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e9
+
+    gather = None
+    if world > 1:
+        # exchange step of config 4: decimated output of every rank to rank 0 over xGMI
+        for _ in range(2):
+            sxdist.gather_channels(y, total_channels, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            sxdist.gather_channels(y, total_channels, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = (time.perf_counter() - g0) / reps
+        t = torch.tensor([g], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g = float(t.item())
+        peer_bytes = y.numel() * 8
+        gather = {
+            "ms": round(g * 1e3, 3),
+            "bytes_per_peer": peer_bytes,
+            "GB/s_into_root": round(peer_bytes * (world - 1) / g / 1e9, 2),
+            "GB/s_per_link": round(peer_bytes / g / 1e9, 2),
+            "value_with_gather": round(world * per_gpu * 1.0 / (elapsed / args.steps + g) / 1e6, 1),
+            "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part "
+                    "of value",
+        }
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * per_gpu * args.steps / elapsed / 1e6
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "complex MS/s, 128-tap decim-by-4 CF32 (input rate, whole job)",
+            "value": round(value, 1),
+            "unit": "MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": workload,
+                "ntaps": NTAPS, "decim": DECIM, "format": "CF32",
+                "channels_per_gpu": nchan_local, "input_samples_per_gpu": per_gpu,
+                "output_MS/s": round(value / DECIM, 1),
+                "per_gpu_MS/s": round(value / world, 1),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel": "sxfir::decim4_tile_kernel<128>",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": int(BYTES_PER_INPUT_SAMPLE * per_gpu),
+                "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                "fp32_TFLOPs": round(FLOP_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e12, 2),
+            },
+        }
+        if gather is not None:
+            line["gather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/*
+ * sxfir.h -- C ABI of the MI355X (gfx950) polyphase FIR resampling path that
+ * sits behind SoapySX::readStream / writeStream.
+ *
+ * This is the INNER drop-in boundary: host C++ (the
+ * SoapySDR Device in sxxcvr_amd/csrc/SoapySXHip.cpp, or any FFI: ctypes, cgo,
+ * JNI) calls hand-written HIP kernels through these plain-C entry points.
+ * Plain pointers and sizes only; no C++ or torch types; no exceptions cross
+ * it.  Every function returns 0 (SXFIR_OK) or a negative SXFIR_E* code and
+ * leaves a message for sxfir_last_error().
+ *
+ * What each entry point replaces in the reference (tejeez/sxxcvr,
+ * SoapySX/SoapySX.cpp = "SX.cpp"):
+ *
+ *   sxfir_create / sxfir_set_ratio ... the SX1255 decimator/interpolator
+ *       configuration written by setSampleRate (SX.cpp:1166-1209, register
+ *       table SX.cpp:180-208): the reference only programs the chip's
+ *       divider; here the filter itself is built.
+ *   sxfir_reset ...................... AlsaPcm::reset (SX.cpp:419-432):
+ *       position = 0, stream restarted (history cleared).
+ *   sxfir_decimate ................... the on-chip RX decimator + the I2S/ALSA
+ *       capture that feeds snd_pcm_readi (SX.cpp:948).
+ *   sxfir_interpolate ................ the on-chip TX interpolator behind
+ *       snd_pcm_writei (SX.cpp:1093).
+ *   sxfir_convert_rx_s32 ............. convert_rx_buffer (SX.cpp:103-112).
+ *   sxfir_convert_tx_s32 ............. convert_tx_buffer (SX.cpp:116-137).
+ *   sxfir_ticks_to_time_ns,
+ *   sxfir_time_ns_to_ticks ........... samples_to_timestamp /
+ *       timestamp_to_samples (SX.cpp:562-571), i.e. SoapySDR::ticksToTimeNs /
+ *       timeNsToTicks.
+ *   sxfir_synth_fill ................. the synthetic CF32 IQ source that
+ *       stands in for the SX1255 ADC stream (no counterpart: hardware).
+ *
+ * Device buffers are caller-owned.  A plan is bound to one GPU and is not
+ * thread-safe (the Device's per-stream mutex serialises calls, mirroring
+ * SX.cpp:878 / :979).  `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream); all work is enqueued asynchronously on it.
+ */
+#ifndef SXFIR_H
+#define SXFIR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SXFIR_ABI_VERSION 1
+
+enum {
+    SXFIR_OK = 0,
+    SXFIR_EINVAL = -1,      /* bad argument */
+    SXFIR_EHIP = -2,        /* HIP runtime error (see sxfir_last_error) */
+    SXFIR_ENOMEM = -3,
+    SXFIR_EUNSUPPORTED = -4,
+    SXFIR_ENODEVICE = -5    /* no gfx950 device visible: the product never falls back to a CPU path */
+};
+
+enum { SXFIR_DECIMATE = 0, SXFIR_INTERPOLATE = 1 };
+
+/* IQ storage format in HBM.  Arithmetic is always fp32. */
+enum { SXFIR_CF32 = 0, SXFIR_CF16 = 1 };
+
+/* Kernel selection (for tests / profiling).  AUTO picks the LDS-tiled kernel
+ * whenever the shape allows it and the generic one-output-per-thread kernel
+ * otherwise; both implement the same numeric contract. */
+enum { SXFIR_KERNEL_AUTO = 0, SXFIR_KERNEL_TILED = 1, SXFIR_KERNEL_GENERIC = 2 };
+
+typedef struct sxfir_plan sxfir_plan;
+
+int sxfir_abi_version(void);
+const char *sxfir_last_error(void);
+int sxfir_device_count(int *count);
+/* name: at least 64 bytes.  arch: at least 32 bytes (e.g. "gfx950"). */
+int sxfir_device_info(int device, char *name, char *arch, int *compute_units, size_t *hbm_bytes);
+
+/* Build a resampler for `nchan` independent channels on GPU `device`
+ * (-1 = the calling thread's current HIP device).
+ *   mode   SXFIR_DECIMATE: y[m] = sum_k taps[k] x[m*ratio - k]
+ *          SXFIR_INTERPOLATE: y[n] = sum_j taps[j*ratio + n%ratio] x[n/ratio - j]
+ *   taps   host pointer, ntaps floats (copied)
+ *   fmt    SXFIR_CF32 or SXFIR_CF16, used for both input and output
+ * Samples before the start of the stream are zero; the last ntaps-1 input
+ * samples persist across calls (per channel) until sxfir_reset. */
+int sxfir_create(sxfir_plan **plan, int mode, const float *taps, int ntaps, int ratio,
+                 int nchan, int fmt, int device);
+int sxfir_destroy(sxfir_plan *plan);
+int sxfir_reset(sxfir_plan *plan, void *stream);
+int sxfir_set_kernel(sxfir_plan *plan, int kernel);
+
+/* The numeric contract of this plan, for an order-matched CPU check:
+ * decimator: taps split into `jsplit` contiguous ranges of polyphase rows j
+ * (k = j*ratio + r) and column groups of `cw` phases r; interpolator: `jsplit`
+ * contiguous ranges of j, cw = 1.  See DESIGN.md "Numeric contract". */
+int sxfir_contract(const sxfir_plan *plan, int *jsplit, int *cw);
+
+/* Absolute count of input samples consumed / output samples produced since
+ * the last reset (per channel; all channels advance together). */
+int sxfir_position(const sxfir_plan *plan, int64_t *consumed, int64_t *produced);
+
+/* Number of outputs a call with n_in new input samples would produce now. */
+int sxfir_outputs_for(const sxfir_plan *plan, size_t n_in, size_t *n_out);
+
+/* Streaming decimation.  in_dev: channel c's samples start at
+ * in_dev + c*in_stride samples (complex samples of the plan's format);
+ * out_dev likewise with out_stride.  Writes *n_out (may be NULL). */
+int sxfir_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
+                   void *out_dev, size_t out_stride, size_t *n_out, void *stream);
+
+/* Streaming interpolation: n_in input samples -> n_in*ratio outputs. */
+int sxfir_interpolate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
+                      void *out_dev, size_t out_stride, size_t *n_out, void *stream);
+
+/* Synthetic CF32/CF16 IQ source: out_dev[c*stride + i] = sample (start+i) of
+ * channel (first_channel + c); index < 0 gives zero.  Counter-based, so any
+ * range can be regenerated anywhere. */
+int sxfir_synth_fill(void *out_dev, size_t n, size_t stride, int nchan, uint64_t seed,
+                     uint32_t first_channel, int64_t start, int fmt, void *stream);
+
+/* S32_LE I2S wire format <-> CF32 (n complex samples, device pointers). */
+int sxfir_convert_rx_s32(const int32_t *src_dev, float *dst_dev, size_t n, void *stream);
+int sxfir_convert_tx_s32(const float *src_dev, int32_t *dst_dev, size_t n, float tx_threshold2,
+                         void *stream);
+/* CF32 <-> CF16 storage conversion (n complex samples). */
+int sxfir_cf32_to_cf16(const float *src_dev, void *dst_dev, size_t n, void *stream);
+int sxfir_cf16_to_cf32(const void *src_dev, float *dst_dev, size_t n, void *stream);
+
+/* Position <-> time at `rate` samples per second. */
+long long sxfir_ticks_to_time_ns(long long ticks, double rate);
+long long sxfir_time_ns_to_ticks(long long time_ns, double rate);
+
+/* Kaiser-windowed-sinc low-pass prototype (host): cutoff 0.5/ratio, sum = gain. */
+int sxfir_design_lowpass(int ntaps, int ratio, double beta, double gain, float *taps);
+
+/* Thin device-memory helpers so that a non-HIP host language can drive the
+ * library without its own HIP binding. */
+int sxfir_malloc(void **dev, size_t bytes);
+int sxfir_free(void *dev);
+int sxfir_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
+int sxfir_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
+int sxfir_stream_sync(void *stream);
+
+/* Timed launches for bench.py: runs `iters` back-to-back decimate passes of
+ * the same buffers on `stream` bracketed by hipEvents ON THAT STREAM and
+ * returns the mean milliseconds per pass of the resampling kernel. */
+int sxfir_time_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
+                        void *out_dev, size_t out_stride, int iters, void *stream, float *ms_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

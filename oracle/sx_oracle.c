@@ -229,69 +229,92 @@ static inline float tree_sum(float *p, int g)
     return p[0];
 }
 
-static void decim_f32_range(const float *h, int ntaps, int D, int groups, const float *x,
+/* Decimator contract with polyphase rows j and phases r (tap k = j*D + r):
+ *   partial[c][p] = fmaf chain from +0.0f over j DESCENDING in row range p
+ *                   (jsplit contiguous ranges of ceil(ntaps/D)/jsplit rows) and,
+ *                   inside a row, r DESCENDING in column group c (cw phases);
+ *                   i.e. ascending sample time inside the (c, p) subset
+ *   col[c]        = adjacent-pair tree over p of partial[c][p]
+ *   y             = adjacent-pair tree over c of col[c]
+ * (jsplit = 1, cw = D) is the plain descending-k chain. */
+static void decim_f32_range(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                             int64_t m_begin, int64_t m_end, int64_t m0, float *y)
 {
-    const int gl = ntaps / groups;
+    const int jt = (ntaps + D - 1) / D;
+    const int jl = jt / jsplit;
+    const int ncol = D / cw;
     /* Blocks of BLK outputs so the compiler can vectorise across outputs; the
      * per-output operation order is unchanged. */
     enum { BLK = 16 };
     int64_t m = m_begin;
     while (m < m_end) {
         const int nb = (int)((m_end - m) < BLK ? (m_end - m) : BLK);
-        const int safe = (m * (int64_t)D - (ntaps - 1) >= 0) && nb == BLK;
-        float pi[SXO_MAX_GROUPS][BLK], pq[SXO_MAX_GROUPS][BLK];
-        for (int p = 0; p < groups; p++) {
-            float ai[BLK], aq[BLK];
-            for (int b = 0; b < BLK; b++) { ai[b] = 0.0f; aq[b] = 0.0f; }
-            if (safe) {
-                for (int k = (p + 1) * gl - 1; k >= p * gl; k--) {
-                    const float c = h[k];
-                    const float *xs = x + 2 * (m * (int64_t)D - k);
-                    for (int b = 0; b < BLK; b++) {
-                        ai[b] = fmaf(c, xs[2 * (int64_t)b * D], ai[b]);
-                        aq[b] = fmaf(c, xs[2 * (int64_t)b * D + 1], aq[b]);
+        const int safe = (m * (int64_t)D - ((int64_t)jt * D - 1) >= 0) && nb == BLK;
+        float ci[SXO_MAX_GROUPS][BLK], cq[SXO_MAX_GROUPS][BLK];
+        for (int c = 0; c < ncol; c++) {
+            float pi[SXO_MAX_GROUPS][BLK], pq[SXO_MAX_GROUPS][BLK];
+            for (int p = 0; p < jsplit; p++) {
+                float ai[BLK], aq[BLK];
+                for (int b = 0; b < BLK; b++) { ai[b] = 0.0f; aq[b] = 0.0f; }
+                for (int j = (p + 1) * jl - 1; j >= p * jl; j--) {
+                    for (int r = (c + 1) * cw - 1; r >= c * cw; r--) {
+                        const int k = j * D + r;
+                        if (k >= ntaps) continue;
+                        const float t = h[k];
+                        if (safe) {
+                            const float *xs = x + 2 * (m * (int64_t)D - k);
+                            for (int b = 0; b < BLK; b++) {
+                                ai[b] = fmaf(t, xs[2 * (int64_t)b * D], ai[b]);
+                                aq[b] = fmaf(t, xs[2 * (int64_t)b * D + 1], aq[b]);
+                            }
+                        } else {
+                            for (int b = 0; b < nb; b++) {
+                                const int64_t idx = (m + b) * (int64_t)D - k;
+                                const float xi = idx < 0 ? 0.0f : x[2 * idx];
+                                const float xq = idx < 0 ? 0.0f : x[2 * idx + 1];
+                                ai[b] = fmaf(t, xi, ai[b]);
+                                aq[b] = fmaf(t, xq, aq[b]);
+                            }
+                        }
                     }
                 }
-            } else {
-                for (int k = (p + 1) * gl - 1; k >= p * gl; k--) {
-                    const float c = h[k];
-                    for (int b = 0; b < nb; b++) {
-                        const int64_t idx = (m + b) * (int64_t)D - k;
-                        const float xi = idx < 0 ? 0.0f : x[2 * idx];
-                        const float xq = idx < 0 ? 0.0f : x[2 * idx + 1];
-                        ai[b] = fmaf(c, xi, ai[b]);
-                        aq[b] = fmaf(c, xq, aq[b]);
-                    }
-                }
+                for (int b = 0; b < BLK; b++) { pi[p][b] = ai[b]; pq[p][b] = aq[b]; }
             }
-            for (int b = 0; b < BLK; b++) { pi[p][b] = ai[b]; pq[p][b] = aq[b]; }
+            for (int b = 0; b < nb; b++) {
+                float ti[SXO_MAX_GROUPS], tq[SXO_MAX_GROUPS];
+                for (int p = 0; p < jsplit; p++) { ti[p] = pi[p][b]; tq[p] = pq[p][b]; }
+                ci[c][b] = tree_sum(ti, jsplit);
+                cq[c][b] = tree_sum(tq, jsplit);
+            }
         }
         for (int b = 0; b < nb; b++) {
             float ti[SXO_MAX_GROUPS], tq[SXO_MAX_GROUPS];
-            for (int p = 0; p < groups; p++) { ti[p] = pi[p][b]; tq[p] = pq[p][b]; }
-            y[2 * (m + b - m0)] = tree_sum(ti, groups);
-            y[2 * (m + b - m0) + 1] = tree_sum(tq, groups);
+            for (int c = 0; c < ncol; c++) { ti[c] = ci[c][b]; tq[c] = cq[c][b]; }
+            y[2 * (m + b - m0)] = tree_sum(ti, ncol);
+            y[2 * (m + b - m0) + 1] = tree_sum(tq, ncol);
         }
         m += nb;
     }
 }
 
-static int decim_check(int ntaps, int D, int groups, size_t n_x, int64_t m0, size_t n_out)
+static int pow2(int v) { return v >= 1 && !(v & (v - 1)); }
+
+static int decim_check(int ntaps, int D, int jsplit, int cw, size_t n_x, int64_t m0, size_t n_out)
 {
-    if (groups < 1 || groups > SXO_MAX_GROUPS || (groups & (groups - 1)) || ntaps % groups)
-        return -2;
-    if (D < 1 || m0 < 0) return -2;
+    if (ntaps < 1 || D < 1 || m0 < 0) return -2;
+    const int jt = (ntaps + D - 1) / D;
+    if (!pow2(jsplit) || jsplit > SXO_MAX_GROUPS || jt % jsplit) return -2;
+    if (cw < 1 || D % cw || !pow2(D / cw) || D / cw > SXO_MAX_GROUPS) return -2;
     if (n_out && (m0 + (int64_t)n_out - 1) * D >= (int64_t)n_x) return -1;
     return 0;
 }
 
-int sxo_decim_f32(const float *h, int ntaps, int D, int groups, const float *x,
+int sxo_decim_f32(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                   size_t n_x, int64_t m0, size_t n_out, float *y)
 {
-    const int rc = decim_check(ntaps, D, groups, n_x, m0, n_out);
+    const int rc = decim_check(ntaps, D, jsplit, cw, n_x, m0, n_out);
     if (rc) return rc;
-    decim_f32_range(h, ntaps, D, groups, x, m0, m0 + (int64_t)n_out, m0, y);
+    decim_f32_range(h, ntaps, D, jsplit, cw, x, m0, m0 + (int64_t)n_out, m0, y);
     return 0;
 }
 
@@ -304,10 +327,10 @@ int sxo_max_threads(void)
 #endif
 }
 
-int sxo_decim_f32_mt(const float *h, int ntaps, int D, int groups, const float *x,
+int sxo_decim_f32_mt(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                      size_t n_x, int64_t m0, size_t n_out, float *y, int threads)
 {
-    const int rc = decim_check(ntaps, D, groups, n_x, m0, n_out);
+    const int rc = decim_check(ntaps, D, jsplit, cw, n_x, m0, n_out);
     if (rc) return rc;
     const int64_t chunk = 4096;
     const int64_t nchunks = ((int64_t)n_out + chunk - 1) / chunk;
@@ -319,7 +342,7 @@ int sxo_decim_f32_mt(const float *h, int ntaps, int D, int groups, const float *
         const int64_t b = m0 + c * chunk;
         int64_t e = b + chunk;
         if (e > m0 + (int64_t)n_out) e = m0 + (int64_t)n_out;
-        decim_f32_range(h, ntaps, D, groups, x, b, e, m0, y);
+        decim_f32_range(h, ntaps, D, jsplit, cw, x, b, e, m0, y);
     }
     return 0;
 }
@@ -328,9 +351,8 @@ int sxo_interp_f32(const float *h, int ntaps, int L, int groups, const float *x,
                    size_t n_x, int64_t n0, size_t n_out, float *y)
 {
     const int jt = ntaps / L;
-    if (groups < 1 || groups > SXO_MAX_GROUPS || (groups & (groups - 1)) || jt % groups)
-        return -2;
-    if (ntaps % L || n0 < 0) return -2;
+    if (ntaps < 1 || L < 1 || ntaps % L || n0 < 0) return -2;
+    if (!pow2(groups) || groups > SXO_MAX_GROUPS || jt % groups) return -2;
     const int gl = jt / groups;
     for (size_t o = 0; o < n_out; o++) {
         const int64_t n = n0 + (int64_t)o;

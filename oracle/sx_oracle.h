@@ -58,10 +58,15 @@ void sxo_design_lowpass(int ntaps, int ratio, double beta, double gain, float *t
 /* Oracle A: fp64 products and accumulation, ascending k, one final rounding. */
 int sxo_decim_f64(const float *h, int ntaps, int D, const float *x, size_t n_x,
                   int64_t m0, size_t n_out, float *y);
-/* Oracle B: order-matched fp32.  Taps split into `groups` contiguous groups;
- * inside a group a fmaf chain from +0.0f over DESCENDING k (ascending sample
- * time); group partials combined by a balanced adjacent-pair tree. */
-int sxo_decim_f32(const float *h, int ntaps, int D, int groups, const float *x,
+/* Oracle B: order-matched fp32 (the numeric contract of the HIP kernels).
+ * Tap k = j*D + r (polyphase row j, phase r).  Rows are split into `jsplit`
+ * contiguous ranges, phases into column groups of `cw`; inside a (range,
+ * column) subset a fmaf chain from +0.0f runs over j DESCENDING, r DESCENDING
+ * (ascending sample time); partials are combined by an adjacent-pair tree
+ * over the row ranges, then an adjacent-pair tree over the columns.
+ * (jsplit=1, cw=D) is the plain descending-k chain; (2, 4) at D=4 splits the
+ * taps into two contiguous halves. */
+int sxo_decim_f32(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                   size_t n_x, int64_t m0, size_t n_out, float *y);
 
 /* ---- a-0: FIR interpolator, y[n] = sum_j h[j*L + n%L] x[n/L - j], x[<0]=0 ---- */
@@ -96,7 +101,7 @@ void sxo_tx_step(int64_t position, int64_t pcm_avail, int64_t pcm_delay, uint64_
                  double rate, sxo_stream_result *r);
 
 /* ---- CPU baseline helper: multi-threaded oracle B (OpenMP over output blocks) ---- */
-int sxo_decim_f32_mt(const float *h, int ntaps, int D, int groups, const float *x,
+int sxo_decim_f32_mt(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                      size_t n_x, int64_t m0, size_t n_out, float *y, int threads);
 int sxo_max_threads(void);
 

@@ -1,0 +1,83 @@
+"""ctypes loader for the in-tree native libraries.  Fails loudly when a
+library is missing: the product has no fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(_HERE, "lib")
+
+_sxfir = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sxfir error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _share_hip_runtime_with_torch():
+    # torch ships its own libamdhip64.so.7; importing it first makes our
+    # library resolve the same runtime instance instead of a second copy.
+    if os.environ.get("SXFIR_NO_TORCH") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+def load_sxfir():
+    """Load sxxcvr_amd/lib/libsxfir.so and declare its prototypes."""
+    global _sxfir
+    if _sxfir is not None:
+        return _sxfir
+    path = os.path.join(LIBDIR, "libsxfir.so")
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build the HIP extension first (python -m sxxcvr_amd.build). "
+            "There is no CPU fallback." % path)
+    _share_hip_runtime_with_torch()
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, sz, i64, u64, ll, dbl, ci = C.c_void_p, C.c_size_t, C.c_int64, C.c_uint64, C.c_longlong, C.c_double, C.c_int
+    P = C.POINTER
+    sig = {
+        "sxfir_abi_version": (ci, []),
+        "sxfir_last_error": (C.c_char_p, []),
+        "sxfir_device_count": (ci, [P(ci)]),
+        "sxfir_device_info": (ci, [ci, C.c_char_p, C.c_char_p, P(ci), P(sz)]),
+        "sxfir_create": (ci, [P(vp), ci, vp, ci, ci, ci, ci, ci]),
+        "sxfir_destroy": (ci, [vp]),
+        "sxfir_reset": (ci, [vp, vp]),
+        "sxfir_set_kernel": (ci, [vp, ci]),
+        "sxfir_contract": (ci, [vp, P(ci), P(ci)]),
+        "sxfir_position": (ci, [vp, P(i64), P(i64)]),
+        "sxfir_outputs_for": (ci, [vp, sz, P(sz)]),
+        "sxfir_decimate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
+        "sxfir_interpolate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
+        "sxfir_time_decimate": (ci, [vp, vp, sz, sz, vp, sz, ci, vp, P(C.c_float)]),
+        "sxfir_synth_fill": (ci, [vp, sz, sz, ci, u64, C.c_uint32, i64, ci, vp]),
+        "sxfir_convert_rx_s32": (ci, [vp, vp, sz, vp]),
+        "sxfir_convert_tx_s32": (ci, [vp, vp, sz, C.c_float, vp]),
+        "sxfir_cf32_to_cf16": (ci, [vp, vp, sz, vp]),
+        "sxfir_cf16_to_cf32": (ci, [vp, vp, sz, vp]),
+        "sxfir_ticks_to_time_ns": (ll, [ll, dbl]),
+        "sxfir_time_ns_to_ticks": (ll, [ll, dbl]),
+        "sxfir_design_lowpass": (ci, [ci, ci, dbl, dbl, vp]),
+        "sxfir_malloc": (ci, [P(vp), sz]),
+        "sxfir_free": (ci, [vp]),
+        "sxfir_memcpy_h2d": (ci, [vp, vp, sz, vp]),
+        "sxfir_memcpy_d2h": (ci, [vp, vp, sz, vp]),
+        "sxfir_stream_sync": (ci, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    lib._sx_signatures = sig
+    _sxfir = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(rc, load_sxfir().sxfir_last_error().decode("utf-8", "replace"))

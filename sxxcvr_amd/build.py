@@ -1,0 +1,80 @@
+"""In-tree build of the native libraries (hipcc, gfx950 only).
+
+    python -m sxxcvr_amd.build          # build what is out of date
+    python -m sxxcvr_amd.build --force
+
+Outputs (git-ignored, shipped to the GPU box by gpurun):
+    sxxcvr_amd/lib/libsxfir.so       C ABI of the HIP resampling path (include/sxfir.h)
+    sxxcvr_amd/lib/libSXSupport.so   SoapySDR-style Device plugin + its C ABI (include/sx_device.h)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+ARCH = "gfx950"
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the product has no non-HIP build")
+    return exe
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(*dirs):
+    out = []
+    for d in dirs:
+        for base, _, files in os.walk(d):
+            out += [os.path.join(base, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
+    return out
+
+
+TARGETS = {
+    "libsxfir.so": {
+        "sources": ["sxfir.hip"],
+        "flags": [],
+    },
+    "libSXSupport.so": {
+        "sources": ["SoapySXHip.cpp", "sx_device_capi.cpp"],
+        "flags": ["-x", "hip", "-I" + os.path.join(CSRC, "compat")],
+        "libs": ["-L" + LIBDIR, "-lsxfir", "-Wl,-rpath,$ORIGIN"],
+    },
+}
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = _deps(CSRC, os.path.join(ROOT, "include"))
+    built = []
+    for name, spec in TARGETS.items():
+        srcs = [os.path.join(CSRC, s) for s in spec["sources"]]
+        if not all(os.path.exists(s) for s in srcs):
+            continue
+        out = os.path.join(LIBDIR, name)
+        if not (force or _newer(out, deps)):
+            continue
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + \
+              ["-o", out] + spec.get("libs", [])
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        built.append(out)
+    return built
+
+
+if __name__ == "__main__":
+    b = build(force="--force" in sys.argv, verbose=True)
+    print("built:", b if b else "(up to date)")

@@ -1,0 +1,564 @@
+// C ABI of the MI355X resampling path (include/sxfir.h).  Host side of the
+// "thin extern C shim": plan bookkeeping, kernel selection and launches.
+#include "../../include/sxfir.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "sxfir_decim_tile.hip.h"
+#include "sxfir_kernels.hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SXFIR_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                            \
+    } while (0)
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t sample_bytes(int fmt) { return fmt == SXFIR_CF16 ? 4 : 8; }
+
+}  // namespace
+
+struct sxfir_plan {
+    int mode, ntaps, ratio, nchan, fmt, device;
+    int kernel;            // SXFIR_KERNEL_*
+    int hist_len;          // samples of history kept per channel
+    int jsplit, cw;        // numeric contract
+    bool tile_capable;
+    int compute_units;
+    float *taps_dev;
+    void *hist_dev;        // nchan * hist_len samples
+    long long consumed, produced;
+};
+
+extern "C" {
+
+int sxfir_abi_version(void) { return SXFIR_ABI_VERSION; }
+
+const char *sxfir_last_error(void) { return g_err; }
+
+int sxfir_device_count(int *count)
+{
+    if (!count) return fail(SXFIR_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(SXFIR_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SXFIR_OK;
+}
+
+int sxfir_device_info(int device, char *name, char *arch, int *compute_units, size_t *hbm_bytes)
+{
+    hipDeviceProp_t p;
+    HIPCHECK(hipGetDeviceProperties(&p, device));
+    if (name) snprintf(name, 64, "%s", p.name);
+    if (arch) {
+        snprintf(arch, 32, "%s", p.gcnArchName);
+        char *colon = strchr(arch, ':');
+        if (colon) *colon = 0;
+    }
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    return SXFIR_OK;
+}
+
+int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int ratio, int nchan, int fmt,
+                 int device)
+{
+    if (!out || !taps) return fail(SXFIR_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (mode != SXFIR_DECIMATE && mode != SXFIR_INTERPOLATE) return fail(SXFIR_EINVAL, "bad mode %d", mode);
+    if (ntaps < 1 || ntaps > 65536) return fail(SXFIR_EINVAL, "ntaps %d out of range", ntaps);
+    if (ratio < 1 || ratio > 4096) return fail(SXFIR_EINVAL, "ratio %d out of range", ratio);
+    if (nchan < 1 || nchan > 65535) return fail(SXFIR_EINVAL, "nchan %d out of range", nchan);
+    if (fmt != SXFIR_CF32 && fmt != SXFIR_CF16) return fail(SXFIR_EINVAL, "bad format %d", fmt);
+    if (mode == SXFIR_INTERPOLATE && ntaps % ratio)
+        return fail(SXFIR_EINVAL, "interpolator needs ntaps %% ratio == 0 (%d, %d)", ntaps, ratio);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(SXFIR_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (device < 0) HIPCHECK(hipGetDevice(&device));
+    if (device >= ndev) return fail(SXFIR_EINVAL, "device %d of %d", device, ndev);
+    HIPCHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SXFIR_ENODEVICE, "device %d is %s; kernels are built for gfx950 only", device,
+                    prop.gcnArchName);
+
+    sxfir_plan *p = new (std::nothrow) sxfir_plan();
+    if (!p) return fail(SXFIR_ENOMEM, "out of host memory");
+    p->mode = mode;
+    p->ntaps = ntaps;
+    p->ratio = ratio;
+    p->nchan = nchan;
+    p->fmt = fmt;
+    p->device = device;
+    p->kernel = SXFIR_KERNEL_AUTO;
+    p->compute_units = prop.multiProcessorCount;
+    p->consumed = p->produced = 0;
+    p->taps_dev = nullptr;
+    p->hist_dev = nullptr;
+
+    if (mode == SXFIR_DECIMATE) {
+        p->hist_len = (ntaps + 1) & ~1;
+        p->tile_capable = (fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64));
+        const int jt = (ntaps + ratio - 1) / ratio;
+        if (ntaps % ratio == 0 && ratio % 4 == 0 && jt % 2 == 0) {
+            p->jsplit = 2;
+            p->cw = 4;
+        } else {
+            p->jsplit = 1;
+            p->cw = ratio;
+        }
+    } else {
+        const int jt = ntaps / ratio;
+        p->hist_len = (jt + 1) & ~1;
+        p->tile_capable = false;
+        p->jsplit = (jt % 2 == 0) ? 2 : 1;
+        p->cw = 1;
+    }
+
+    hipError_t e = hipMalloc((void **)&p->taps_dev, sizeof(float) * (size_t)ntaps);
+    if (e == hipSuccess) e = hipMalloc(&p->hist_dev, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
+    if (e == hipSuccess) e = hipMemcpy(p->taps_dev, taps, sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(p->hist_dev, 0, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
+    if (e != hipSuccess) {
+        if (p->taps_dev) (void)hipFree(p->taps_dev);
+        if (p->hist_dev) (void)hipFree(p->hist_dev);
+        delete p;
+        return fail(SXFIR_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return SXFIR_OK;
+}
+
+int sxfir_destroy(sxfir_plan *p)
+{
+    if (!p) return SXFIR_OK;
+    (void)hipFree(p->taps_dev);
+    (void)hipFree(p->hist_dev);
+    delete p;
+    return SXFIR_OK;
+}
+
+int sxfir_reset(sxfir_plan *p, void *stream)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    HIPCHECK(hipMemsetAsync(p->hist_dev, 0, sample_bytes(p->fmt) * (size_t)p->hist_len * (size_t)p->nchan,
+                            S(stream)));
+    p->consumed = p->produced = 0;
+    return SXFIR_OK;
+}
+
+int sxfir_set_kernel(sxfir_plan *p, int kernel)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (kernel < SXFIR_KERNEL_AUTO || kernel > SXFIR_KERNEL_GENERIC) return fail(SXFIR_EINVAL, "bad kernel id");
+    if (kernel == SXFIR_KERNEL_TILED && !p->tile_capable)
+        return fail(SXFIR_EUNSUPPORTED, "no tiled kernel for ntaps=%d ratio=%d fmt=%d mode=%d", p->ntaps,
+                    p->ratio, p->fmt, p->mode);
+    p->kernel = kernel;
+    return SXFIR_OK;
+}
+
+int sxfir_contract(const sxfir_plan *p, int *jsplit, int *cw)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (jsplit) *jsplit = p->jsplit;
+    if (cw) *cw = p->cw;
+    return SXFIR_OK;
+}
+
+int sxfir_position(const sxfir_plan *p, int64_t *consumed, int64_t *produced)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (consumed) *consumed = p->consumed;
+    if (produced) *produced = p->produced;
+    return SXFIR_OK;
+}
+
+static long long outputs_for(const sxfir_plan *p, long long n_in)
+{
+    if (p->mode == SXFIR_INTERPOLATE) return n_in * p->ratio;
+    const long long D = p->ratio;
+    const long long before = (p->consumed + D - 1) / D;
+    const long long after = (p->consumed + n_in + D - 1) / D;
+    return after - before;
+}
+
+int sxfir_outputs_for(const sxfir_plan *p, size_t n_in, size_t *n_out)
+{
+    if (!p || !n_out) return fail(SXFIR_EINVAL, "NULL argument");
+    *n_out = (size_t)outputs_for(p, (long long)n_in);
+    return SXFIR_OK;
+}
+
+static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, hipStream_t st)
+{
+    if (p->fmt == SXFIR_CF32)
+        hipLaunchKernelGGL(sxfir::history_kernel<float2>, dim3(p->nchan), dim3(256), 0, st,
+                           (float2 *)p->hist_dev, (const float2 *)in_dev, (long long)n_in, (long long)in_stride,
+                           (long long)p->hist_len, p->hist_len);
+    else
+        hipLaunchKernelGGL(sxfir::history_kernel<uint32_t>, dim3(p->nchan), dim3(256), 0, st,
+                           (uint32_t *)p->hist_dev, (const uint32_t *)in_dev, (long long)n_in,
+                           (long long)in_stride, (long long)p->hist_len, p->hist_len);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+// Launch only the resampling kernel (no history update, no position change).
+static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                        size_t out_stride, long long n_out, hipStream_t st)
+{
+    const long long D = p->ratio;
+    const long long first = ((p->consumed + D - 1) / D) * D - p->consumed;
+    bool tiled = p->tile_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
+                 ((uintptr_t)in_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && in_stride % 2 == 0 &&
+                 out_stride % 2 == 0;
+    if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
+        return fail(SXFIR_EUNSUPPORTED,
+                    "tiled kernel needs 16-byte aligned buffers, even strides and a call that starts on an "
+                    "output boundary");
+    if (tiled) {
+        sxfir::DecimTileArgs a;
+        a.in = (const float *)in_dev;
+        a.hist = (const float *)p->hist_dev;
+        a.out = (float *)out_dev;
+        a.taps = p->taps_dev;
+        a.n_in = (long long)n_in;
+        a.n_out = n_out;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hist_stride = p->hist_len;
+        const int tile_out = 256;
+        const long long n_tiles = (n_out + tile_out - 1) / tile_out;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        // ~16 resident waves per CU; give each wave a contiguous run of tiles
+        const long long want_waves = (long long)p->compute_units * 16 * 4;
+        long long tpw = (n_tiles + want_waves - 1) / want_waves;
+        if (tpw < 1) tpw = 1;
+        const long long waves = (n_tiles + tpw - 1) / tpw;
+        a.tiles_per_wave = (int)tpw;
+        a.n_tiles = (int)n_tiles;
+        dim3 grid((unsigned)waves, (unsigned)p->nchan);
+        if (p->ntaps == 128)
+            hipLaunchKernelGGL(sxfir::decim4_tile_kernel<128>, grid, dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL(sxfir::decim4_tile_kernel<64>, grid, dim3(64), 0, st, a);
+    } else {
+        sxfir::GenericArgs a;
+        a.in = in_dev;
+        a.hist = p->hist_dev;
+        a.out = out_dev;
+        a.taps = p->taps_dev;
+        a.n_in = (long long)n_in;
+        a.n_out = n_out;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hist_stride = p->hist_len;
+        a.first = first;
+        a.ntaps = p->ntaps;
+        a.ratio = p->ratio;
+        a.hist_len = p->hist_len;
+        a.jsplit = p->jsplit;
+        a.cw = p->cw;
+        dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
+        if (p->fmt == SXFIR_CF32)
+            hipLaunchKernelGGL(sxfir::decim_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(sxfir::decim_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, st, a);
+    }
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+static int check_io(const sxfir_plan *p, int mode, const void *in_dev, size_t n_in, size_t in_stride,
+                    const void *out_dev, size_t out_stride, long long n_out)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (p->mode != mode) return fail(SXFIR_EINVAL, "plan was created for the other direction");
+    if (n_in && (!in_dev || !out_dev)) return fail(SXFIR_EINVAL, "NULL device buffer");
+    if (p->nchan > 1 && (in_stride < n_in || out_stride < (size_t)n_out))
+        return fail(SXFIR_EINVAL, "channel stride smaller than the block");
+    if ((uintptr_t)in_dev % sample_bytes(p->fmt) || (uintptr_t)out_dev % sample_bytes(p->fmt))
+        return fail(SXFIR_EINVAL, "buffers must be aligned to one complex sample");
+    return SXFIR_OK;
+}
+
+int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                   size_t out_stride, size_t *n_out_p, void *stream)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    const long long n_out = outputs_for(p, (long long)n_in);
+    int rc = check_io(p, SXFIR_DECIMATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+    if (rc) return rc;
+    if (n_in == 0) return SXFIR_OK;
+    HIPCHECK(hipSetDevice(p->device));
+    if (n_out > 0) {
+        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream));
+        if (rc) return rc;
+    }
+    rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+    if (rc) return rc;
+    p->consumed += (long long)n_in;
+    p->produced += n_out;
+    if (n_out_p) *n_out_p = (size_t)n_out;
+    return SXFIR_OK;
+}
+
+int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                      size_t out_stride, size_t *n_out_p, void *stream)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    const long long n_out = outputs_for(p, (long long)n_in);
+    int rc = check_io(p, SXFIR_INTERPOLATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+    if (rc) return rc;
+    if (n_in == 0) return SXFIR_OK;
+    HIPCHECK(hipSetDevice(p->device));
+    sxfir::GenericArgs a;
+    a.in = in_dev;
+    a.hist = p->hist_dev;
+    a.out = out_dev;
+    a.taps = p->taps_dev;
+    a.n_in = (long long)n_in;
+    a.n_out = n_out;
+    a.in_stride = (long long)in_stride;
+    a.out_stride = (long long)out_stride;
+    a.hist_stride = p->hist_len;
+    a.first = 0;
+    a.ntaps = p->ntaps;
+    a.ratio = p->ratio;
+    a.hist_len = p->hist_len;
+    a.jsplit = p->jsplit;
+    a.cw = p->cw;
+    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
+    if (p->fmt == SXFIR_CF32)
+        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, S(stream), a);
+    else
+        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, S(stream), a);
+    HIPCHECK(hipGetLastError());
+    rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+    if (rc) return rc;
+    p->consumed += (long long)n_in;
+    p->produced += n_out;
+    if (n_out_p) *n_out_p = (size_t)n_out;
+    return SXFIR_OK;
+}
+
+int sxfir_time_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                        size_t out_stride, int iters, void *stream, float *ms_per_pass)
+{
+    if (!p || !ms_per_pass || iters < 1) return fail(SXFIR_EINVAL, "bad argument");
+    const long long n_out = outputs_for(p, (long long)n_in);
+    int rc = check_io(p, SXFIR_DECIMATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+    if (rc) return rc;
+    if (n_out < 1) return fail(SXFIR_EINVAL, "nothing to do");
+    HIPCHECK(hipSetDevice(p->device));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, S(stream)));
+    for (int i = 0; i < iters; ++i) {
+        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream));
+        if (rc) break;
+    }
+    hipError_t e = hipEventRecord(e1, S(stream));
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(SXFIR_EHIP, "event timing failed: %s", hipGetErrorString(e));
+    *ms_per_pass = ms / (float)iters;
+    return SXFIR_OK;
+}
+
+int sxfir_synth_fill(void *out_dev, size_t n, size_t stride, int nchan, uint64_t seed, uint32_t first_channel,
+                     int64_t start, int fmt, void *stream)
+{
+    if (!out_dev && n) return fail(SXFIR_EINVAL, "NULL buffer");
+    if (nchan < 1) return fail(SXFIR_EINVAL, "nchan < 1");
+    if (n == 0) return SXFIR_OK;
+    unsigned bx = (unsigned)((n + 255) / 256);
+    if (bx > 16384) bx = 16384;
+    dim3 grid(bx, (unsigned)nchan);
+    if (fmt == SXFIR_CF32)
+        hipLaunchKernelGGL(sxfir::synth_kernel<sxfir::CF32>, grid, dim3(256), 0, S(stream), out_dev, (long long)n,
+                           (long long)stride, seed, first_channel, (long long)start);
+    else if (fmt == SXFIR_CF16)
+        hipLaunchKernelGGL(sxfir::synth_kernel<sxfir::CF16>, grid, dim3(256), 0, S(stream), out_dev, (long long)n,
+                           (long long)stride, seed, first_channel, (long long)start);
+    else
+        return fail(SXFIR_EINVAL, "bad format");
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+static unsigned stream_grid(size_t n)
+{
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+int sxfir_convert_rx_s32(const int32_t *src, float *dst, size_t n, void *stream)
+{
+    if (n == 0) return SXFIR_OK;
+    if (!src || !dst) return fail(SXFIR_EINVAL, "NULL buffer");
+    hipLaunchKernelGGL(sxfir::convert_rx_kernel, dim3(stream_grid(n)), dim3(256), 0, S(stream), (const int2 *)src,
+                       (float2 *)dst, (long long)n);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+int sxfir_convert_tx_s32(const float *src, int32_t *dst, size_t n, float thr2, void *stream)
+{
+    if (n == 0) return SXFIR_OK;
+    if (!src || !dst) return fail(SXFIR_EINVAL, "NULL buffer");
+    hipLaunchKernelGGL(sxfir::convert_tx_kernel, dim3(stream_grid(n)), dim3(256), 0, S(stream),
+                       (const float2 *)src, (int2 *)dst, (long long)n, thr2);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+int sxfir_cf32_to_cf16(const float *src, void *dst, size_t n, void *stream)
+{
+    if (n == 0) return SXFIR_OK;
+    if (!src || !dst) return fail(SXFIR_EINVAL, "NULL buffer");
+    hipLaunchKernelGGL(sxfir::cf32_to_cf16_kernel, dim3(stream_grid(n)), dim3(256), 0, S(stream),
+                       (const float2 *)src, (__half2 *)dst, (long long)n);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+int sxfir_cf16_to_cf32(const void *src, float *dst, size_t n, void *stream)
+{
+    if (n == 0) return SXFIR_OK;
+    if (!src || !dst) return fail(SXFIR_EINVAL, "NULL buffer");
+    hipLaunchKernelGGL(sxfir::cf16_to_cf32_kernel, dim3(stream_grid(n)), dim3(256), 0, S(stream),
+                       (const __half2 *)src, (float2 *)dst, (long long)n);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+// SoapySDR::ticksToTimeNs / timeNsToTicks as used by SoapySX.cpp:562-571
+// (SoapySDR lib/TimeC.cpp): whole seconds in integers, remainder in double.
+long long sxfir_ticks_to_time_ns(long long ticks, double rate)
+{
+    const long long ratell = (long long)rate;
+    const long long full = ticks / ratell;
+    const long long err = ticks - full * ratell;
+    const double part = (double)full * (rate - (double)ratell);
+    const double frac = (((double)err - part) * 1e9) / rate;
+    return full * 1000000000LL + std::llround(frac);
+}
+
+long long sxfir_time_ns_to_ticks(long long time_ns, double rate)
+{
+    const long long ratell = (long long)rate;
+    const long long full = time_ns / 1000000000LL;
+    const long long err = time_ns - full * 1000000000LL;
+    const double part = (double)full * (rate - (double)ratell);
+    const double frac = part + ((double)err * rate) / 1e9;
+    return full * ratell + std::llround(frac);
+}
+
+static double i0(double x)
+{
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 500; ++k) {
+        term *= q / ((double)k * k);
+        sum += term;
+        if (term < sum * 1e-18) break;
+    }
+    return sum;
+}
+
+int sxfir_design_lowpass(int ntaps, int ratio, double beta, double gain, float *taps)
+{
+    if (ntaps < 1 || ratio < 1 || !taps) return fail(SXFIR_EINVAL, "bad argument");
+    std::vector<double> h((size_t)ntaps);
+    const double pi = 3.14159265358979323846;
+    const double centre = (ntaps - 1) / 2.0;
+    const double den = i0(beta);
+    double total = 0.0;
+    for (int k = 0; k < ntaps; ++k) {
+        const double t = k - centre;
+        const double arg = t / ratio;                       // 2*fc*t with fc = 0.5/ratio
+        const double sinc = (t == 0.0) ? 1.0 : std::sin(pi * arg) / (pi * arg);
+        double u = (centre > 0.0) ? t / centre : 0.0;
+        u = 1.0 - u * u;
+        const double win = i0(beta * std::sqrt(u > 0.0 ? u : 0.0)) / den;
+        h[(size_t)k] = sinc * win / ratio;
+        total += h[(size_t)k];
+    }
+    for (int k = 0; k < ntaps; ++k) taps[k] = (float)(h[(size_t)k] * (gain / total));
+    return SXFIR_OK;
+}
+
+int sxfir_malloc(void **dev, size_t bytes)
+{
+    if (!dev) return fail(SXFIR_EINVAL, "NULL argument");
+    *dev = nullptr;
+    hipError_t e = hipMalloc(dev, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return fail(SXFIR_ENOMEM, "hipMalloc(%zu) out of memory", bytes);
+    if (e != hipSuccess) return fail(SXFIR_EHIP, "hipMalloc: %s", hipGetErrorString(e));
+    return SXFIR_OK;
+}
+
+int sxfir_free(void *dev)
+{
+    if (dev) HIPCHECK(hipFree(dev));
+    return SXFIR_OK;
+}
+
+int sxfir_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+    return SXFIR_OK;
+}
+
+int sxfir_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+    return SXFIR_OK;
+}
+
+int sxfir_stream_sync(void *stream)
+{
+    HIPCHECK(hipStreamSynchronize(S(stream)));
+    return SXFIR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+// LDS-tiled polyphase FIR decimator for gfx950 (MI355X), decimate-by-4.
+//
+// This is new code: the reference (tejeez/sxxcvr) has no software FIR; the
+// SX1255 chip decimates in silicon and SoapySX.cpp:180-208 / :1197-1208 only
+// program its divider.  The kernel plays the role of that on-chip decimator,
+// feeding the stream that SoapySX::readStream (SoapySX.cpp:868-967) hands out.
+//
+// Work decomposition (wave64, one wave = one workgroup, no barriers):
+//   * a wave owns a contiguous run of tiles of one channel; a tile is 256
+//     outputs = 1024 input samples (8 KiB) plus a 128-sample halo;
+//   * the tile is staged in LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+//     wave-instruction, coalesced 16 B per lane), taps live in VGPRs;
+//   * lanes l and l+32 form a pair: both compute the same R = 8 consecutive
+//     outputs, lane half p = l >> 5 over the tap range [NT/2*p, NT/2*(p+1));
+//     each 16-byte ds_read_b128 (two complex samples) feeds up to 64 v_fma;
+//   * the two partial dot products are combined with v_permlane32_swap
+//     (gfx950) + one add, which also leaves outputs 0-3 on the low lane and
+//     4-7 on the high lane, so every lane stores 32 contiguous bytes.
+// LDS image: 16-byte chunks, one pad chunk after every 16, so the 16 lanes of
+// a ds_read_b128 group (lane stride 256 B) hit 16 different 16-byte slots.
+//
+// Numeric contract (DESIGN.md "Numeric contract", jsplit=2, cw=4): per output
+// and per I/Q, partial_p = fmaf chain from +0.0f over the taps of half p in
+// DESCENDING k; y = partial_0 + partial_1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sxfir {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DecimTileArgs {
+    const float *in;        // channel 0, sample 0 of this call (16-byte aligned)
+    const float *hist;      // channel 0 history: HIST samples preceding `in`
+    float *out;             // channel 0, first output of this call
+    const float *taps;      // NT floats (device)
+    long long n_in;         // new input samples per channel
+    long long n_out;        // outputs per channel
+    long long in_stride;    // samples between channels
+    long long out_stride;
+    long long hist_stride;
+    int tiles_per_wave;     // contiguous tiles owned by one wave
+    int n_tiles;            // tiles per channel
+};
+
+template <int NT>
+struct DecimTile4 {
+    static constexpr int D = 4;
+    static constexpr int R = 8;                       // outputs per lane
+    static constexpr int TPL = NT / 2;                // taps per lane
+    static constexpr int TILE_OUT = 32 * R;           // 256
+    static constexpr int TILE_IN = TILE_OUT * D;      // 1024
+    static constexpr int HALO = NT;                   // >= NT-1, multiple of 64
+    static constexpr int HIST = NT;                   // history samples kept per channel
+    static constexpr int CHUNKS = (TILE_IN + HALO) / 2;
+    static constexpr int SLOTS = CHUNKS + CHUNKS / 16;
+    static constexpr int NLOAD = (SLOTS + 63) / 64;
+    static constexpr int LDS_BYTES = NLOAD * 1024;
+    static constexpr int WMAX = D * (R - 1) + TPL;    // highest window sample index used
+    static constexpr int WCH = WMAX / 2 + 1;          // window chunks per lane
+    static_assert(NT % 64 == 0, "tile kernel needs NT % 64 == 0");
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, void *ldst)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
+{
+    using C = DecimTile4<NT>;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[C::NLOAD * 64];
+
+    const int lane = threadIdx.x;
+    const int g = lane & 31;
+    const int p = lane >> 5;
+    const int ch = blockIdx.y;
+
+    const float *in = a.in + 2 * a.in_stride * ch;
+    const float *hist = a.hist + 2 * a.hist_stride * ch;
+    float *out = a.out + 2 * a.out_stride * ch;
+
+    // taps of this lane's half, h[kl] = taps[TPL*p + kl]
+    float h[C::TPL];
+#pragma unroll
+    for (int k = 0; k < C::TPL; ++k) h[k] = a.taps[C::TPL * p + k];
+
+    // Source chunk (in 16-byte chunks relative to tile start - HALO) of every
+    // LDS slot this lane fills: slot q = 64*i + lane holds chunk q - q/17;
+    // q % 17 == 16 is a pad slot (re-loads its left neighbour, never read).
+    int coff[C::NLOAD];
+#pragma unroll
+    for (int i = 0; i < C::NLOAD; ++i) {
+        int q = 64 * i + lane;
+        if (q % 17 == 16) q -= 1;
+        int c = q - q / 17;
+        coff[i] = c < C::CHUNKS ? c : C::CHUNKS - 1;
+    }
+
+    // LDS byte address of this lane's window chunk 0
+    const int u0c = 16 * g - (NT / 4) * p + NT / 4;             // logical chunk, multiple of 16
+    const f32x4 *win = lds + (u0c + (u0c >> 4));
+
+    const long long last_chunk = (a.n_in - 1) >> 1;              // last input chunk holding a valid sample
+    const int tile_begin = blockIdx.x * a.tiles_per_wave;
+    int tile_end = tile_begin + a.tiles_per_wave;
+    if (tile_end > a.n_tiles) tile_end = a.n_tiles;
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const long long t0 = (long long)tile * C::TILE_IN;       // first input sample of the tile
+        const long long c0 = (t0 - C::HALO) >> 1;                // first chunk staged (may be negative)
+
+        // ---- stage: HBM -> LDS, no VGPR round trip -------------------------
+        const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= last_chunk);
+        if (interior) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(in) + c0;
+#pragma unroll
+            for (int i = 0; i < C::NLOAD; ++i) glds16(src + coff[i], lds + 64 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::NLOAD; ++i) {
+                long long c = c0 + coff[i];
+                const f32x4 *src;
+                if (c < 0) {
+                    src = reinterpret_cast<const f32x4 *>(hist) + (c + C::HIST / 2);
+                } else {
+                    if (c > last_chunk) c = last_chunk;
+                    src = reinterpret_cast<const f32x4 *>(in) + c;
+                }
+                glds16(src, lds + 64 * i);
+            }
+        }
+        // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // ---- compute: window sample w (ascending) meets output i at local tap
+        //      kl = 4*i + TPL - w; ascending w = descending k, per the contract
+        float ai[C::R], aq[C::R];
+#pragma unroll
+        for (int i = 0; i < C::R; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
+
+#pragma unroll
+        for (int t = 0; t < C::WCH; ++t) {
+            const f32x4 v = win[t + (t >> 4)];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int w = 2 * t + s;
+                const float xi = s ? v.z : v.x;
+                const float xq = s ? v.w : v.y;
+#pragma unroll
+                for (int i = 0; i < C::R; ++i) {
+                    const int kl = 4 * i + C::TPL - w;
+                    if (kl >= 0 && kl < C::TPL) {
+                        ai[i] = __builtin_fmaf(h[kl], xi, ai[i]);
+                        aq[i] = __builtin_fmaf(h[kl], xq, aq[i]);
+                    }
+                }
+            }
+        }
+
+        // ---- combine the two tap halves: lanes l (p=0) and l+32 (p=1) -------
+        // swap(vdst = acc[i], src = acc[i+4]): high half of acc[i] <-> low half
+        // of acc[i+4].  Afterwards acc[i] + acc[i+4] is partial_0 + partial_1 of
+        // output i on the low lane and of output i+4 on the high lane.
+        float oi[4], oq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            auto ri = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ai[i]),
+                                                       __builtin_bit_cast(unsigned, ai[i + 4]), false, false);
+            auto rq = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, aq[i]),
+                                                       __builtin_bit_cast(unsigned, aq[i + 4]), false, false);
+            oi[i] = __builtin_bit_cast(float, ri[0]) + __builtin_bit_cast(float, ri[1]);
+            oq[i] = __builtin_bit_cast(float, rq[0]) + __builtin_bit_cast(float, rq[1]);
+        }
+
+        // ---- store: 4 complex outputs (32 contiguous bytes) per lane ---------
+        const long long m = (long long)tile * C::TILE_OUT + 8 * g + 4 * p;
+        float *dst = out + 2 * m;
+        if (m + 4 <= a.n_out) {
+            *reinterpret_cast<f32x4 *>(dst) = (f32x4){oi[0], oq[0], oi[1], oq[1]};
+            *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){oi[2], oq[2], oi[3], oq[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m + i < a.n_out) { dst[2 * i] = oi[i]; dst[2 * i + 1] = oq[i]; }
+        }
+    }
+}
+
+}  // namespace sxfir

@@ -1,0 +1,148 @@
+"""Python face of the C ABI in include/sxfir.h.
+
+Device memory comes either from torch (complex64 / int32 CUDA tensors, the
+current torch stream is used) or from the library's own sxfir_malloc for
+numpy-only callers (``*_host`` helpers).  No arithmetic happens in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._native import check, load_sxfir
+
+DECIMATE, INTERPOLATE = 0, 1
+CF32, CF16 = 0, 1
+KERNEL_AUTO, KERNEL_TILED, KERNEL_GENERIC = 0, 1, 2
+_FMT = {"CF32": CF32, "CF16": CF16, CF32: CF32, CF16: CF16}
+
+
+def design_lowpass(ntaps, ratio, beta=8.0, gain=1.0):
+    lib = load_sxfir()
+    taps = np.empty(ntaps, dtype=np.float32)
+    check(lib.sxfir_design_lowpass(ntaps, ratio, beta, gain, taps.ctypes.data_as(C.c_void_p)))
+    return taps
+
+
+def _torch_stream(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def synth_fill(out, seed, first_channel=0, start=0, fmt="CF32"):
+    """Fill a CUDA tensor [nchan, n] (complex64 for CF32, int32 words for CF16)
+    with the synthetic IQ source."""
+    lib = load_sxfir()
+    t = out if out.dim() == 2 else out.unsqueeze(0)
+    nchan, n = t.shape
+    check(lib.sxfir_synth_fill(C.c_void_p(t.data_ptr()), n, t.stride(0), nchan, seed, first_channel, start,
+                               _FMT[fmt], _torch_stream(t)))
+    return out
+
+
+class Resampler:
+    """One sxfir plan: `nchan` independent channels of one GPU."""
+
+    def __init__(self, mode, taps, ratio, nchan=1, fmt="CF32", device=-1):
+        self._lib = load_sxfir()
+        self._plan = C.c_void_p()
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        self.mode, self.ratio, self.nchan, self.fmt, self.ntaps = mode, int(ratio), int(nchan), _FMT[fmt], taps.size
+        check(self._lib.sxfir_create(C.byref(self._plan), mode, taps.ctypes.data_as(C.c_void_p), taps.size,
+                                     int(ratio), int(nchan), self.fmt, int(device)))
+
+    def close(self):
+        if self._plan:
+            self._lib.sxfir_destroy(self._plan)
+            self._plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- introspection --------------------------------------------------------
+    @property
+    def contract(self):
+        a, b = C.c_int(), C.c_int()
+        check(self._lib.sxfir_contract(self._plan, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @property
+    def position(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self._lib.sxfir_position(self._plan, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def outputs_for(self, n_in):
+        n = C.c_size_t()
+        check(self._lib.sxfir_outputs_for(self._plan, n_in, C.byref(n)))
+        return n.value
+
+    def set_kernel(self, kernel):
+        check(self._lib.sxfir_set_kernel(self._plan, kernel))
+
+    def reset(self, stream=None):
+        check(self._lib.sxfir_reset(self._plan, C.c_void_p(stream or 0)))
+
+    # -- raw pointers ---------------------------------------------------------
+    def process_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, stream=0):
+        n_out = C.c_size_t()
+        fn = self._lib.sxfir_decimate if self.mode == DECIMATE else self._lib.sxfir_interpolate
+        check(fn(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr), out_stride, C.byref(n_out),
+                 C.c_void_p(stream)))
+        return n_out.value
+
+    def time_decimate_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream=0):
+        ms = C.c_float()
+        check(self._lib.sxfir_time_decimate(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+                                            out_stride, iters, C.c_void_p(stream), C.byref(ms)))
+        return ms.value
+
+    # -- torch tensors --------------------------------------------------------
+    def process(self, x, out=None):
+        """x: CUDA tensor [nchan, n] or [n]; complex64 (CF32) or int32 words (CF16)."""
+        import torch
+        squeeze = x.dim() == 1
+        x2 = x.unsqueeze(0) if squeeze else x
+        if x2.shape[0] != self.nchan or x2.stride(1) != 1:
+            raise ValueError("expected a [nchan=%d, n] tensor with unit sample stride" % self.nchan)
+        n_in = x2.shape[1]
+        n_out = self.outputs_for(n_in)
+        if out is None:
+            out = torch.empty((self.nchan, n_out), dtype=x2.dtype, device=x2.device)
+        o2 = out.unsqueeze(0) if out.dim() == 1 else out
+        got = self.process_ptr(x2.data_ptr(), n_in, x2.stride(0) if self.nchan > 1 else n_in, o2.data_ptr(),
+                               o2.stride(0) if self.nchan > 1 else max(n_out, 1),
+                               torch.cuda.current_stream(x2.device).cuda_stream)
+        assert got == n_out
+        res = o2[:, :n_out]
+        return res[0] if squeeze else res
+
+    # -- numpy host arrays (library-owned device memory) ----------------------
+    def process_host(self, x):
+        """x: complex64 numpy [nchan, n] or [n] (CF32 plans only).  Copies to the
+        GPU, runs the HIP path, copies back."""
+        if self.fmt != CF32:
+            raise ValueError("process_host handles CF32 plans")
+        lib = self._lib
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        squeeze = x.ndim == 1
+        x2 = x.reshape(1, -1) if squeeze else x
+        nchan, n_in = x2.shape
+        n_out = self.outputs_for(n_in)
+        y = np.empty((nchan, n_out), dtype=np.complex64)
+        din, dout = C.c_void_p(), C.c_void_p()
+        check(lib.sxfir_malloc(C.byref(din), max(x2.nbytes, 16)))
+        check(lib.sxfir_malloc(C.byref(dout), max(y.nbytes, 16)))
+        try:
+            if x2.nbytes:
+                check(lib.sxfir_memcpy_h2d(din, x2.ctypes.data_as(C.c_void_p), x2.nbytes, None))
+            self.process_ptr(din.value, n_in, n_in, dout.value, max(n_out, 1))
+            if y.nbytes:
+                check(lib.sxfir_memcpy_d2h(y.ctypes.data_as(C.c_void_p), dout, y.nbytes, None))
+            check(lib.sxfir_stream_sync(None))
+        finally:
+            lib.sxfir_free(din)
+            lib.sxfir_free(dout)
+        return y[0] if squeeze else y

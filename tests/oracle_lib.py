@@ -58,11 +58,12 @@ def _load(name):
     for f in (lib.sxo_decim_f64, lib.sxo_interp_f64):
         f.restype = C.c_int
         f.argtypes = [vp, C.c_int, C.c_int, vp, sz, i64, sz, vp]
-    for f in (lib.sxo_decim_f32, lib.sxo_interp_f32):
-        f.restype = C.c_int
-        f.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp]
+    lib.sxo_interp_f32.restype = C.c_int
+    lib.sxo_interp_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp]
+    lib.sxo_decim_f32.restype = C.c_int
+    lib.sxo_decim_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp]
     lib.sxo_decim_f32_mt.restype = C.c_int
-    lib.sxo_decim_f32_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp, C.c_int]
+    lib.sxo_decim_f32_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp, C.c_int]
     lib.sxo_max_threads.restype = C.c_int
     lib.sxo_f32_to_f16.argtypes = [vp, vp, sz]
     lib.sxo_f16_to_f32.argtypes = [vp, vp, sz]
@@ -116,7 +117,7 @@ class Oracle:
         y = np.empty(n_out, dtype=np.complex64)
         args = [_fp(h), h.size, int(ratio)]
         if groups is not None:
-            args.append(int(groups))
+            args += [int(g) for g in (groups if isinstance(groups, tuple) else (groups,))]
         args += [_fp(x), x.size, int(o0), n_out, _fp(y)]
         if threads is not None:
             args.append(int(threads))
@@ -129,11 +130,13 @@ class Oracle:
         n_out = (len(x) + D - 1) // D - m0 if n_out is None else n_out
         return self._run(self.lib.sxo_decim_f64, h, D, x, m0, n_out)
 
-    def decim_f32(self, h, D, x, groups, m0=0, n_out=None, threads=None):
+    def decim_f32(self, h, D, x, jsplit=1, cw=None, m0=0, n_out=None, threads=None):
+        """Order-matched fp32 decimator; (jsplit, cw) is the kernel's contract."""
         n_out = (len(x) + D - 1) // D - m0 if n_out is None else n_out
+        g = (jsplit, D if cw is None else cw)
         if threads is None:
-            return self._run(self.lib.sxo_decim_f32, h, D, x, m0, n_out, groups=groups)
-        return self._run(self.lib.sxo_decim_f32_mt, h, D, x, m0, n_out, groups=groups, threads=threads)
+            return self._run(self.lib.sxo_decim_f32, h, D, x, m0, n_out, groups=g)
+        return self._run(self.lib.sxo_decim_f32_mt, h, D, x, m0, n_out, groups=g, threads=threads)
 
     def interp_f64(self, h, L, x, n0=0, n_out=None):
         n_out = len(x) * L - n0 if n_out is None else n_out

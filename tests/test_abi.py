@@ -1,0 +1,81 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol that include/sxfir.h declares; host-only entry points work; the
+product refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sxxcvr_amd
+from sxxcvr_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:sxfir|sx_device)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_sxfir_exports_every_declared_symbol():
+    lib = sxxcvr_amd.load_sxfir()
+    names = _declared("sxfir.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libsxfir.so does not export " + n
+    # and the python binding declares a prototype for each of them
+    assert set(names) <= set(lib._sx_signatures), set(names) - set(lib._sx_signatures)
+    assert lib.sxfir_abi_version() == 1
+
+
+def test_time_arithmetic_matches_oracle(oracle):
+    lib = sxxcvr_amd.load_sxfir()
+    for clock in (32.0e6, 38.4e6):
+        for div in (1536, 768, 512, 256, 128, 64):
+            rate = clock / div
+            for t in (0, 1, 255, 256, 768, 65536, 10 ** 9 + 7, 123456789012):
+                ns = lib.sxfir_ticks_to_time_ns(t, rate)
+                assert ns == oracle.ticks_to_time_ns(t, rate)
+                assert lib.sxfir_time_ns_to_ticks(ns, rate) == t
+                assert lib.sxfir_time_ns_to_ticks(ns + 12345, rate) == oracle.time_ns_to_ticks(ns + 12345, rate)
+
+
+def test_tap_designer_matches_fixture(golden_dir):
+    taps = np.load(os.path.join(golden_dir, "taps.npz"))
+    for name, (n, r, g) in {"n128_d4": (128, 4, 1.0), "n256_d8": (256, 8, 1.0), "n256_l8": (256, 8, 8.0),
+                            "n1024_d32": (1024, 32, 1.0)}.items():
+        got = sxxcvr_amd.design_lowpass(n, r, 8.0, g)
+        d = np.abs(got.view(np.int32).astype(np.int64) - taps[name].view(np.int32).astype(np.int64))
+        assert d.max() <= 1, name
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly, never compute on the host."""
+    import ctypes as C
+    lib = sxxcvr_amd.load_sxfir()
+    n = C.c_int(-1)
+    lib.sxfir_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sxxcvr_amd.NativeError) as ei:
+        sxxcvr_amd.Resampler(0, np.ones(128, dtype=np.float32), 4)
+    assert ei.value.code == -5
+
+
+def test_product_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing in the package may reference it."""
+    pkg = os.path.join(ROOT, "sxxcvr_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "sx_oracle" not in text and "libsxoracle" not in text and "oracle_lib" not in text, f
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_sxfir", None)
+    monkeypatch.setattr(_native, "LIBDIR", str(tmp_path))
+    with pytest.raises(ImportError):
+        _native.load_sxfir()
