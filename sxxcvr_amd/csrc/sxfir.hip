@@ -241,8 +241,8 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     const long long D = p->ratio;
     const long long first = ((p->consumed + D - 1) / D) * D - p->consumed;
     bool tiled = p->tile_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
-                 ((uintptr_t)in_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && in_stride % 2 == 0 &&
-                 out_stride % 2 == 0;
+                 ((uintptr_t)in_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) &&
+                 (p->nchan == 1 || (in_stride % 2 == 0 && out_stride % 2 == 0));
     if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
         return fail(SXFIR_EUNSUPPORTED,
                     "tiled kernel needs 16-byte aligned buffers, even strides and a call that starts on an "
@@ -305,7 +305,7 @@ static int check_io(const sxfir_plan *p, int mode, const void *in_dev, size_t n_
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
     if (p->mode != mode) return fail(SXFIR_EINVAL, "plan was created for the other direction");
-    if (n_in && (!in_dev || !out_dev)) return fail(SXFIR_EINVAL, "NULL device buffer");
+    if ((n_in && !in_dev) || (n_out > 0 && !out_dev)) return fail(SXFIR_EINVAL, "NULL device buffer");
     if (p->nchan > 1 && (in_stride < n_in || out_stride < (size_t)n_out))
         return fail(SXFIR_EINVAL, "channel stride smaller than the block");
     if ((uintptr_t)in_dev % sample_bytes(p->fmt) || (uintptr_t)out_dev % sample_bytes(p->fmt))

@@ -69,6 +69,17 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *ldst)
                                      (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
 }
 
+// v_permlane32_swap_b32 vdst, src (gfx950): lanes 32-63 of vdst <-> lanes 0-31
+// of src.  Inline asm on purpose: with two DIFFERENT operands hipcc 7.2's
+// __builtin_amdgcn_permlane32_swap returns the first result register for both
+// elements of its result pair (seen in the .s: "v_permlane32_swap v1, v2" then
+// v1 used for r[0] and r[1]).  "s_nop 1" = the 2 wait states the ISA requires
+// between a VALU write of an operand and the swap.
+__device__ __forceinline__ void permlane32_swap(float &vdst, float &src)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(vdst), "+v"(src));
+}
+
 template <int NT>
 __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
 {
@@ -169,12 +180,10 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
         float oi[4], oq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            auto ri = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ai[i]),
-                                                       __builtin_bit_cast(unsigned, ai[i + 4]), false, false);
-            auto rq = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, aq[i]),
-                                                       __builtin_bit_cast(unsigned, aq[i + 4]), false, false);
-            oi[i] = __builtin_bit_cast(float, ri[0]) + __builtin_bit_cast(float, ri[1]);
-            oq[i] = __builtin_bit_cast(float, rq[0]) + __builtin_bit_cast(float, rq[1]);
+            permlane32_swap(ai[i], ai[i + 4]);
+            permlane32_swap(aq[i], aq[i + 4]);
+            oi[i] = __fadd_rn(ai[i], ai[i + 4]);
+            oq[i] = __fadd_rn(aq[i], aq[i + 4]);
         }
 
         // ---- store: 4 complex outputs (32 contiguous bytes) per lane ---------
