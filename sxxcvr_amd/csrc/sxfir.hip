@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -47,6 +48,10 @@ struct sxfir_plan {
     int hist_len;          // samples of history kept per channel
     int jsplit, cw;        // numeric contract
     bool tile_capable;
+    bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
+    int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
+    int oversub;           // waves launched = CUs * occupancy * oversub
+    int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int compute_units;
     float *taps_dev;
     void *hist_dev;        // nchan * hist_len samples
@@ -143,6 +148,29 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         p->tile_capable = false;
         p->jsplit = (jt % 2 == 0) ? 2 : 1;
         p->cw = 1;
+    }
+
+    // measured on MI355X (tools/kbench.py): single-buffered LDS-DMA at 16 waves/CU with four
+    // generations of waves beats the double-buffered variant at 8 waves/CU
+    p->tile_dbuf = false;
+    p->occ_sb = p->occ_db = 8;
+    p->oversub = 4;
+    p->ablate = 0;
+    if (p->tile_capable) {
+        int nb = 0;
+        const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
+                                       : (const void *)sxfir::decim4_tile_kernel<64, false>;
+        const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
+                                       : (const void *)sxfir::decim4_tile_kernel<64, true>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kdb, 64, 0) == hipSuccess && nb > 0) p->occ_db = nb;
+        // experiment knobs (profiling only; defaults are what ships)
+        if (const char *v = getenv("SXFIR_TILE_VARIANT")) p->tile_dbuf = (strcmp(v, "sb") != 0);
+        if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
+        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
+        if (const char *v = getenv("SXFIR_OCC")) {
+            if (atoi(v) > 0) p->occ_sb = p->occ_db = atoi(v);
+        }
     }
 
     hipError_t e = hipMalloc((void **)&p->taps_dev, sizeof(float) * (size_t)ntaps);
@@ -261,18 +289,26 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         const int tile_out = 256;
         const long long n_tiles = (n_out + tile_out - 1) / tile_out;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
-        // ~16 resident waves per CU; give each wave a contiguous run of tiles
-        const long long want_waves = (long long)p->compute_units * 16 * 4;
-        long long tpw = (n_tiles + want_waves - 1) / want_waves;
-        if (tpw < 1) tpw = 1;
-        const long long waves = (n_tiles + tpw - 1) / tpw;
-        a.tiles_per_wave = (int)tpw;
+        // One resident generation of waves: every wave owns a contiguous run of tiles, so there is
+        // no tail of partly filled dispatch rounds and halo re-reads stay in the wave's own L1/L2.
+        const bool dbuf = p->tile_dbuf;
+        long long per_chan = ((long long)p->compute_units * (dbuf ? p->occ_db : p->occ_sb) * p->oversub) / p->nchan;
+        if (per_chan < 1) per_chan = 1;
+        if (per_chan > n_tiles) per_chan = n_tiles;
         a.n_tiles = (int)n_tiles;
-        dim3 grid((unsigned)waves, (unsigned)p->nchan);
-        if (p->ntaps == 128)
-            hipLaunchKernelGGL(sxfir::decim4_tile_kernel<128>, grid, dim3(64), 0, st, a);
-        else
-            hipLaunchKernelGGL(sxfir::decim4_tile_kernel<64>, grid, dim3(64), 0, st, a);
+        a.n_waves = (int)per_chan;
+        dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
+        if (p->ntaps == 128 && p->ablate == 1) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 1>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 2) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 2>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128) {
+            if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);
+        } else {
+            if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, true>), grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, false>), grid, dim3(64), 0, st, a);
+        }
     } else {
         sxfir::GenericArgs a;
         a.in = in_dev;

@@ -9,7 +9,9 @@
 //   * a wave owns a contiguous run of tiles of one channel; a tile is 256
 //     outputs = 1024 input samples (8 KiB) plus a 128-sample halo;
 //   * the tile is staged in LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-//     wave-instruction, coalesced 16 B per lane), taps live in VGPRs;
+//     wave-instruction, coalesced 16 B per lane), taps live in VGPRs; with
+//     DBUF the next tile's DMA is issued before the current tile is computed
+//     and retired by a counted s_waitcnt vmcnt (two LDS buffers per wave);
 //   * lanes l and l+32 form a pair: both compute the same R = 8 consecutive
 //     outputs, lane half p = l >> 5 over the tap range [NT/2*p, NT/2*(p+1));
 //     each 16-byte ds_read_b128 (two complex samples) feeds up to 64 v_fma;
@@ -41,8 +43,8 @@ struct DecimTileArgs {
     long long in_stride;    // samples between channels
     long long out_stride;
     long long hist_stride;
-    int tiles_per_wave;     // contiguous tiles owned by one wave
     int n_tiles;            // tiles per channel
+    int n_waves;            // waves (workgroups) per channel; tiles are dealt in contiguous runs
 };
 
 template <int NT>
@@ -57,7 +59,7 @@ struct DecimTile4 {
     static constexpr int CHUNKS = (TILE_IN + HALO) / 2;
     static constexpr int SLOTS = CHUNKS + CHUNKS / 16;
     static constexpr int NLOAD = (SLOTS + 63) / 64;
-    static constexpr int LDS_BYTES = NLOAD * 1024;
+    static constexpr int BUF_SLOTS = NLOAD * 64;
     static constexpr int WMAX = D * (R - 1) + TPL;    // highest window sample index used
     static constexpr int WCH = WMAX / 2 + 1;          // window chunks per lane
     static_assert(NT % 64 == 0, "tile kernel needs NT % 64 == 0");
@@ -81,121 +83,187 @@ __device__ __forceinline__ void permlane32_swap(float &vdst, float &src)
 }
 
 template <int NT>
+struct DecimTileCtx {
+    const float *in, *hist;
+    float *out;
+    long long n_out, last_chunk;
+    int lane, g, p;
+};
+
+// HBM -> LDS for one tile, no VGPR round trip.  Slot q = 64*i + lane of the
+// buffer holds logical chunk q - (q+1)/17 (a pad slot re-loads its left
+// neighbour and is never read).
+template <int NT>
+__device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, f32x4 *buf)
+{
+    using C = DecimTile4<NT>;
+    const long long c0 = ((long long)tile * C::TILE_IN - C::HALO) >> 1;   // first chunk staged (may be < 0)
+    const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk);
+    if (interior) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(c.in) + c0;
+#pragma unroll
+        for (int i = 0; i < C::NLOAD; ++i) {
+            const unsigned q = 64u * i + c.lane;
+            unsigned off = q - (((q + 1u) * 3856u) >> 16);                // (q+1)/17, exact for q < 4096
+            off = off < (unsigned)C::CHUNKS ? off : (unsigned)C::CHUNKS - 1u;
+            glds16(src + off, buf + 64 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C::NLOAD; ++i) {
+            const unsigned q = 64u * i + c.lane;
+            unsigned off = q - (((q + 1u) * 3856u) >> 16);
+            off = off < (unsigned)C::CHUNKS ? off : (unsigned)C::CHUNKS - 1u;
+            long long ch = c0 + off;
+            const f32x4 *src;
+            if (ch < 0) {
+                src = reinterpret_cast<const f32x4 *>(c.hist) + (ch + C::HIST / 2);
+            } else {
+                if (ch > c.last_chunk) ch = c.last_chunk;
+                src = reinterpret_cast<const f32x4 *>(c.in) + ch;
+            }
+            glds16(src, buf + 64 * i);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,
+                                             const float (&h)[NT / 2])
+{
+    using C = DecimTile4<NT>;
+    // window sample w (ascending) meets output i at local tap kl = 4*i + TPL - w;
+    // ascending w = descending k, per the contract
+    float ai[C::R], aq[C::R];
+#pragma unroll
+    for (int i = 0; i < C::R; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
+
+#pragma unroll
+    for (int t = 0; t < C::WCH; ++t) {
+        const f32x4 v = win[t + (t >> 4)];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int w = 2 * t + s;
+            const float xi = s ? v.z : v.x;
+            const float xq = s ? v.w : v.y;
+#pragma unroll
+            for (int i = 0; i < C::R; ++i) {
+                const int kl = 4 * i + C::TPL - w;
+                if (kl >= 0 && kl < C::TPL) {
+                    ai[i] = __builtin_fmaf(h[kl], xi, ai[i]);
+                    aq[i] = __builtin_fmaf(h[kl], xq, aq[i]);
+                }
+            }
+        }
+    }
+
+    // combine the two tap halves: lanes l (p=0) and l+32 (p=1).
+    // swap(vdst = acc[i], src = acc[i+4]): high half of acc[i] <-> low half of
+    // acc[i+4].  Afterwards acc[i] + acc[i+4] is partial_0 + partial_1 of output
+    // i on the low lane and of output i+4 on the high lane.
+    float oi[4], oq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        permlane32_swap(ai[i], ai[i + 4]);
+        permlane32_swap(aq[i], aq[i + 4]);
+        oi[i] = __fadd_rn(ai[i], ai[i + 4]);
+        oq[i] = __fadd_rn(aq[i], aq[i + 4]);
+    }
+
+    // 4 complex outputs (32 contiguous bytes) per lane
+    const long long m = (long long)tile * C::TILE_OUT + 8 * c.g + 4 * c.p;
+    float *dst = c.out + 2 * m;
+    if (m + 4 <= c.n_out) {
+        *reinterpret_cast<f32x4 *>(dst) = (f32x4){oi[0], oq[0], oi[1], oq[1]};
+        *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){oi[2], oq[2], oi[3], oq[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (m + i < c.n_out) { dst[2 * i] = oi[i]; dst[2 * i + 1] = oq[i]; }
+    }
+}
+
+#define SXFIR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// ABL (profiling builds only): 0 = the real kernel, 1 = stage + store but no FIR arithmetic
+// (memory side alone), 2 = FIR arithmetic on whatever LDS holds, no staging (compute side alone).
+template <int NT, bool DBUF, int ABL = 0>
 __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
 {
     using C = DecimTile4<NT>;
-    __shared__ __attribute__((aligned(16))) f32x4 lds[C::NLOAD * 64];
+    __shared__ __attribute__((aligned(16))) f32x4 lds[(DBUF ? 2 : 1) * C::BUF_SLOTS];
 
-    const int lane = threadIdx.x;
-    const int g = lane & 31;
-    const int p = lane >> 5;
+    DecimTileCtx<NT> c;
+    c.lane = threadIdx.x;
+    c.g = c.lane & 31;
+    c.p = c.lane >> 5;
     const int ch = blockIdx.y;
-
-    const float *in = a.in + 2 * a.in_stride * ch;
-    const float *hist = a.hist + 2 * a.hist_stride * ch;
-    float *out = a.out + 2 * a.out_stride * ch;
+    c.in = a.in + 2 * a.in_stride * ch;
+    c.hist = a.hist + 2 * a.hist_stride * ch;
+    c.out = a.out + 2 * a.out_stride * ch;
+    c.n_out = a.n_out;
+    c.last_chunk = (a.n_in - 1) >> 1;                 // last input chunk holding a valid sample
 
     // taps of this lane's half, h[kl] = taps[TPL*p + kl]
     float h[C::TPL];
 #pragma unroll
-    for (int k = 0; k < C::TPL; ++k) h[k] = a.taps[C::TPL * p + k];
+    for (int k = 0; k < C::TPL; ++k) h[k] = a.taps[C::TPL * c.p + k];
 
-    // Source chunk (in 16-byte chunks relative to tile start - HALO) of every
-    // LDS slot this lane fills: slot q = 64*i + lane holds chunk q - q/17;
-    // q % 17 == 16 is a pad slot (re-loads its left neighbour, never read).
-    int coff[C::NLOAD];
-#pragma unroll
-    for (int i = 0; i < C::NLOAD; ++i) {
-        int q = 64 * i + lane;
-        if (q % 17 == 16) q -= 1;
-        int c = q - q / 17;
-        coff[i] = c < C::CHUNKS ? c : C::CHUNKS - 1;
-    }
+    // this lane's window chunk 0 inside a buffer
+    const int u0c = 16 * c.g - (NT / 4) * c.p + NT / 4;   // logical chunk, multiple of 16
+    const f32x4 *win0 = lds + (u0c + (u0c >> 4));
 
-    // LDS byte address of this lane's window chunk 0
-    const int u0c = 16 * g - (NT / 4) * p + NT / 4;             // logical chunk, multiple of 16
-    const f32x4 *win = lds + (u0c + (u0c >> 4));
+    // contiguous run of tiles for this wave (balanced to within one tile)
+    const int wave = blockIdx.x;
+    const int base = a.n_tiles / a.n_waves, extra = a.n_tiles % a.n_waves;
+    const int tile_begin = wave * base + (wave < extra ? wave : extra);
+    const int tile_end = tile_begin + base + (wave < extra ? 1 : 0);
+    if (tile_begin >= tile_end) return;
 
-    const long long last_chunk = (a.n_in - 1) >> 1;              // last input chunk holding a valid sample
-    const int tile_begin = blockIdx.x * a.tiles_per_wave;
-    int tile_end = tile_begin + a.tiles_per_wave;
-    if (tile_end > a.n_tiles) tile_end = a.n_tiles;
-
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const long long t0 = (long long)tile * C::TILE_IN;       // first input sample of the tile
-        const long long c0 = (t0 - C::HALO) >> 1;                // first chunk staged (may be negative)
-
-        // ---- stage: HBM -> LDS, no VGPR round trip -------------------------
-        const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= last_chunk);
-        if (interior) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(in) + c0;
-#pragma unroll
-            for (int i = 0; i < C::NLOAD; ++i) glds16(src + coff[i], lds + 64 * i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < C::NLOAD; ++i) {
-                long long c = c0 + coff[i];
-                const f32x4 *src;
-                if (c < 0) {
-                    src = reinterpret_cast<const f32x4 *>(hist) + (c + C::HIST / 2);
-                } else {
-                    if (c > last_chunk) c = last_chunk;
-                    src = reinterpret_cast<const f32x4 *>(in) + c;
-                }
-                glds16(src, lds + 64 * i);
-            }
-        }
-        // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-        // ---- compute: window sample w (ascending) meets output i at local tap
-        //      kl = 4*i + TPL - w; ascending w = descending k, per the contract
-        float ai[C::R], aq[C::R];
-#pragma unroll
-        for (int i = 0; i < C::R; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
-
-#pragma unroll
-        for (int t = 0; t < C::WCH; ++t) {
-            const f32x4 v = win[t + (t >> 4)];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int w = 2 * t + s;
-                const float xi = s ? v.z : v.x;
-                const float xq = s ? v.w : v.y;
-#pragma unroll
-                for (int i = 0; i < C::R; ++i) {
-                    const int kl = 4 * i + C::TPL - w;
-                    if (kl >= 0 && kl < C::TPL) {
-                        ai[i] = __builtin_fmaf(h[kl], xi, ai[i]);
-                        aq[i] = __builtin_fmaf(h[kl], xq, aq[i]);
-                    }
+    if constexpr (!DBUF) {
+        for (int tile = tile_begin; tile < tile_end; ++tile) {
+            if constexpr (ABL != 2) stage_tile<NT>(c, tile, lds);
+            // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
+            SXFIR_WAIT_VMCNT(0);
+            if constexpr (ABL != 1) {
+                compute_tile<NT>(c, tile, win0, h);
+            } else {
+                const f32x4 v0 = win0[0], v1 = win0[17];
+                const long long m = (long long)tile * C::TILE_OUT + 8 * c.g + 4 * c.p;
+                float *dst = c.out + 2 * m;
+                if (m + 4 <= c.n_out) {
+                    *reinterpret_cast<f32x4 *>(dst) = v0 + h[0];
+                    *reinterpret_cast<f32x4 *>(dst + 4) = v1 + h[63 % C::TPL];
                 }
             }
         }
-
-        // ---- combine the two tap halves: lanes l (p=0) and l+32 (p=1) -------
-        // swap(vdst = acc[i], src = acc[i+4]): high half of acc[i] <-> low half
-        // of acc[i+4].  Afterwards acc[i] + acc[i+4] is partial_0 + partial_1 of
-        // output i on the low lane and of output i+4 on the high lane.
-        float oi[4], oq[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            permlane32_swap(ai[i], ai[i + 4]);
-            permlane32_swap(aq[i], aq[i + 4]);
-            oi[i] = __fadd_rn(ai[i], ai[i + 4]);
-            oq[i] = __fadd_rn(aq[i], aq[i + 4]);
-        }
-
-        // ---- store: 4 complex outputs (32 contiguous bytes) per lane ---------
-        const long long m = (long long)tile * C::TILE_OUT + 8 * g + 4 * p;
-        float *dst = out + 2 * m;
-        if (m + 4 <= a.n_out) {
-            *reinterpret_cast<f32x4 *>(dst) = (f32x4){oi[0], oq[0], oi[1], oq[1]};
-            *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){oi[2], oq[2], oi[3], oq[3]};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (m + i < a.n_out) { dst[2 * i] = oi[i]; dst[2 * i + 1] = oq[i]; }
+    } else {
+        // vmcnt bookkeeping (in issue order): every stage_tile issues exactly NLOAD DMAs, and the
+        // stores of tile-1 are older than the prefetch of tile+1.  After issuing that prefetch the
+        // DMAs of `tile` have landed once at most NLOAD operations remain outstanding.
+        static_assert(C::NLOAD == 10 || C::NLOAD == 6, "vmcnt immediates below assume NLOAD");
+        const f32x4 *win1 = win0 + C::BUF_SLOTS;
+        stage_tile<NT>(c, tile_begin, lds);
+        int tile = tile_begin;
+        while (true) {
+            // even phase: compute from buffer 0, prefetch into buffer 1
+            if (tile + 1 < tile_end) {
+                stage_tile<NT>(c, tile + 1, lds + C::BUF_SLOTS);
+                if constexpr (C::NLOAD == 10) SXFIR_WAIT_VMCNT(10); else SXFIR_WAIT_VMCNT(6);
+            } else {
+                SXFIR_WAIT_VMCNT(0);
+            }
+            compute_tile<NT>(c, tile, win0, h);
+            if (++tile >= tile_end) break;
+            // odd phase: compute from buffer 1, prefetch into buffer 0
+            if (tile + 1 < tile_end) {
+                stage_tile<NT>(c, tile + 1, lds);
+                if constexpr (C::NLOAD == 10) SXFIR_WAIT_VMCNT(10); else SXFIR_WAIT_VMCNT(6);
+            } else {
+                SXFIR_WAIT_VMCNT(0);
+            }
+            compute_tile<NT>(c, tile, win1, h);
+            if (++tile >= tile_end) break;
         }
     }
 }

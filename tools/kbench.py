@@ -1,0 +1,49 @@
+"""Kernel-variant A/B on one GPU, interleaved rounds in one process (profiling aid)."""
+import os, sys, itertools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import sxxcvr_amd
+from sxxcvr_amd.resampler import DECIMATE
+
+log2n = int(os.environ.get("KB_LOG2N", "28"))
+rounds = int(os.environ.get("KB_ROUNDS", "5"))
+iters = int(os.environ.get("KB_ITERS", "10"))
+nchan = int(os.environ.get("KB_NCHAN", "1"))
+configs = []
+for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
+    f = spec.split(":")
+    v, ov, occ = f[0], f[1], f[2]
+    configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0))
+
+n = (1 << log2n) // nchan
+x = torch.empty((nchan, n), dtype=torch.complex64, device="cuda")
+sxxcvr_amd.synth_fill(x, 0x51255, 0, 0)
+y = torch.empty((nchan, n // 4), dtype=torch.complex64, device="cuda")
+taps = sxxcvr_amd.design_lowpass(128, 4)
+plans = []
+for v, ov, occ, abl in configs:
+    os.environ["SXFIR_TILE_VARIANT"] = v
+    os.environ["SXFIR_OVERSUB"] = str(ov)
+    os.environ["SXFIR_ABLATE"] = str(abl)
+    if occ: os.environ["SXFIR_OCC"] = str(occ)
+    else: os.environ.pop("SXFIR_OCC", None)
+    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, 4, nchan=nchan))
+ref = None
+res = {c: [] for c in configs}
+st = torch.cuda.current_stream().cuda_stream
+for r in range(rounds):
+    for c, p in zip(configs, plans):
+        p.reset()
+        ms = p.time_decimate_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 4, iters, st)
+        res[c].append(ms)
+        if r == 0:
+            torch.cuda.synchronize()
+            chk = torch.view_as_real(y).view(torch.int32).sum(dtype=torch.int64).item()
+            if ref is None: ref = chk
+            print("config", c, "checksum", "same" if chk == ref else "DIFFERENT")
+for c in configs:
+    a = np.array(res[c])
+    gbs = 10.0 * (1 << log2n) / (a * 1e-3) / 1e9
+    print("%-12s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
+        "%s:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
