@@ -41,14 +41,20 @@ def _deps(*dirs):
     return out
 
 
+# libsxfir.so: HIP kernels + the extern "C" shim, built by hipcc for gfx950.
+# libSXSupport.so: host-only C++ (no HIP headers): the SoapySDR Device module, its flat C view and,
+# because the real SoapySDR headers/library are absent in this image, the API-compatible subset under
+# csrc/compat.  It reaches the GPU only through libsxfir.so's C ABI.
 TARGETS = {
     "libsxfir.so": {
+        "compiler": "hipcc",
         "sources": ["sxfir.hip"],
-        "flags": [],
+        "flags": ["--offload-arch=" + ARCH, "-O3"],
     },
     "libSXSupport.so": {
-        "sources": ["SoapySXHip.cpp", "sx_device_capi.cpp"],
-        "flags": ["-x", "hip", "-I" + os.path.join(CSRC, "compat")],
+        "compiler": "g++",
+        "sources": ["SoapySXHip.cpp", "sx_device_capi.cpp", "compat/SoapySDRCompat.cpp"],
+        "flags": ["-O2", "-ffp-contract=off", "-pthread", "-I" + os.path.join(CSRC, "compat")],
         "libs": ["-L" + LIBDIR, "-lsxfir", "-Wl,-rpath,$ORIGIN"],
     },
 }
@@ -65,9 +71,9 @@ def build(force=False, verbose=False):
         out = os.path.join(LIBDIR, name)
         if not (force or _newer(out, deps)):
             continue
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + \
-              ["-o", out] + spec.get("libs", [])
+        cc = hipcc() if spec["compiler"] == "hipcc" else (shutil.which("g++") or "g++")
+        cmd = [cc, "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+               "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + ["-o", out] + spec.get("libs", [])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

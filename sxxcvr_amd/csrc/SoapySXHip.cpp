@@ -1,0 +1,600 @@
+// SoapySDR Device module "sx" for MI355X: the Device/Stream plugin surface of
+// tejeez/sxxcvr (class SoapySX, SoapySX/SoapySX.cpp:524-1656) with the
+// SX1255-over-I2S/ALSA sample feed replaced by a synthetic CF32 IQ source/sink
+// and the chip's decimator/interpolator replaced by HIP kernels reached
+// through the extern "C" shim of include/sxfir.h.
+//
+// Kept with the reference's meaning (file:line = SoapySX/SoapySX.cpp):
+//   stream lifecycle + arguments threshold/link/period ........ :740-866
+//   readStream: overrun skip, non-blocking clamp, timestamps ... :868-967
+//   writeStream: timed placement, past-discard, underrun skip .. :969-1105
+//   getHardwareTime / hasHardwareTime .......................... :1107-1139, :1618-1623
+//   sample-rate table and validation ........................... :180-208, :1145-1219
+//   formats / channels / keys / registration ................... :1567-1656
+// Not carried over (no counterpart without the Raspberry Pi HAT): SPI, GPIO,
+// SX1255 register programming, clock detection, HAT EEPROM.  Frequency, gain
+// and antenna are inert cached values so that probing tools keep working.
+//
+// New device arguments (the reference ignores its device args, :711):
+//   gpu=<n>            HIP device (default 0)
+//   clock=virtual|wall sample clock model (default wall, like hardware)
+//   master_clock=<Hz>  32e6 or 38.4e6 (default 38.4e6; the reference probes the PLL, :639-665)
+//   decim=<D>          RX decimation done on the GPU (default 4)
+//   interp=<L>         TX interpolation done on the GPU (default 4)
+//   taps_per_phase=<n> filter length = n * ratio (default 32)
+//   seed=<u64>         synthetic source seed (default 0x51255)
+#include <SoapySDR/Device.hpp>
+#include <SoapySDR/Logger.hpp>
+#include <SoapySDR/Registry.hpp>
+#include <SoapySDR/Time.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "GpuChains.hpp"
+#include "SynthPcm.hpp"
+
+const char *SoapySXHip_tag = "sx-mi355x";
+const char *SoapySXHip_commit = "round1";
+
+namespace {
+
+struct sampleRateDiv {
+    uint16_t div;   // ratio of master clock to sample rate
+};
+
+// The six SX1255 I2S rates the reference supports (SoapySX.cpp:196-208).
+const sampleRateDiv sample_rates[] = {{1536}, {768}, {512}, {256}, {128}, {64}};
+const size_t N_SAMPLE_RATES = sizeof(sample_rates) / sizeof(sample_rates[0]);
+
+int pcm_error_to_soapy_rx(int err) { return err == -EPIPE ? SOAPY_SDR_OVERFLOW : SOAPY_SDR_STREAM_ERROR; }
+int pcm_error_to_soapy_tx(int err) { return err == -EPIPE ? SOAPY_SDR_UNDERFLOW : SOAPY_SDR_STREAM_ERROR; }
+
+std::string arg(const SoapySDR::Kwargs &args, const char *key, const char *dflt)
+{
+    const auto it = args.find(key);
+    return it == args.end() ? std::string(dflt) : it->second;
+}
+
+}  // namespace
+
+class SoapySXHip : public SoapySDR::Device {
+private:
+    double masterClock;
+    double sampleRate;
+    mutable std::recursive_mutex reg_mutex;
+
+    sx::SampleClock clock;
+    sx::SynthPcm pcm_rx;
+    sx::SynthPcm pcm_tx;
+    float tx_threshold2;
+    bool linked;
+
+    int gpu;
+    int decim, interp, taps_per_phase;
+    uint64_t seed;
+    std::unique_ptr<sx::RxChain> rx_chain;
+    std::unique_ptr<sx::TxChain> tx_chain;
+    int64_t tx_ptt_samples;     // written samples at or above the TX threshold (PTT bit of :132-133)
+
+    // inert front-end state
+    double frequency[2];
+    double gain[2];
+    std::string antenna[2];
+
+    int64_t timestamp_to_samples(long long timestamp) const { return SoapySDR::timeNsToTicks(timestamp, sampleRate); }
+    long long samples_to_timestamp(int64_t samples) const { return SoapySDR::ticksToTimeNs(samples, sampleRate); }
+
+    void reset_streams()
+    {
+        pcm_rx.reset();
+        pcm_tx.reset();
+        if (rx_chain) rx_chain->reset();
+        if (tx_chain) tx_chain->reset();
+        tx_ptt_samples = 0;
+    }
+
+public:
+    SoapySXHip(const SoapySDR::Kwargs &args)
+        : masterClock(std::stod(arg(args, "master_clock", "38.4e6"))),
+          sampleRate(masterClock / 256.0),    // default after clock detection, :662
+          clock(arg(args, "clock", "wall") == "virtual" ? sx::SampleClock::VIRTUAL : sx::SampleClock::WALL, sampleRate),
+          pcm_rx("synth:rx", sx::SynthPcm::CAPTURE, &clock),
+          pcm_tx("synth:tx", sx::SynthPcm::PLAYBACK, &clock),
+          tx_threshold2(0.0f),
+          linked(false),
+          gpu(std::stoi(arg(args, "gpu", "0"))),
+          decim(std::stoi(arg(args, "decim", "4"))),
+          interp(std::stoi(arg(args, "interp", "4"))),
+          taps_per_phase(std::stoi(arg(args, "taps_per_phase", "32"))),
+          seed(std::stoull(arg(args, "seed", "0x51255"), nullptr, 0)),
+          tx_ptt_samples(0)
+    {
+        SoapySDR_logf(SOAPY_SDR_INFO, "Initializing SoapySX (MI355X synthetic-IQ build)");
+        if (masterClock != 32.0e6 && masterClock != 38.4e6)
+            throw std::runtime_error("master_clock must be 32e6 or 38.4e6");
+        if (decim < 1 || interp < 1 || taps_per_phase < 1) throw std::runtime_error("bad decim/interp/taps_per_phase");
+        int ndev = 0;
+        if (sxfir_device_count(&ndev) != SXFIR_OK || ndev < 1)
+            throw std::runtime_error(std::string("No MI355X visible: ") + sxfir_last_error());
+        frequency[0] = frequency[1] = 433.92e6;     // :663-664
+        gain[0] = gain[1] = 0.0;
+        antenna[SOAPY_SDR_RX] = "RX";
+        antenna[SOAPY_SDR_TX] = "TX";
+        rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, 0));
+        tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536));
+    }
+
+    ~SoapySXHip(void) { SoapySDR_logf(SOAPY_SDR_INFO, "Uninitializing SoapySX"); }
+
+    /*******************************************************************
+     * Sample streams
+     ******************************************************************/
+
+    SoapySDR::Stream *setupStream(const int direction, const std::string &format, const std::vector<size_t> &channels,
+                                  const SoapySDR::Kwargs &args)
+    {
+        (void)channels;   // one channel per device, :747
+        std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
+
+        if (format != "CF32") throw std::runtime_error("Only CF32 format is currently supported");
+        if (pcm_rx.state() == sx::SynthPcm::RUNNING || pcm_tx.state() == sx::SynthPcm::RUNNING)
+            throw std::runtime_error("Streams can be setup only if none of the streams are running");
+
+        auto *stream = direction == SOAPY_SDR_RX ? &pcm_rx : &pcm_tx;
+        if (stream->setup_done) throw std::runtime_error("Stream has been setup already");
+
+        if (stream->is_tx()) {
+            const float tx_threshold_default = 1.0e-3;
+            const float tx_threshold =
+                (args.count("threshold") > 0) ? std::stof(args.at("threshold")) : tx_threshold_default;
+            tx_threshold2 = tx_threshold * tx_threshold;
+        }
+
+        const bool arg_link = (args.count("link") > 0 && args.at("link") == "1");
+        stream->stream_mode = arg_link ? sx::STREAM_MODE_LINK : sx::STREAM_MODE_NORMAL;
+        stream->configure(args.count("period") > 0 ? std::stoul(args.at("period")) : 0);
+        stream->setup_done = 1;
+
+        // RX and TX run from one sample clock once both exist (snd_pcm_link, :784-788)
+        if ((!linked) && pcm_rx.setup_done && pcm_tx.setup_done) {
+            SoapySDR_logf(SOAPY_SDR_DEBUG, "Linking streams");
+            pcm_rx.link(&pcm_tx);
+            linked = 1;
+        }
+        return reinterpret_cast<SoapySDR::Stream *>(stream);
+    }
+
+    void closeStream(SoapySDR::Stream *handle)
+    {
+        auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
+        std::scoped_lock lock(stream->mutex);
+        stream->setup_done = 0;
+    }
+
+    int activateStream(SoapySDR::Stream *handle, const int flags, const long long timeNs, const size_t numElems)
+    {
+        (void)flags; (void)timeNs; (void)numElems;   // ignored like the reference, :810
+        std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
+        auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
+        if (stream->activated) {
+            SoapySDR_logf(SOAPY_SDR_ERROR, "Stream was already activated");
+            return SOAPY_SDR_STREAM_ERROR;
+        }
+        stream->activated = 1;
+        if (stream->stream_mode == sx::STREAM_MODE_NORMAL) {
+            if (stream->state() == sx::SynthPcm::PREPARED) stream->start();
+        }
+        return 0;
+    }
+
+    int deactivateStream(SoapySDR::Stream *handle, const int flags, const long long timeNs)
+    {
+        (void)flags; (void)timeNs;
+        std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
+        auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
+        if (!stream->activated) {
+            SoapySDR_logf(SOAPY_SDR_ERROR, "Stream was already deactivated");
+            return SOAPY_SDR_STREAM_ERROR;
+        }
+        stream->activated = 0;
+        // both inactive -> stop and rewind: position restarts at 0, :850-854
+        if ((!pcm_rx.activated) && (!pcm_tx.activated)) {
+            SoapySDR_logf(SOAPY_SDR_INFO, "Stopping and resetting streams");
+            try {
+                reset_streams();
+            } catch (const std::exception &e) {
+                SoapySDR_logf(SOAPY_SDR_ERROR, "reset: %s", e.what());
+                return SOAPY_SDR_STREAM_ERROR;
+            }
+        }
+        return 0;
+    }
+
+    size_t getStreamMTU(SoapySDR::Stream *handle) const
+    {
+        auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
+        std::scoped_lock lock(stream->mutex);
+        return stream->hwp_period_size;
+    }
+
+    int readStream(SoapySDR::Stream *handle, void *const *buffs, const size_t numElems, int &flags, long long &timeNs,
+                   const long timeoutUs)
+    {
+        auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
+        std::scoped_lock lock(stream->mutex);
+
+        flags = 0;
+        if (stream->is_tx()) throw std::runtime_error("Wrong direction");
+        if (!stream->activated) return 0;
+
+        int64_t pcm_avail = 0, pcm_delay = 0;
+        const int avail_ret = stream->avail_delay(&pcm_avail, &pcm_delay);
+        if (avail_ret < 0) {
+            SoapySDR_logf(SOAPY_SDR_ERROR, "rx avail_delay: %d", avail_ret);
+            return pcm_error_to_soapy_rx(avail_ret);
+        }
+        SoapySDR_logf(SOAPY_SDR_DEBUG, "rx avail_delay: %d %ld %ld", avail_ret, (long)pcm_avail, (long)pcm_delay);
+
+        // More available than the ring holds: the oldest samples were
+        // overwritten.  Skip whole periods plus a 1-2 period margin, :910-927.
+        if (pcm_avail > (int64_t)stream->hwp_buffer_size) {
+            const uint64_t overwritten = (uint64_t)pcm_avail - stream->hwp_buffer_size;
+            const uint64_t samples_to_skip = (overwritten / stream->hwp_period_size + 2) * stream->hwp_period_size;
+            const int64_t forwarded = stream->forward((int64_t)samples_to_skip);
+            if (forwarded >= 0) {
+                stream->position += forwarded;
+                pcm_avail -= forwarded;
+                SoapySDR_logf(SOAPY_SDR_WARNING, "RX buffer overrun. Skipped %ld samples", (long)forwarded);
+            } else {
+                SoapySDR_logf(SOAPY_SDR_ERROR, "rx forward: %ld", (long)forwarded);
+                return pcm_error_to_soapy_rx((int)forwarded);
+            }
+        }
+
+        uint64_t length = (uint64_t)std::min(numElems, (size_t)ULONG_MAX);
+        if (timeoutUs <= 0) {   // non-blocking: what is there now, :934-942
+            if (pcm_avail <= 0) length = 0;
+            else if ((uint64_t)pcm_avail < length) length = (uint64_t)pcm_avail;
+        }
+        if (length == 0) return 0;
+        if (length > (uint64_t)INT_MAX) length = (uint64_t)INT_MAX;
+
+        int64_t first = 0;
+        const int64_t samples_read = stream->begin_read((int64_t)length, &first);
+        if (samples_read < 0) return pcm_error_to_soapy_rx((int)samples_read);
+
+        timeNs = samples_to_timestamp(stream->position);   // :950
+        flags |= SOAPY_SDR_HAS_TIME;
+        stream->position += samples_read;
+
+        try {
+            // stream sample `first` == position before the read: the PCM frame
+            // counter and `position` advance together
+            rx_chain->produce(first, (size_t)samples_read, static_cast<float *>(buffs[0]));
+        } catch (const std::exception &e) {
+            SoapySDR_logf(SOAPY_SDR_ERROR, "rx chain: %s", e.what());
+            return SOAPY_SDR_STREAM_ERROR;
+        }
+        return (int)samples_read;
+    }
+
+    int writeStream(SoapySDR::Stream *handle, const void *const *buffs, const size_t numElems, int &flags,
+                    const long long timeNs, const long timeoutUs)
+    {
+        auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
+        std::scoped_lock lock(stream->mutex);
+
+        if (!stream->is_tx()) throw std::runtime_error("Wrong direction");
+        if (!stream->activated) return 0;
+
+        int64_t pcm_avail = 0, pcm_delay = 0;
+        const int avail_ret = stream->avail_delay(&pcm_avail, &pcm_delay);
+        if (avail_ret < 0) {
+            SoapySDR_logf(SOAPY_SDR_ERROR, "tx avail_delay: %d", avail_ret);
+            return pcm_error_to_soapy_tx(avail_ret);
+        }
+        SoapySDR_logf(SOAPY_SDR_DEBUG, "tx avail_delay: %d %ld %ld", avail_ret, (long)pcm_avail, (long)pcm_delay);
+
+        const int64_t playback_position = stream->position - pcm_delay;   // :1000
+        int64_t write_position;
+        uint64_t length = (uint64_t)std::min(numElems, (size_t)ULONG_MAX);
+        if (length > (uint64_t)INT_MAX) length = (uint64_t)INT_MAX;
+
+        if (flags & SOAPY_SDR_HAS_TIME) {
+            // place the block at the position its timestamp names; a timestamp
+            // in the past is dropped but reported as written, :1009-1023
+            write_position = timestamp_to_samples(timeNs);
+            const int64_t diff = playback_position - write_position;
+            if (diff > 0) {
+                SoapySDR_logf(SOAPY_SDR_WARNING, "Discarding TX %ld samples in the past", (long)diff);
+                return (int)length;
+            }
+        } else {
+            // continue where the last write ended; after an underrun skip
+            // ahead by whole periods plus a 1-2 period margin, :1024-1038
+            write_position = stream->position;
+            int64_t diff = playback_position - write_position;
+            if (diff > 0) {
+                diff = (diff / (int64_t)stream->hwp_period_size + 2) * (int64_t)stream->hwp_period_size;
+                write_position += diff;
+                SoapySDR_logf(SOAPY_SDR_WARNING, "TX buffer underrun. Forwarding TX stream by %ld samples", (long)diff);
+            }
+        }
+
+        // forward to the write position; what is skipped plays as silence, :1043-1073
+        int64_t posdiff = write_position - stream->position;
+        while (posdiff > 0) {
+            const int64_t forwardable = stream->forwardable();
+            if (forwardable < 0) {
+                SoapySDR_logf(SOAPY_SDR_ERROR, "tx forwardable: %ld", (long)forwardable);
+                return pcm_error_to_soapy_tx((int)forwardable);
+            }
+            int64_t forwarded;
+            if (posdiff < forwardable) {
+                forwarded = stream->forward(posdiff);
+            } else {
+                forwarded = stream->forward(forwardable);
+                if (stream->state() != sx::SynthPcm::RUNNING && forwarded == 0) {
+                    // a stopped ring never drains; the reference would wait forever in snd_pcm_wait
+                    SoapySDR_logf(SOAPY_SDR_ERROR, "tx forward: stream is not running");
+                    return SOAPY_SDR_TIMEOUT;
+                }
+                stream->wait_for_space_or_data();
+            }
+            if (forwarded < 0) {
+                SoapySDR_logf(SOAPY_SDR_ERROR, "tx forward: %ld", (long)forwarded);
+                return pcm_error_to_soapy_tx((int)forwarded);
+            }
+            stream->position += forwarded;
+            posdiff -= forwarded;
+            pcm_avail -= forwarded;
+        }
+
+        if (timeoutUs <= 0) {   // non-blocking: what fits now, :1076-1085
+            if (pcm_avail <= 0) length = 0;
+            else if ((uint64_t)pcm_avail < length) length = (uint64_t)pcm_avail;
+        }
+        if (length == 0) return 0;
+
+        int64_t first = 0;
+        const int64_t samples_written = stream->begin_write((int64_t)length, &first);
+        if (samples_written < 0) return pcm_error_to_soapy_tx((int)samples_written);
+        try {
+            const float *src = static_cast<const float *>(buffs[0]);
+            // transmitter keying of convert_tx_buffer (:132-133): count the samples whose
+            // squared magnitude reaches the threshold (the PTT bit of the I2S word)
+            for (int64_t i = 0; i < samples_written; ++i) {
+                const float fi = src[2 * i], fq = src[2 * i + 1];
+                const float ii = fi * fi, qq = fq * fq;
+                if (ii + qq >= tx_threshold2) ++tx_ptt_samples;
+            }
+            tx_chain->consume(first, (size_t)samples_written, src);
+        } catch (const std::exception &e) {
+            SoapySDR_logf(SOAPY_SDR_ERROR, "tx chain: %s", e.what());
+            return SOAPY_SDR_STREAM_ERROR;
+        }
+        stream->position += samples_written;
+        return (int)samples_written;
+    }
+
+    long long getHardwareTime(const std::string &what) const
+    {
+        if (what == "") {
+            // TX side on purpose: does not contend with an RX thread, :1110-1125
+            auto *stream = const_cast<sx::SynthPcm *>(&pcm_tx);
+            std::scoped_lock lock(stream->mutex);
+            int64_t pcm_avail = 0, pcm_delay = 0;
+            const int ret = stream->avail_delay(&pcm_avail, &pcm_delay);
+            if (ret < 0) throw std::runtime_error("PCM error");
+            return samples_to_timestamp(stream->position - pcm_delay);
+        }
+        throw std::runtime_error("Unsupported time");
+    }
+
+    bool hasHardwareTime(const std::string &what) const { return what == ""; }
+
+    /*******************************************************************
+     * Sample rates
+     ******************************************************************/
+
+    std::vector<double> listSampleRates(const int direction, const size_t channel) const
+    {
+        (void)direction; (void)channel;
+        std::vector<double> sampleRates;
+        for (size_t i = 0; i < N_SAMPLE_RATES; i++) sampleRates.push_back(masterClock / (double)sample_rates[i].div);
+        return sampleRates;
+    }
+
+    SoapySDR::RangeList getSampleRateRange(const int direction, const size_t channel) const
+    {
+        SoapySDR::RangeList ranges;
+        for (const auto rate : listSampleRates(direction, channel)) ranges.push_back({rate, rate, 0});
+        return ranges;
+    }
+
+    void setSampleRate(const int direction, const size_t channel, const double rate)
+    {
+        (void)direction; (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        if (rate != rate || rate <= 0) throw std::runtime_error("Sample rate must be positive");
+        const double divider = round(masterClock / rate);
+        bool found = false;
+        for (size_t i = 0; i < N_SAMPLE_RATES; i++) {
+            if ((double)sample_rates[i].div == divider) { found = true; break; }
+        }
+        if (!found) throw std::runtime_error("Unsupported sample rate");
+        sampleRate = masterClock / divider;
+        clock.set_rate(sampleRate);
+    }
+
+    double getSampleRate(const int direction, const size_t channel) const
+    {
+        (void)direction; (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        return sampleRate;
+    }
+
+    /*******************************************************************
+     * Inert RF front-end state (no SX1255 behind this build)
+     ******************************************************************/
+
+    void setFrequency(const int direction, const size_t channel, const double f, const SoapySDR::Kwargs &)
+    {
+        (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        // tuning step masterClock / 2^20, :1236-1239
+        const double step = masterClock / 1048576.0;
+        frequency[direction == SOAPY_SDR_RX ? 1 : 0] = round(f / step) * step;
+    }
+    double getFrequency(const int direction, const size_t channel) const
+    {
+        (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        return frequency[direction == SOAPY_SDR_RX ? 1 : 0];
+    }
+    void setGain(const int direction, const size_t channel, const double value)
+    {
+        (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        gain[direction == SOAPY_SDR_RX ? 1 : 0] = value;
+    }
+    double getGain(const int direction, const size_t channel) const
+    {
+        (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        return gain[direction == SOAPY_SDR_RX ? 1 : 0];
+    }
+    std::vector<std::string> listAntennas(const int direction, const size_t channel) const
+    {
+        (void)channel;
+        if (direction == SOAPY_SDR_RX) return {"RX", "LB", "DLB"};
+        return {"TX", "NONE"};
+    }
+    void setAntenna(const int direction, const size_t channel, const std::string &name)
+    {
+        (void)channel;
+        const auto names = listAntennas(direction, 0);
+        if (std::find(names.begin(), names.end(), name) == names.end()) throw std::runtime_error("Unknown antenna");
+        std::scoped_lock lock(reg_mutex);
+        antenna[direction == SOAPY_SDR_RX ? SOAPY_SDR_RX : SOAPY_SDR_TX] = name;
+    }
+    std::string getAntenna(const int direction, const size_t channel) const
+    {
+        (void)channel;
+        std::scoped_lock lock(reg_mutex);
+        return antenna[direction == SOAPY_SDR_RX ? SOAPY_SDR_RX : SOAPY_SDR_TX];
+    }
+
+    /*******************************************************************
+     * Settings: the virtual sample clock and the synthetic sink are driven
+     * and inspected here (new; the reference only has "PA", :1472-1493)
+     ******************************************************************/
+
+    void writeSetting(const std::string &key, const std::string &value)
+    {
+        if (key == "CLOCK_ADVANCE") {
+            clock.advance(std::stoll(value));
+        } else if (key == "PA") {
+            if (value != "ON" && value != "OFF" && value != "AUTO") throw std::runtime_error("Unknown PA setting");
+        } else {
+            throw std::runtime_error("Unknown setting");
+        }
+    }
+
+    std::string readSetting(const std::string &key) const
+    {
+        if (key == "CLOCK_NOW") return std::to_string(clock.now());
+        if (key == "RX_POSITION") return std::to_string(pcm_rx.position);
+        if (key == "TX_POSITION") return std::to_string(pcm_tx.position);
+        if (key == "TX_WRITTEN") return std::to_string(tx_chain->written());
+        if (key == "TX_PTT_SAMPLES") return std::to_string(tx_ptt_samples);
+        if (key == "RX_DECIM") return std::to_string(decim);
+        if (key == "TX_INTERP") return std::to_string(interp);
+        if (key == "RX_NTAPS") return std::to_string(rx_chain->ntaps());
+        if (key == "SEED") return std::to_string(seed);
+        throw std::runtime_error("Unknown setting");
+    }
+
+    // Synthetic sink inspection (used by the C ABI, include/sx_device.h)
+    void txCapture(long long dac_pos, size_t n, float *dst)
+    {
+        std::scoped_lock lock(pcm_tx.mutex);
+        tx_chain->capture(dac_pos, n, dst);
+    }
+
+    /*******************************************************************
+     * Other hardware and driver information
+     ******************************************************************/
+
+    std::string getDriverKey(void) const { return "sx"; }
+    std::string getHardwareKey(void) const { return "sx"; }
+
+    SoapySDR::Kwargs getHardwareInfo(void) const
+    {
+        SoapySDR::Kwargs args;
+        args["soapysx_tag"] = SoapySXHip_tag;
+        args["soapysx_commit"] = SoapySXHip_commit;
+        args["hardware_version"] = "unknown";       // no HAT EEPROM to read, :1582-1587
+        char name[64] = "", arch[32] = "";
+        int cus = 0;
+        size_t hbm = 0;
+        if (sxfir_device_info(gpu, name, arch, &cus, &hbm) == SXFIR_OK) {
+            args["gpu_name"] = name;
+            args["gpu_arch"] = arch;
+            args["gpu_compute_units"] = std::to_string(cus);
+        }
+        return args;
+    }
+
+    size_t getNumChannels(const int direction) const { (void)direction; return 1; }
+
+    std::string getNativeStreamFormat(const int direction, const size_t channel, double &fullScale) const
+    {
+        (void)direction; (void)channel;
+        fullScale = 1.0;
+        return "CF32";
+    }
+
+    std::vector<std::string> getStreamFormats(const int direction, const size_t channel) const
+    {
+        (void)direction; (void)channel;
+        return {"CF32"};
+    }
+};
+
+/***********************************************************************
+ * Find / make / register (SoapySX.cpp:1629-1656)
+ **********************************************************************/
+static SoapySDR::KwargsList findDevice(const SoapySDR::Kwargs &args)
+{
+    (void)args;
+    SoapySDR::KwargsList devices;
+    SoapySDR::Kwargs device;
+    device["label"] = "sx";
+    device["driver"] = "sx";
+    devices.push_back(device);
+    return devices;
+}
+
+static SoapySDR::Device *makeDevice(const SoapySDR::Kwargs &args)
+{
+    SoapySDR::logf(SOAPY_SDR_INFO, "SoapySX version %s %s", SoapySXHip_tag, SoapySXHip_commit);
+    return new SoapySXHip(args);
+}
+
+static SoapySDR::Registry registerDevice("sx", &findDevice, &makeDevice, SOAPY_SDR_ABI_VERSION);
+
+// Used by the C ABI wrapper (sx_device_capi.cpp) for the sink read-back.
+extern "C" int sx_device_internal_tx_capture(SoapySDR::Device *dev, long long dac_pos, size_t n, float *dst)
+{
+    auto *d = dynamic_cast<SoapySXHip *>(dev);
+    if (!d) return -1;
+    d->txCapture(dac_pos, n, dst);
+    return 0;
+}

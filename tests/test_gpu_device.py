@@ -1,0 +1,334 @@
+"""The SoapySDR ``driver=sx`` surface on the GPU box, exercised the way the
+reference's own scripts exercise it (SoapySX/test/test_timestamps.py,
+test_linked_streams.py, example/linear_repeater.py), but asserting instead of
+printing.  A virtual sample clock (device arg clock=virtual) makes every run
+deterministic; sample data is checked bit for bit against the oracle and
+position / timestamp arithmetic against the oracle's restatement of
+SoapySX.cpp:897-1104."""
+import numpy as np
+import pytest
+
+import sxxcvr_amd
+import sxxcvr_amd.soapy as SoapySDR
+from gpu_util import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x51255
+RATE = 75000.0
+
+
+def make(**extra):
+    args = {"driver": "sx", "clock": "virtual"}
+    args.update(extra)
+    dev = SoapySDR.Device(args)
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, RATE)
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_TX, 0, RATE)
+    return dev
+
+
+def rx_reference(oracle, decim, n_out):
+    """The stream the RX chain must deliver: decimated synthetic source, from stream position 0."""
+    h = sxxcvr_amd.design_lowpass(32 * decim, decim)
+    x = oracle.synth_iq(SEED, 0, 0, n_out * decim)
+    return oracle.decim_f32(h, decim, x, 2, 4)
+
+
+def tx_reference(oracle, interp, stream):
+    h = sxxcvr_amd.design_lowpass(32 * interp, interp, 8.0, float(interp))
+    return oracle.interp_f32(h, interp, stream, 2)
+
+
+def test_identity_and_formats():
+    dev = make()
+    assert dev.getDriverKey() == "sx" and dev.getHardwareKey() == "sx"      # SoapySX.cpp:1567-1575
+    info = dev.getHardwareInfo()
+    assert info["hardware_version"] == "unknown" and "soapysx_tag" in info and info["gpu_arch"] == "gfx950"
+    assert dev.getNumChannels(SoapySDR.SOAPY_SDR_RX) == 1 and dev.getNumChannels(SoapySDR.SOAPY_SDR_TX) == 1
+    assert dev.getStreamFormats(SoapySDR.SOAPY_SDR_RX, 0) == ["CF32"]
+    assert dev.getNativeStreamFormat(SoapySDR.SOAPY_SDR_TX, 0) == ("CF32", 1.0)
+    assert dev.hasHardwareTime("") and not dev.hasHardwareTime("pps")
+    with pytest.raises(RuntimeError, match="Unsupported time"):
+        dev.getHardwareTime("pps")
+
+
+def test_sample_rate_table():
+    dev = make()
+    rates = dev.listSampleRates(SoapySDR.SOAPY_SDR_RX, 0)
+    assert rates == [38.4e6 / d for d in (1536, 768, 512, 256, 128, 64)]     # SoapySX.cpp:196-208
+    dev32 = SoapySDR.Device({"driver": "sx", "clock": "virtual", "master_clock": "32e6"})
+    assert dev32.listSampleRates(SoapySDR.SOAPY_SDR_TX, 0) == [32e6 / d for d in (1536, 768, 512, 256, 128, 64)]
+    assert dev32.getSampleRate(SoapySDR.SOAPY_SDR_RX, 0) == 125000.0          # masterClock / 256, :662
+    for r in rates:
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, r)
+        assert dev.getSampleRate(SoapySDR.SOAPY_SDR_RX, 0) == r
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 75010.0)                      # rounds to the nearest divider, :1179
+    assert dev.getSampleRate(SoapySDR.SOAPY_SDR_TX, 0) == 75000.0
+    for bad in (100000.0, 38.4e6 / 384, 1.0):
+        with pytest.raises(RuntimeError, match="Unsupported sample rate"):
+            dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, bad)
+    for bad in (0.0, -75000.0, float("nan")):
+        with pytest.raises(RuntimeError, match="Sample rate must be positive"):
+            dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, bad)
+
+
+def test_stream_lifecycle_errors():
+    dev = make()
+    with pytest.raises(RuntimeError, match="Only CF32"):
+        dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CS16", [0], {})
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    with pytest.raises(RuntimeError, match="setup already"):
+        dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "1000"})
+    assert dev.getStreamMTU(rx) == 256 and dev.getStreamMTU(tx) == 1000       # :451, :861-866
+    buf = np.zeros(256, dtype=np.complex64)
+    # not activated -> 0, no flags (:893-894, :984-985)
+    r = dev.readStream(rx, [buf], 256)
+    assert (r.ret, r.flags) == (0, 0)
+    assert dev.writeStream(tx, [buf], 256).ret == 0
+    with pytest.raises(RuntimeError, match="Wrong direction"):
+        dev.readStream(tx, [buf], 256)
+    with pytest.raises(RuntimeError, match="Wrong direction"):
+        dev.writeStream(rx, [buf], 256)
+    assert dev.activateStream(rx) == 0
+    assert dev.activateStream(rx) == SoapySDR.SOAPY_SDR_STREAM_ERROR          # :815-818
+    dev.closeStream(tx)
+    with pytest.raises(RuntimeError, match="none of the streams are running"):
+        dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {})   # :754-758
+    assert dev.deactivateStream(rx) == 0
+    assert dev.deactivateStream(rx) == SoapySDR.SOAPY_SDR_STREAM_ERROR        # :843-846
+
+
+def test_rx_timestamps_and_data(oracle):
+    """SoapySX/test/test_timestamps.py: untimed reads of one period; time = position / rate."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    ref = rx_reference(oracle, 4, 256 * 12)
+    buf = np.zeros(256, dtype=np.complex64)
+    times = []
+    for i in range(12):
+        before = dev.getHardwareTime()
+        r = dev.readStream(rx, [buf], len(buf))
+        after = dev.getHardwareTime()
+        assert r.ret == 256 and r.flags == SoapySDR.SOAPY_SDR_HAS_TIME
+        assert r.timeNs == oracle.ticks_to_time_ns(256 * i, RATE)
+        assert_bit_exact(buf, ref[256 * i:256 * (i + 1)], "rx block %d" % i)
+        # delay from the last RX sample to "now": at most one sample period on the virtual clock
+        d = after - (r.timeNs + int(round(1.0e9 * (r.ret - 1) / RATE)))
+        assert 0 <= d <= int(1e9 / RATE) + 1 and before <= after
+        times.append(r.timeNs)
+    assert times[:3] == [0, 3413333, 6826667]
+    # reads that are not period-aligned keep sample-exact positions
+    odd = np.zeros(100, dtype=np.complex64)
+    r = dev.readStream(rx, [odd], 100)
+    assert r.ret == 100 and r.timeNs == oracle.ticks_to_time_ns(256 * 12, RATE)
+    assert dev.readSetting("RX_POSITION") == str(256 * 12 + 100)
+
+
+def test_full_duplex_timed_loop(oracle):
+    """example/linear_repeater.py:40-69: every RX block is retransmitted with a timestamp
+    768 samples later; the TX block must land at exactly rx_position + 768."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"threshold": "0"})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    latency = 768
+    dt = int(round(latency * 1e9 / RATE))
+    assert dt == 10240000
+    nblk = 10
+    buf = np.zeros(256, dtype=np.complex64)
+    stream = np.zeros(latency + 256 * nblk, dtype=np.complex64)
+    for i in range(nblk):
+        r = dev.readStream(rx, [buf], len(buf))
+        assert r.ret == 256
+        t = dev.writeStream(tx, [buf], len(buf), flags=SoapySDR.SOAPY_SDR_HAS_TIME, timeNs=r.timeNs + dt)
+        assert t.ret == 256
+        assert int(dev.readSetting("TX_POSITION")) == 256 * i + latency + 256
+        stream[latency + 256 * i: latency + 256 * (i + 1)] = buf
+    assert int(dev.readSetting("TX_WRITTEN")) == 256 * nblk
+    assert int(dev.readSetting("TX_PTT_SAMPLES")) == 256 * nblk        # threshold 0 keeps the PA keyed
+    # what reached the synthetic DAC: the interpolated stream, silence before the first block
+    L = int(dev.readSetting("TX_INTERP"))
+    got = dev.txCapture(0, len(stream) * L)
+    assert_bit_exact(got, tx_reference(oracle, L, stream), "dac stream")
+    assert not got[: (latency - 40) * L].any()
+
+
+def test_rx_overrun_skip(oracle):
+    """RX overrun: more than the ring is pending -> whole periods + margin are skipped (:910-927)."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    buf = np.zeros(256, dtype=np.complex64)
+    assert dev.readStream(rx, [buf], 256).ret == 256
+    dev.writeSetting("CLOCK_ADVANCE", 70000)                           # application stalls
+    pos, avail = 256, 70000
+    exp = oracle.rx_step(pos, avail, 256, 65536, 256, 100000, RATE)
+    SoapySDR.drainLog()
+    r = dev.readStream(rx, [buf], 256)
+    assert (r.ret, r.flags, r.timeNs) == (exp.ret, exp.flags, exp.time_ns)
+    assert exp.skipped == ((70000 - 65536) // 256 + 2) * 256
+    assert int(dev.readSetting("RX_POSITION")) == exp.position
+    assert "RX buffer overrun. Skipped %d samples" % exp.skipped in SoapySDR.drainLog()
+    ref = rx_reference(oracle, 4, exp.position)
+    assert_bit_exact(buf, ref[exp.position - 256: exp.position], "data after the skip")
+
+
+def test_rx_nonblocking(oracle):
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    buf = np.zeros(256, dtype=np.complex64)
+    r = dev.readStream(rx, [buf], 256, timeoutUs=0)                    # nothing captured yet
+    assert (r.ret, r.flags) == (0, 0)
+    dev.writeSetting("CLOCK_ADVANCE", 100)
+    r = dev.readStream(rx, [buf], 256, timeoutUs=0)                    # clamps to what is there, :934-942
+    assert (r.ret, r.flags, r.timeNs) == (100, 4, 0)
+    dev.writeSetting("CLOCK_ADVANCE", 1000)
+    r = dev.readStream(rx, [buf], 256, timeoutUs=0)
+    assert (r.ret, r.timeNs) == (256, oracle.ticks_to_time_ns(100, RATE))
+    assert_bit_exact(buf, rx_reference(oracle, 4, 356)[100:356], "non-blocking data")
+
+
+def test_tx_rules_against_oracle(oracle):
+    """writeStream placement (:989-1104) on the virtual clock vs the oracle's restatement."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    buf = (np.arange(256) / 512.0 + 0.25j).astype(np.complex64)
+    pos = 0
+
+    def state():
+        clk = int(dev.readSetting("CLOCK_NOW"))
+        delay = pos - clk                                              # playback: appl - hw
+        return 65536 - delay, delay
+
+    # untimed write right after start: no underrun
+    avail, delay = state()
+    exp = oracle.tx_step(pos, avail, delay, 256, 256, 0, 0, 100000, RATE)
+    assert dev.writeStream(tx, [buf], 256).ret == exp.ret == 256
+    pos = exp.position
+    assert int(dev.readSetting("TX_POSITION")) == pos == 256
+    # the application stalls for 1000 samples: untimed write skips whole periods + margin (:1032-1037)
+    dev.writeSetting("CLOCK_ADVANCE", 1000)
+    avail, delay = state()
+    exp = oracle.tx_step(pos, avail, delay, 256, 256, 0, 0, 100000, RATE)
+    assert exp.skipped == ((1000 - 256) // 256 + 2) * 256
+    SoapySDR.drainLog()
+    assert dev.writeStream(tx, [buf], 256).ret == exp.ret
+    pos = exp.position
+    assert int(dev.readSetting("TX_POSITION")) == pos
+    assert "TX buffer underrun. Forwarding TX stream by %d samples" % exp.skipped in SoapySDR.drainLog()
+    # timestamp in the past: dropped but reported as written (:1013-1023)
+    avail, delay = state()
+    exp = oracle.tx_step(pos, avail, delay, 256, 256, 4, 1000, 100000, RATE)
+    assert exp.discarded == 1
+    assert dev.writeStream(tx, [buf], 256, flags=SoapySDR.SOAPY_SDR_HAS_TIME, timeNs=1000).ret == 256
+    assert int(dev.readSetting("TX_POSITION")) == pos
+    assert "Discarding TX" in SoapySDR.drainLog()
+    # timestamp in the future: forwarded to the exact sample
+    t = oracle.ticks_to_time_ns(pos + 5000, RATE)
+    avail, delay = state()
+    exp = oracle.tx_step(pos, avail, delay, 256, 256, 4, t, 100000, RATE)
+    assert dev.writeStream(tx, [buf], 256, flags=SoapySDR.SOAPY_SDR_HAS_TIME, timeNs=t).ret == 256
+    pos = exp.position
+    assert int(dev.readSetting("TX_POSITION")) == pos == exp.position
+    # hardware time = playback position in ns (:1107-1139)
+    assert dev.getHardwareTime() == oracle.ticks_to_time_ns(int(dev.readSetting("CLOCK_NOW")), RATE)
+    # PTT keying: default threshold 1e-3; the ramp's first sample has |s| = 0.25 -> all keyed
+    assert int(dev.readSetting("TX_PTT_SAMPLES")) == 256 * 3
+
+
+def test_deactivate_resets_positions(oracle):
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    buf = np.zeros(512, dtype=np.complex64)
+    assert dev.readStream(rx, [buf], 512).ret == 512
+    assert dev.writeStream(tx, [buf], 512).ret == 512
+    dev.deactivateStream(rx)
+    assert int(dev.readSetting("RX_POSITION")) == 512                  # only one side stopped
+    dev.deactivateStream(tx)                                           # both inactive -> reset, :850-854
+    assert int(dev.readSetting("RX_POSITION")) == 0 and int(dev.readSetting("TX_POSITION")) == 0
+    dev.activateStream(rx)
+    first = buf.copy()
+    r = dev.readStream(rx, [buf], 512)
+    assert r.timeNs == 0 and np.array_equal(first.view(np.uint64), buf.view(np.uint64))
+
+
+def test_linked_streams(oracle):
+    """SoapySX/test/test_linked_streams.py: link=1, prefill TX, then lock-step read/write."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"link": "1"})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"link": "1"})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    buf = np.zeros(256, dtype=np.complex64)
+    initial = np.zeros(256 * 4, dtype=np.complex64)
+    clk0 = int(dev.readSetting("CLOCK_NOW"))
+    dev.writeSetting("CLOCK_ADVANCE", 5000)                            # nothing runs before the first write
+    assert dev.writeStream(tx, [initial], len(initial)).ret == 1024    # starts both streams
+    ref = rx_reference(oracle, 4, 256 * 40)
+    for i in range(40):
+        r = dev.readStream(rx, [buf], len(buf))
+        assert r.ret == 256 and r.timeNs == oracle.ticks_to_time_ns(256 * i, RATE)
+        assert_bit_exact(buf, ref[256 * i:256 * (i + 1)], "linked rx %d" % i)
+        assert dev.writeStream(tx, [buf], len(buf)).ret == 256
+    assert int(dev.readSetting("CLOCK_NOW")) == clk0 + 5000 + 256 * 40
+    # TX starves: both linked streams stop (:36-43, :497-501)
+    dev.writeSetting("CLOCK_ADVANCE", 2000)
+    assert dev.writeStream(tx, [buf], len(buf)).ret == SoapySDR.SOAPY_SDR_UNDERFLOW
+    assert dev.readStream(rx, [buf], len(buf)).ret == SoapySDR.SOAPY_SDR_OVERFLOW
+
+
+def test_decim8_interp8_chain(oracle):
+    """BASELINE config 3 shape: 256-tap decimate-by-8 RX and interpolate-by-8 TX, full duplex."""
+    dev = make(decim="8", interp="8")
+    assert dev.readSetting("RX_NTAPS") == "256"
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    ref = rx_reference(oracle, 8, 1024 * 4)
+    buf = np.zeros(1024, dtype=np.complex64)
+    latency = 2048                                                     # > one block, or the write is in the past
+    dt = oracle.ticks_to_time_ns(latency, RATE)
+    stream = np.zeros(latency + 4096, dtype=np.complex64)
+    for i in range(4):
+        r = dev.readStream(rx, [buf], 1024)
+        assert r.ret == 1024
+        assert_bit_exact(buf, ref[1024 * i:1024 * (i + 1)], "rx d8 block %d" % i)
+        assert dev.writeStream(tx, [buf], 1024, flags=SoapySDR.SOAPY_SDR_HAS_TIME, timeNs=r.timeNs + dt).ret == 1024
+        assert int(dev.readSetting("TX_POSITION")) == 1024 * (i + 1) + latency
+        stream[latency + 1024 * i: latency + 1024 * (i + 1)] = buf
+    got = dev.txCapture(0, len(stream) * 8)
+    assert_bit_exact(got, tx_reference(oracle, 8, stream), "dac stream L=8")
+
+
+def test_wall_clock_mode():
+    """Free-running clock: a blocking read of one period takes about period / rate."""
+    import time
+    dev = SoapySDR.Device({"driver": "sx", "clock": "wall"})
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 600000.0)
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "8192"})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    assert dev.getHardwareTime() == 0                                  # hardware time is the TX side's clock
+    dev.activateStream(rx)                                             # linked: both PCMs start together
+    dev.activateStream(tx)
+    buf = np.zeros(60000, dtype=np.complex64)
+    t0 = time.time()
+    r = dev.readStream(rx, [buf], len(buf))
+    dt = time.time() - t0
+    assert r.ret == 60000 and r.timeNs == 0
+    assert 0.08 <= dt < 1.0                                            # 0.1 s of signal
+    t1 = dev.getHardwareTime()
+    time.sleep(0.05)
+    assert dev.getHardwareTime() - t1 >= 40_000_000
