@@ -51,6 +51,7 @@ struct sxfir_plan {
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
     int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
     int oversub;           // waves launched = CUs * occupancy * oversub
+    int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int compute_units;
     float *taps_dev;
@@ -150,12 +151,14 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         p->cw = 1;
     }
 
-    // measured on MI355X (tools/kbench.py): single-buffered LDS-DMA at 16 waves/CU with four
-    // generations of waves beats the double-buffered variant at 8 waves/CU
+    // measured on MI355X (tools/kbench.py): single-buffered LDS-DMA at 16 waves/CU, 16 generations
+    // of short-lived waves (4 tiles each at 2^28 samples), strided XCD-blocked passes; the
+    // double-buffered variant at 8 waves/CU and long contiguous runs are slower
     p->tile_dbuf = false;
     p->occ_sb = p->occ_db = 8;
-    p->oversub = 4;
+    p->oversub = 16;
     p->ablate = 0;
+    p->sched = 0;
     if (p->tile_capable) {
         int nb = 0;
         const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
@@ -167,6 +170,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         // experiment knobs (profiling only; defaults are what ships)
         if (const char *v = getenv("SXFIR_TILE_VARIANT")) p->tile_dbuf = (strcmp(v, "sb") != 0);
         if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
+        if (const char *v = getenv("SXFIR_SCHED")) p->sched = atoi(v);
         if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
         if (const char *v = getenv("SXFIR_OCC")) {
             if (atoi(v) > 0) p->occ_sb = p->occ_db = atoi(v);
@@ -297,11 +301,14 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         if (per_chan > n_tiles) per_chan = n_tiles;
         a.n_tiles = (int)n_tiles;
         a.n_waves = (int)per_chan;
+        a.sched = p->sched;
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
         if (p->ntaps == 128 && p->ablate == 1) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 1>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->ablate == 2) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 2>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 3) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 3>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128) {
             if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
             else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);

@@ -1,0 +1,126 @@
+"""Parity of the remaining HIP kernels behind the C ABI: interpolator,
+synthetic source, S32 wire-format converters, CF16 storage."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import sxxcvr_amd
+from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE
+from gpu_util import assert_bit_exact, to_cpu, to_gpu
+
+pytestmark = pytest.mark.gpu
+SEED = 0x51255
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def test_synth_source_matches_oracle(oracle):
+    import torch
+    x = torch.empty((3, 5000), dtype=torch.complex64, device="cuda")
+    sxxcvr_amd.synth_fill(x, SEED, first_channel=5, start=-100)
+    _sync()
+    got = to_cpu(x)
+    for c in range(3):
+        assert_bit_exact(got[c], oracle.synth_iq(SEED, 5 + c, -100, 5000), "synth channel %d" % c)
+    assert not got[:, :100].any()
+
+
+@pytest.mark.parametrize("ntaps,L", [(256, 8), (128, 4), (96, 3), (5, 5), (64, 1)])
+def test_interpolator_bit_exact(oracle, ntaps, L):
+    h = sxxcvr_amd.design_lowpass(ntaps, L, 8.0, float(L))
+    x = oracle.synth_iq(SEED, 7, 0, 3000)
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, L)
+    js, cw = plan.contract
+    assert cw == 1
+    y = to_cpu(plan.process(to_gpu(x)))
+    assert_bit_exact(y, oracle.interp_f32(h, L, x, js), "interp %d/%d" % (ntaps, L))
+    assert plan.position == (3000, 3000 * L)
+
+
+def test_interpolator_streaming_and_golden(oracle, golden_dir):
+    h = np.load(os.path.join(golden_dir, "taps.npz"))["n256_l8"]
+    kat = np.load(os.path.join(golden_dir, "fir_kat.npz"))
+    x = kat["x"][:256]
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, 8)
+    parts = [to_cpu(plan.process(to_gpu(x[a:b]))) for a, b in ((0, 1), (1, 100), (100, 101), (101, 256))]
+    y = np.concatenate(parts)
+    assert_bit_exact(y, oracle.interp_f32(h, 8, x, 2), "chunked interp")
+    err = np.max(np.abs(y.astype(np.complex128) - kat["interp_n256_l8"])) / float(np.abs(h).sum())
+    assert err < 2e-6
+
+
+def test_decim_then_interp_roundtrip(oracle):
+    """Size-independent property: a band-limited tone survives decimate-by-4 then interpolate-by-4."""
+    n = 1 << 16
+    t = np.arange(n)
+    x = (0.5 * np.exp(2j * np.pi * 0.01 * t)).astype(np.complex64)      # well inside the 0.125 cutoff
+    hd = sxxcvr_amd.design_lowpass(128, 4)
+    hi = sxxcvr_amd.design_lowpass(128, 4, 8.0, 4.0)
+    y = to_cpu(sxxcvr_amd.Resampler(DECIMATE, hd, 4).process(to_gpu(x)))
+    z = to_cpu(sxxcvr_amd.Resampler(INTERPOLATE, hi, 4).process(to_gpu(y)))
+    delay = 127                                                         # two linear-phase 128-tap filters: (127/2) * 2
+    a, b = z[1000 + delay: n - 1000], x[1000: n - 1000 - delay]
+    assert np.max(np.abs(a - b)) < 2e-3
+
+
+def test_s32_wire_converters(oracle, golden_dir):
+    import torch
+    lib = sxxcvr_amd.load_sxfir()
+    kat = np.load(os.path.join(golden_dir, "convert_kat.npz"))
+    rng = np.random.default_rng(5)
+    s32 = np.concatenate([kat["s32"], rng.integers(-2 ** 31, 2 ** 31, size=100000, dtype=np.int64).astype(np.int32)])
+    src = to_gpu(s32)
+    dst = torch.empty(s32.size // 2, dtype=torch.complex64, device="cuda")
+    sxxcvr_amd._native.check(lib.sxfir_convert_rx_s32(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                                      s32.size // 2, None))
+    _sync()
+    assert_bit_exact(to_cpu(dst), oracle.convert_rx(s32), "convert_rx")
+    tx_in = np.concatenate([kat["tx_in"], (rng.uniform(-1.3, 1.3, 50000) + 1j * rng.uniform(-1.3, 1.3, 50000)),
+                            [complex(np.nan, 0.5), complex(np.inf, -np.inf), 1 + 1j, -1 - 1j]]).astype(np.complex64)
+    thr2 = float(kat["thr2"][0])
+    src = to_gpu(tx_in)
+    out = torch.empty(2 * tx_in.size, dtype=torch.int32, device="cuda")
+    sxxcvr_amd._native.check(lib.sxfir_convert_tx_s32(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                      tx_in.size, thr2, None))
+    _sync()
+    assert np.array_equal(to_cpu(out), oracle.convert_tx(tx_in, thr2))
+    assert np.array_equal(to_cpu(out)[: 2 * len(kat["tx_in"])], kat["tx"])
+
+
+def test_cf16_storage_path(oracle, golden_dir):
+    """BASELINE config 5 shape: 1024-tap decimate-by-32, IQ stored as half, fp32 arithmetic.
+    Bit-exact against the oracle run on the half-rounded input and rounded to half at the end;
+    and within the stated tolerance of the CF32 path."""
+    import torch
+    lib = sxxcvr_amd.load_sxfir()
+    h = np.load(os.path.join(golden_dir, "taps.npz"))["n1024_d32"]
+    n = 1 << 15
+    x = oracle.synth_iq(SEED, 9, 0, n)
+    xg = to_gpu(x)
+    x16 = torch.empty(n, dtype=torch.int32, device="cuda")
+    sxxcvr_amd._native.check(lib.sxfir_cf32_to_cf16(C.c_void_p(xg.data_ptr()), C.c_void_p(x16.data_ptr()), n, None))
+    _sync()
+    x16_ref = oracle.f32_to_f16(x.view(np.float32))
+    assert np.array_equal(to_cpu(x16).view(np.uint16), x16_ref)
+    plan16 = sxxcvr_amd.Resampler(DECIMATE, h, 32, fmt="CF16")
+    y16 = plan16.process(x16)
+    _sync()
+    xq = oracle.f16_to_f32(x16_ref).view(np.complex64)
+    want32 = oracle.decim_f32(h, 32, xq, *plan16.contract)
+    want16 = oracle.f32_to_f16(want32.view(np.float32))
+    assert np.array_equal(to_cpu(y16).view(np.uint16), want16)
+    # against the CF32 path: error normalised by sum|h|; half has 11 significant bits
+    y32 = to_cpu(sxxcvr_amd.Resampler(DECIMATE, h, 32).process(xg))
+    back = oracle.f16_to_f32(to_cpu(y16).view(np.uint16)).view(np.complex64)
+    err = np.max(np.abs(back - y32)) / float(np.abs(h).sum())
+    assert err < 2.0 ** -10, err
+    # and a CF16 synthetic source equals the half-rounded CF32 source
+    s16 = torch.empty(4096, dtype=torch.int32, device="cuda")
+    sxxcvr_amd.synth_fill(s16, SEED, 9, 0, fmt="CF16")
+    _sync()
+    assert np.array_equal(to_cpu(s16).view(np.uint16), oracle.f32_to_f16(x[:4096].view(np.float32)))

@@ -14,7 +14,7 @@ configs = []
 for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
     f = spec.split(":")
     v, ov, occ = f[0], f[1], f[2]
-    configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0))
+    configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0, int(f[4]) if len(f) > 4 else 0))
 
 n = (1 << log2n) // nchan
 x = torch.empty((nchan, n), dtype=torch.complex64, device="cuda")
@@ -22,10 +22,11 @@ sxxcvr_amd.synth_fill(x, 0x51255, 0, 0)
 y = torch.empty((nchan, n // 4), dtype=torch.complex64, device="cuda")
 taps = sxxcvr_amd.design_lowpass(128, 4)
 plans = []
-for v, ov, occ, abl in configs:
+for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_TILE_VARIANT"] = v
     os.environ["SXFIR_OVERSUB"] = str(ov)
     os.environ["SXFIR_ABLATE"] = str(abl)
+    os.environ["SXFIR_SCHED"] = str(sched)
     if occ: os.environ["SXFIR_OCC"] = str(occ)
     else: os.environ.pop("SXFIR_OCC", None)
     plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, 4, nchan=nchan))
@@ -46,4 +47,4 @@ for c in configs:
     a = np.array(res[c])
     gbs = 10.0 * (1 << log2n) / (a * 1e-3) / 1e9
     print("%-12s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
-        "%s:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
+        "%s:%d:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
