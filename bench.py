@@ -4,9 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one streaming pass of the 128-tap decimate-by-4 CF32 polyphase
-FIR (sxfir_decimate through the C ABI: resampling kernel + history carry-over)
+FIR (sxfir_decimate through the C ABI: one kernel launch, history carry-over fused)
 over the rank's resident synthetic IQ block (2^28 complex samples per GPU,
-already in HBM when the timed region starts).  N = 1 runs BASELINE config 2
+already in HBM when the timed region starts); consecutive steps are consecutive
+blocks of one continuous stream (filter history carried over on the GPU).  N = 1 runs BASELINE config 2
 (1 channel); N > 1 runs config 4's layout (8 independent channels per GPU,
 8*N in total, no data-path collective), and measures the RCCL gather of the
 decimated output to rank 0 separately (reported under "gather", never part of
@@ -48,30 +49,31 @@ def cpu_baseline(seconds_target=12.0):
         if line.startswith("model name"):
             model = line.split(":", 1)[1].strip()
             break
-    n_probe = 1 << 20
+    n_probe = 1 << 21
     x = orc.synth_iq(SEED, 0, 0, n_probe)
     t0 = time.perf_counter()
     orc.decim_f32(taps, DECIM, x, 2, 4, threads=1)
     t1 = time.perf_counter() - t0
     one_thread = n_probe / t1 / 1e6
-    t0 = time.perf_counter()
-    orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)
-    tn = time.perf_counter() - t0
-    rate = n_probe / tn
-    n = int(min(max(rate * seconds_target, n_probe), 1 << 28))
-    n -= n % 4096
+    # bounded sample: the first 2^26 input samples of the workload's stream, filtered repeatedly
+    # until about `seconds_target` of wall time has been spent
+    n = 1 << 26
     x = orc.synth_iq(SEED, 0, 0, n)
+    orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)          # warm-up (page faults, thread pool)
+    reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)
-    dt = time.perf_counter() - t0
+    while dt < seconds_target and reps < 1000:
+        orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)
+        reps += 1
+        dt = time.perf_counter() - t0
     return {
-        "value": round(n / dt / 1e6, 2),
+        "value": round(n * reps / dt / 1e6, 2),
         "unit": "MS/s (complex input samples)",
         "cores": threads,
         "kind": "port",
-        "sample": "first %d input samples of the same synthetic channel-0 stream, %d threads (OpenMP over "
-                  "output blocks), %s build; the reference has no software FIR, this is the build's own "
-                  "CPU FIR" % (n, threads, "AVX2+FMA" if fast else "portable"),
+        "sample": "first %d input samples of the same synthetic channel-0 stream filtered %d times, %d threads "
+                  "(OpenMP over output blocks), %s build; the reference has no software FIR, this is the "
+                  "build's own CPU FIR" % (n, reps, threads, "AVX2+FMA" if fast else "portable"),
         "one_thread_value": round(one_thread, 2),
         "cpu_model": model,
         "seconds": round(dt, 2),
@@ -81,8 +83,10 @@ def cpu_baseline(seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the chip's power management needs ~20 launches (~10 ms) of this kernel to settle
+    # (kernel time swings 0.50 -> 0.77 -> 0.60 ms before it does), so warm up past that
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (log2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -122,7 +126,8 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        plan.reset()          # every step filters the same block from stream start (async memset)
+        # one streaming pass: the block is the next 2^28 samples of a continuous stream (the filter
+        # history carries over from the previous step, as it does in readStream)
         plan.process(x, out=y)
 
     for _ in range(args.warmup):
@@ -149,7 +154,7 @@ def main():
     plan.reset()
     torch.cuda.synchronize()
     kernel_ms = plan.time_decimate_ptr(x.data_ptr(), n_in, x.stride(0) if nchan_local > 1 else n_in, y.data_ptr(),
-                                       y.stride(0) if nchan_local > 1 else n_in // DECIM, max(args.steps, 5), stream)
+                                       y.stride(0) if nchan_local > 1 else n_in // DECIM, min(max(args.steps, 20), 200), stream)
     achieved = BYTES_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e9
 
     gather = None

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "sxfir_decim_tile.hip.h"
@@ -55,7 +56,8 @@ struct sxfir_plan {
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int compute_units;
     float *taps_dev;
-    void *hist_dev;        // nchan * hist_len samples
+    void *hist_dev;        // current history: nchan * hist_len samples
+    void *hist_alt;        // the tile kernel writes the next history here, then the two swap
     long long consumed, produced;
 };
 
@@ -131,6 +133,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->consumed = p->produced = 0;
     p->taps_dev = nullptr;
     p->hist_dev = nullptr;
+    p->hist_alt = nullptr;
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
@@ -179,11 +182,13 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
 
     hipError_t e = hipMalloc((void **)&p->taps_dev, sizeof(float) * (size_t)ntaps);
     if (e == hipSuccess) e = hipMalloc(&p->hist_dev, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
+    if (e == hipSuccess) e = hipMalloc(&p->hist_alt, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e == hipSuccess) e = hipMemcpy(p->taps_dev, taps, sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(p->hist_dev, 0, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e != hipSuccess) {
         if (p->taps_dev) (void)hipFree(p->taps_dev);
         if (p->hist_dev) (void)hipFree(p->hist_dev);
+        if (p->hist_alt) (void)hipFree(p->hist_alt);
         delete p;
         return fail(SXFIR_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
     }
@@ -196,6 +201,7 @@ int sxfir_destroy(sxfir_plan *p)
     if (!p) return SXFIR_OK;
     (void)hipFree(p->taps_dev);
     (void)hipFree(p->hist_dev);
+    (void)hipFree(p->hist_alt);
     delete p;
     return SXFIR_OK;
 }
@@ -268,8 +274,9 @@ static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t
 
 // Launch only the resampling kernel (no history update, no position change).
 static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
-                        size_t out_stride, long long n_out, hipStream_t st)
+                        size_t out_stride, long long n_out, hipStream_t st, bool *history_done)
 {
+    *history_done = false;
     const long long D = p->ratio;
     const long long first = ((p->consumed + D - 1) / D) * D - p->consumed;
     bool tiled = p->tile_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
@@ -283,7 +290,9 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         sxfir::DecimTileArgs a;
         a.in = (const float *)in_dev;
         a.hist = (const float *)p->hist_dev;
+        a.hist_out = (float *)p->hist_alt;
         a.out = (float *)out_dev;
+        *history_done = true;      // caller swaps hist_dev / hist_alt when it commits the call
         a.taps = p->taps_dev;
         a.n_in = (long long)n_in;
         a.n_out = n_out;
@@ -366,12 +375,17 @@ int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_str
     if (rc) return rc;
     if (n_in == 0) return SXFIR_OK;
     HIPCHECK(hipSetDevice(p->device));
+    bool history_done = false;
     if (n_out > 0) {
-        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream));
+        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
         if (rc) return rc;
     }
-    rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
-    if (rc) return rc;
+    if (history_done) {
+        std::swap(p->hist_dev, p->hist_alt);
+    } else {
+        rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+        if (rc) return rc;
+    }
     p->consumed += (long long)n_in;
     p->produced += n_out;
     if (n_out_p) *n_out_p = (size_t)n_out;
@@ -432,7 +446,8 @@ int sxfir_time_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     HIPCHECK(hipEventCreate(&e1));
     HIPCHECK(hipEventRecord(e0, S(stream)));
     for (int i = 0; i < iters; ++i) {
-        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream));
+        bool history_done = false;   // history buffers are not swapped: every pass filters from the same state
+        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
         if (rc) break;
     }
     hipError_t e = hipEventRecord(e1, S(stream));

@@ -36,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct DecimTileArgs {
     const float *in;        // channel 0, sample 0 of this call (16-byte aligned)
     const float *hist;      // channel 0 history: HIST samples preceding `in`
+    float *hist_out;        // where the wave of the last tile leaves the history for the next call
     float *out;             // channel 0, first output of this call
     const float *taps;      // NT floats (device)
     long long n_in;         // new input samples per channel
@@ -232,6 +233,22 @@ __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile
     store_tile<NT>(c, tile, oi, oq);
 }
 
+// History carry-over fused into the launch (no second kernel): the wave that owns the last tile
+// copies the last HIST samples of (hist ++ in) into the plan's OTHER history buffer (the current
+// one is still being read by the wave of tile 0).
+template <int NT>
+__device__ __forceinline__ void write_history(const DecimTileCtx<NT> &c, float *hist_out, long long n_in)
+{
+    using C = DecimTile4<NT>;
+#pragma unroll
+    for (int j = c.lane; j < C::HIST; j += 64) {
+        const long long s = n_in - C::HIST + j;
+        const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(c.in)[s]
+                                : reinterpret_cast<const float2 *>(c.hist)[s + C::HIST];
+        reinterpret_cast<float2 *>(hist_out)[j] = v;
+    }
+}
+
 #define SXFIR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // ABL (profiling builds only; 3 = packed-FMA arithmetic): 0 = the real kernel, 1 = stage + store but no FIR arithmetic
@@ -282,6 +299,12 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
         tile_step = 1;
     }
     if (tile_begin >= tile_end) return;
+
+    // the wave that owns the last tile also carries the history over (before it issues any DMA, so
+    // the counted vmcnt waits of the double-buffered loop are not disturbed)
+    const int last = a.n_tiles - 1;
+    if (last >= tile_begin && last < tile_end && (last - tile_begin) % tile_step == 0)
+        write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
 
     if constexpr (!DBUF) {
         for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
