@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "sxfir_decim_tile.hip.h"
+#include "sxfir_decim_multi.hip.h"
 #include "sxfir_kernels.hip.h"
 
 namespace {
@@ -48,7 +49,10 @@ struct sxfir_plan {
     int kernel;            // SXFIR_KERNEL_*
     int hist_len;          // samples of history kept per channel
     int jsplit, cw;        // numeric contract
-    bool tile_capable;
+    bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
+    bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
+    int multi_waves;       // waves per workgroup of the multi kernel
+    int occ_multi;         // resident workgroups per CU of the multi kernel
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
     int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
     int oversub;           // waves launched = CUs * occupancy * oversub
@@ -138,6 +142,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
         p->tile_capable = (fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64));
+        p->multi_capable = (fmt == SXFIR_CF32 && ntaps == 32 * ratio && (ratio == 8 || ratio == 16 || ratio == 32));
         const int jt = (ntaps + ratio - 1) / ratio;
         if (ntaps % ratio == 0 && ratio % 4 == 0 && jt % 2 == 0) {
             p->jsplit = 2;
@@ -150,6 +155,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const int jt = ntaps / ratio;
         p->hist_len = (jt + 1) & ~1;
         p->tile_capable = false;
+        p->multi_capable = false;
         p->jsplit = (jt % 2 == 0) ? 2 : 1;
         p->cw = 1;
     }
@@ -162,6 +168,27 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->oversub = 16;
     p->ablate = 0;
     p->sched = 0;
+    // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
+    // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
+    p->multi_waves = ratio == 8 ? 1 : (ratio == 16 ? 2 : 4);
+    p->occ_multi = 2;
+    if (p->multi_capable) {
+        if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
+        // resident workgroups per CU: LDS is the limiter (checked against the occupancy API below)
+        const int W = p->multi_waves;
+        int nb = 0;
+        const void *k = nullptr;
+        switch (ratio * 100 + W) {
+        case 801: k = (const void *)sxfir::decim_multi_kernel<8, 1>; break;
+        case 804: k = (const void *)sxfir::decim_multi_kernel<8, 4>; break;
+        case 1602: k = (const void *)sxfir::decim_multi_kernel<16, 2>; break;
+        case 3204: k = (const void *)sxfir::decim_multi_kernel<32, 4>; break;
+        case 3208: k = (const void *)sxfir::decim_multi_kernel<32, 8>; break;
+        }
+        if (k && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0)
+            p->occ_multi = nb;
+        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
+    }
     if (p->tile_capable) {
         int nb = 0;
         const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
@@ -219,7 +246,7 @@ int sxfir_set_kernel(sxfir_plan *p, int kernel)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
     if (kernel < SXFIR_KERNEL_AUTO || kernel > SXFIR_KERNEL_GENERIC) return fail(SXFIR_EINVAL, "bad kernel id");
-    if (kernel == SXFIR_KERNEL_TILED && !p->tile_capable)
+    if (kernel == SXFIR_KERNEL_TILED && !p->tile_capable && !p->multi_capable)
         return fail(SXFIR_EUNSUPPORTED, "no tiled kernel for ntaps=%d ratio=%d fmt=%d mode=%d", p->ntaps,
                     p->ratio, p->fmt, p->mode);
     p->kernel = kernel;
@@ -282,6 +309,47 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     bool tiled = p->tile_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
                  ((uintptr_t)in_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) &&
                  (p->nchan == 1 || (in_stride % 2 == 0 && out_stride % 2 == 0));
+    const bool multi = p->multi_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
+                       ((uintptr_t)in_dev % 8 == 0) && ((uintptr_t)out_dev % 16 == 0) &&
+                       (p->nchan == 1 || out_stride % 2 == 0);
+    if (multi) {
+        sxfir::DecimMultiArgs a;
+        a.in = (const float *)in_dev;
+        a.hist = (const float *)p->hist_dev;
+        a.hist_out = (float *)p->hist_alt;
+        a.out = (float *)out_dev;
+        a.taps = p->taps_dev;
+        a.n_in = (long long)n_in;
+        a.n_out = n_out;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hist_stride = p->hist_len;
+        const int W = p->multi_waves;
+        const int tile_out = W * 8 * (32 / (p->ratio / 4));
+        const long long n_tiles = (n_out + tile_out - 1) / tile_out;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        long long groups = ((long long)p->compute_units * p->occ_multi * p->oversub) / p->nchan;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        a.n_tiles = (int)n_tiles;
+        a.n_groups = (int)groups;
+        dim3 grid((unsigned)groups, (unsigned)p->nchan);
+#define SXFIR_LAUNCH_MULTI(DD, WW) \
+        hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW>), grid, dim3(64 * WW), 0, st, a)
+        const int key = p->ratio * 100 + W;
+        switch (key) {
+        case 801: SXFIR_LAUNCH_MULTI(8, 1); break;
+        case 804: SXFIR_LAUNCH_MULTI(8, 4); break;
+        case 1602: SXFIR_LAUNCH_MULTI(16, 2); break;
+        case 3204: SXFIR_LAUNCH_MULTI(32, 4); break;
+        case 3208: SXFIR_LAUNCH_MULTI(32, 8); break;
+        default: return fail(SXFIR_EUNSUPPORTED, "no multi kernel for ratio %d with %d waves", p->ratio, W);
+        }
+#undef SXFIR_LAUNCH_MULTI
+        HIPCHECK(hipGetLastError());
+        *history_done = true;
+        return SXFIR_OK;
+    }
     if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
         return fail(SXFIR_EUNSUPPORTED,
                     "tiled kernel needs 16-byte aligned buffers, even strides and a call that starts on an "

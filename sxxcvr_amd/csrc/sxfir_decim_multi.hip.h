@@ -1,0 +1,252 @@
+// LDS-tiled polyphase FIR decimator for gfx950, any decimation D = 4*NCOL
+// (4, 8, 16, 32) with 32 taps per phase (NT = 32*D): BASELINE configs 3 (256
+// taps, /8) and 5 (1024 taps, /32).  New code, like sxfir_decim_tile.hip.h: the
+// reference decimates inside the SX1255 (SoapySX.cpp:180-208 only programs it).
+//
+// Idea: a decimate-by-D polyphase filter is the sum over NCOL = D/4 "column
+// groups" c of a decimate-by-4 filter: group c owns phases r in [4c, 4c+4),
+//     y[m] = sum_c  sum_j sum_rr  h[D*j + 4c + rr] * x[D*(m-j) - 4c - rr].
+// Per group the samples it touches form a sub-stream of rows (one row = the 4
+// samples x[D*q-4c-3 .. D*q-4c] of output row q).  The LDS image holds the NCOL
+// sub-streams de-interleaved, each as a dense padded row sequence, so a lane's
+// window is contiguous and the inner loop is the decimate-by-4 one: 46
+// ds_read_b128 feeding 1024 v_fmac per lane.  The de-interleave costs nothing:
+// LDS-DMA (global_load_lds_dwordx4) takes a per-lane SOURCE address, so each
+// 16-byte piece (half a row) is fetched from wherever it lives; pieces start
+// on odd sample indices (8-byte aligned sources, verified on MI355X).
+//
+// Workgroup = W waves sharing one tile of W*1024 input samples (+ 31 halo
+// rows); every wave owns 1024 of them: lanes = (p, c, g): tap-row half p (lane
+// bit 5), column group c (next lane bits), output group g (8 outputs each).
+// Reduction: v_permlane32_swap over p, v_permlane16_swap over c bit 0, lane
+// xor 8 / xor 4 for c bits 1, 2: the adjacent-pair trees of the numeric
+// contract: first over the two row halves, then over the columns.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sxfir_decim_tile.hip.h"
+
+namespace sxfir {
+
+struct DecimMultiArgs {
+    const float *in;        // channel 0, sample 0 of this call (8-byte aligned is enough)
+    const float *hist;      // NT samples preceding `in`
+    float *hist_out;
+    float *out;             // 16-byte aligned
+    const float *taps;
+    long long n_in, n_out;
+    long long in_stride, out_stride, hist_stride;
+    int n_tiles;            // workgroup tiles per channel
+    int n_groups;           // workgroups per channel (strided passes over the tiles)
+};
+
+template <int D, int W>
+struct DecimMulti {
+    static constexpr int NT = 32 * D;
+    static constexpr int NCOL = D / 4;
+    static constexpr int GW = 32 / NCOL;                  // output groups per wave
+    static constexpr int R = 8;                           // outputs per lane
+    static constexpr int OW = GW * R;                     // outputs per wave
+    static constexpr int TILE_OUT = W * OW;
+    static constexpr int NROWS = TILE_OUT + 31;           // rows q in [M0 - 31, M0 + TILE_OUT)
+    static constexpr int CH = 2 * NROWS;                  // 16-byte chunks per sub-stream
+    static constexpr int SUBSL = CH + CH / 16 + 1;        // with one pad chunk after every 16
+    // sub-stream pitch: a whole number of DMA instructions (64 slots) with room for the bank skew
+    static constexpr int IPS = (SUBSL + (NCOL >= 4 ? 12 : 0) + 63) / 64;   // DMA instructions per sub-stream
+    static constexpr int SUBSTRIDE = IPS * 64;
+    static constexpr int NI = NCOL * IPS;                 // DMA instructions per tile (all waves together)
+    static constexpr int LDS_SLOTS = NI * 64;
+    static constexpr int WCH = 46;                        // window chunks per lane: 23 rows
+    static_assert(D % 4 == 0 && (NCOL & (NCOL - 1)) == 0 && NCOL <= 8, "D must be 4, 8, 16 or 32");
+    static_assert(SUBSL < 4000, "the (r+1)/17 multiply-shift is exact below 4000 only");
+    // bank skew per column group so that the 16 lanes of every ds_read_b128 group differ in slot
+    static __device__ __forceinline__ int skew(int c)
+    {
+        return NCOL == 8 ? 8 * (c & 1) + 4 * ((c >> 1) & 1) : (NCOL == 4 ? 8 * (c & 1) : 0);
+    }
+};
+
+__device__ __forceinline__ void permlane16_swap(float &vdst, float &src)
+{
+    // odd 16-lane rows of vdst <-> even rows of src (inline asm for the same reason as permlane32_swap)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(vdst), "+v"(src));
+}
+
+template <int D, int W>
+__global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArgs a)
+{
+    using C = DecimMulti<D, W>;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ww = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane >> 5;
+    // column group: c bit 0 = lane bit 4, c bit 1 = lane bit 3, c bit 2 = lane bit 2
+    int c = 0;
+    if (C::NCOL >= 2) c |= (lane >> 4) & 1;
+    if (C::NCOL >= 4) c |= ((lane >> 3) & 1) << 1;
+    if (C::NCOL >= 8) c |= ((lane >> 2) & 1) << 2;
+    const int g = lane & (C::GW - 1);
+    const int ch = blockIdx.y;
+
+    const float *in = a.in + 2 * a.in_stride * ch;
+    const float *hist = a.hist + 2 * a.hist_stride * ch;
+    float *out = a.out + 2 * a.out_stride * ch;
+
+    // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16p + jj) + 4c + rr
+    float h[64];
+#pragma unroll
+    for (int kl = 0; kl < 64; ++kl) h[kl] = a.taps[D * (16 * p + (kl >> 2)) + 4 * c + (kl & 3)];
+
+    const int G = ww * C::GW + g;                          // output group inside the workgroup tile
+    const int cc0 = 16 * (G - 2 * p + 2);                  // first window chunk in the sub-stream (multiple of 16)
+    const f32x4 *win = lds + (c * C::SUBSTRIDE + C::skew(c) + cc0 + (cc0 >> 4));
+
+    // fused history carry-over: workgroup 0's last wave (channel ch) copies the tail of (hist ++ in)
+    if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && ww == W - 1) {
+        float *ho = a.hist_out + 2 * a.hist_stride * ch;
+        for (int j = lane; j < C::NT; j += 64) {
+            const long long s = a.n_in - C::NT + j;
+            const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
+                                    : reinterpret_cast<const float2 *>(hist)[s + C::NT];
+            reinterpret_cast<float2 *>(ho)[j] = v;
+        }
+    }
+
+    // Tile-invariant part of the staging: byte offset (from the tile's first row, sample
+    // x[D*(M0-31)]) of the 16-byte piece each of this wave's DMA instructions fetches for this lane.
+    constexpr int NIW = (C::NI + W - 1) / W;
+    int poff[NIW];
+#pragma unroll
+    for (int i0 = 0; i0 < NIW; ++i0) {
+        // Issue order: row block kb of every sub-stream before row block kb+1, so the NCOL pieces
+        // that share a 128-byte line of the input are fetched close together (L1 hits at D = 32).
+        const int o = i0 * W + ww;
+        const int kb = o / C::NCOL, cs = o % C::NCOL;      // sub-stream (column group) of this instruction
+        int r = 64 * kb + lane - C::skew(cs);              // slot inside the sub-stream image
+        r = r < 0 ? 0 : (r >= C::SUBSL - 1 ? C::SUBSL - 2 : r);
+        const int cc = r - (((r + 1) * 3856) >> 16);       // logical chunk (pad slots dup a neighbour)
+        // piece = samples x[D*q - 4c - 3 + 2*half], +1 with q = M0 - 31 + (cc >> 1), half = cc & 1
+        poff[i0] = 8 * (D * (cc >> 1) - 4 * cs - 3 + 2 * (cc & 1));
+    }
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
+        const long long M0 = (long long)tile * C::TILE_OUT;
+        // samples of the tile: [D*(M0-32)+1, D*(M0+TILE_OUT-1)]; interior = all inside `in`
+        const bool interior = (M0 >= 32) && (D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1);
+        const long long s_base = D * (M0 - 31);
+        const char *base = reinterpret_cast<const char *>(in) + 8 * s_base;
+
+        __syncthreads();                                   // everyone is done reading the previous tile
+        // ---- stage: the W waves share the NI DMA instructions -------------------
+#pragma unroll
+        for (int i0 = 0; i0 < NIW; ++i0) {
+            const int o = i0 * W + ww;
+            if (o < C::NI) {
+                const int i = (o % C::NCOL) * C::IPS + o / C::NCOL;      // instruction's place in the LDS image
+                if (interior) {
+                    glds16(base + poff[i0], lds + 64 * i);
+                } else {
+                    // edge tiles (first / last of a call): through registers, sample by sample
+                    const long long s = s_base + (poff[i0] >> 3);
+                    float2 v0, v1;
+                    const long long s1 = s + 1;
+                    const long long last = a.n_in - 1;
+                    if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
+                    else v0 = (s + C::NT >= 0) ? reinterpret_cast<const float2 *>(hist)[s + C::NT] : make_float2(0.f, 0.f);
+                    if (s1 >= 0) v1 = reinterpret_cast<const float2 *>(in)[s1 <= last ? s1 : last];
+                    else v1 = (s1 + C::NT >= 0) ? reinterpret_cast<const float2 *>(hist)[s1 + C::NT] : make_float2(0.f, 0.f);
+                    lds[64 * i + lane] = (f32x4){v0.x, v0.y, v1.x, v1.y};
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMAs landed ...
+        __syncthreads();                                   // ... and everybody else's
+
+        // ---- compute: window sample w meets output i at local tap kl = 4*i + 63 - w ---
+        float ai[8], aq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < C::WCH; ++t) {
+            const f32x4 v = win[t + (t >> 4)];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int w = 2 * t + s;
+                const float xi = s ? v.z : v.x;
+                const float xq = s ? v.w : v.y;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kl = 4 * i + 63 - w;
+                    if (kl >= 0 && kl < 64) {
+                        ai[i] = __builtin_fmaf(h[kl], xi, ai[i]);
+                        aq[i] = __builtin_fmaf(h[kl], xq, aq[i]);
+                    }
+                }
+            }
+        }
+
+        // ---- reduce over p: outputs 0-3 stay on the low half-wave, 4-7 on the high one
+        float oi[4], oq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            permlane32_swap(ai[i], ai[i + 4]);
+            permlane32_swap(aq[i], aq[i + 4]);
+            oi[i] = __fadd_rn(ai[i], ai[i + 4]);
+            oq[i] = __fadd_rn(aq[i], aq[i + 4]);
+        }
+        const long long mw = M0 + (long long)ww * C::OW + 8 * g + 4 * p;
+        if constexpr (C::NCOL == 1) {
+            float *dst = out + 2 * mw;
+            if (mw + 4 <= a.n_out) {
+                __builtin_nontemporal_store((f32x4){oi[0], oq[0], oi[1], oq[1]}, reinterpret_cast<f32x4 *>(dst));
+                __builtin_nontemporal_store((f32x4){oi[2], oq[2], oi[3], oq[3]}, reinterpret_cast<f32x4 *>(dst + 4));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (mw + i < a.n_out) { dst[2 * i] = oi[i]; dst[2 * i + 1] = oq[i]; }
+            }
+        } else {
+            // ---- reduce over column bit 0 (lane bit 4): even rows keep outputs 0-1, odd rows 2-3
+            float ri[2], rq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                permlane16_swap(oi[i], oi[i + 2]);
+                permlane16_swap(oq[i], oq[i + 2]);
+                ri[i] = __fadd_rn(oi[i], oi[i + 2]);
+                rq[i] = __fadd_rn(oq[i], oq[i + 2]);
+            }
+            // ---- remaining column bits: butterflies (every lane of the group ends with the sum)
+            if constexpr (C::NCOL >= 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ri[i] = __fadd_rn(ri[i], __shfl_xor(ri[i], 8));
+                    rq[i] = __fadd_rn(rq[i], __shfl_xor(rq[i], 8));
+                }
+            }
+            if constexpr (C::NCOL >= 8) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ri[i] = __fadd_rn(ri[i], __shfl_xor(ri[i], 4));
+                    rq[i] = __fadd_rn(rq[i], __shfl_xor(rq[i], 4));
+                }
+            }
+            const long long m = mw + 2 * ((lane >> 4) & 1);
+            const bool writer = (C::NCOL < 4 || ((lane >> 3) & 1) == 0) && (C::NCOL < 8 || ((lane >> 2) & 1) == 0);
+            if (writer) {
+                float *dst = out + 2 * m;
+                if (m + 2 <= a.n_out) {
+                    __builtin_nontemporal_store((f32x4){ri[0], rq[0], ri[1], rq[1]}, reinterpret_cast<f32x4 *>(dst));
+                } else if (m < a.n_out) {
+                    dst[0] = ri[0];
+                    dst[1] = rq[0];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace sxfir

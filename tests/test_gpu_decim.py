@@ -172,3 +172,32 @@ def test_full_size_properties(oracle, taps):
     p_out = float(torch.mean(torch.view_as_real(y).double() ** 2).item()) * 2
     assert abs(p_out / (p_in * float((h.astype(np.float64) ** 2).sum())) - 1.0) < 5e-3
     assert abs(torch.mean(torch.view_as_real(y).double()).item()) < 1e-4
+
+
+@pytest.mark.parametrize("D,n_in", [(8, 8), (8, 4096), (8, 4096 + 8 * 37), (8, 1 << 19), (16, 1 << 18), (32, 32),
+                                    (32, 4096 * 3 + 32 * 5), (32, 1 << 20)])
+def test_multi_column_tiled_bit_exact(oracle, D, n_in):
+    """decim_multi_kernel: decimate-by-8/16/32 with 32 taps per phase (configs 3 and 5 shapes)."""
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    x = oracle.synth_iq(SEED, 11, 0, n_in)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
+    assert plan.contract == (2, 4)
+    plan.set_kernel(KERNEL_TILED)
+    y = _run(plan, x)
+    assert_bit_exact(y, oracle.decim_f32(h, D, x, 2, 4), "multi D=%d n_in=%d" % (D, n_in))
+    # streaming continuation through the fused history carry-over
+    x2 = oracle.synth_iq(SEED, 11, n_in, 4096 * D // 8)
+    y2 = _run(plan, x2)
+    both = oracle.decim_f32(h, D, np.concatenate([x, x2]), 2, 4)
+    assert_bit_exact(y2, both[len(y):], "multi D=%d continuation" % D)
+
+
+def test_multi_column_multichannel(oracle):
+    D, nchan, n = 8, 3, 40000
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    x = np.stack([oracle.synth_iq(SEED, 20 + c, 0, n) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D, nchan=nchan)
+    plan.set_kernel(KERNEL_TILED)
+    y = _run(plan, x)
+    for c in range(nchan):
+        assert_bit_exact(y[c], oracle.decim_f32(h, D, x[c], 2, 4), "multi channel %d" % c)

@@ -10,6 +10,7 @@ log2n = int(os.environ.get("KB_LOG2N", "28"))
 rounds = int(os.environ.get("KB_ROUNDS", "5"))
 iters = int(os.environ.get("KB_ITERS", "10"))
 nchan = int(os.environ.get("KB_NCHAN", "1"))
+D = int(os.environ.get("KB_D", "4"))
 configs = []
 for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
     f = spec.split(":")
@@ -19,8 +20,8 @@ for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
 n = (1 << log2n) // nchan
 x = torch.empty((nchan, n), dtype=torch.complex64, device="cuda")
 sxxcvr_amd.synth_fill(x, 0x51255, 0, 0)
-y = torch.empty((nchan, n // 4), dtype=torch.complex64, device="cuda")
-taps = sxxcvr_amd.design_lowpass(128, 4)
+y = torch.empty((nchan, n // D), dtype=torch.complex64, device="cuda")
+taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_TILE_VARIANT"] = v
@@ -29,14 +30,14 @@ for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_SCHED"] = str(sched)
     if occ: os.environ["SXFIR_OCC"] = str(occ)
     else: os.environ.pop("SXFIR_OCC", None)
-    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, 4, nchan=nchan))
+    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, D, nchan=nchan))
 ref = None
 res = {c: [] for c in configs}
 st = torch.cuda.current_stream().cuda_stream
 for r in range(rounds):
     for c, p in zip(configs, plans):
         p.reset()
-        ms = p.time_decimate_ptr(x.data_ptr(), n, n, y.data_ptr(), n // 4, iters, st)
+        ms = p.time_decimate_ptr(x.data_ptr(), n, n, y.data_ptr(), n // D, iters, st)
         res[c].append(ms)
         if r == 0:
             torch.cuda.synchronize()
@@ -45,6 +46,6 @@ for r in range(rounds):
             print("config", c, "checksum", "same" if chk == ref else "DIFFERENT")
 for c in configs:
     a = np.array(res[c])
-    gbs = 10.0 * (1 << log2n) / (a * 1e-3) / 1e9
+    gbs = (8.0 + 8.0 / D) * (1 << log2n) / (a * 1e-3) / 1e9
     print("%-12s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
         "%s:%d:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
