@@ -15,6 +15,7 @@
 
 #include "sxfir_decim_tile.hip.h"
 #include "sxfir_decim_multi.hip.h"
+#include "sxfir_interp_tile.hip.h"
 #include "sxfir_kernels.hip.h"
 
 namespace {
@@ -51,6 +52,7 @@ struct sxfir_plan {
     int jsplit, cw;        // numeric contract
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
+    bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
     int multi_waves;       // waves per workgroup of the multi kernel
     int occ_multi;         // resident workgroups per CU of the multi kernel
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
@@ -138,6 +140,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->taps_dev = nullptr;
     p->hist_dev = nullptr;
     p->hist_alt = nullptr;
+    p->itile_capable = false;
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
@@ -156,6 +159,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         p->hist_len = (jt + 1) & ~1;
         p->tile_capable = false;
         p->multi_capable = false;
+        p->itile_capable = (fmt == SXFIR_CF32 && ntaps == 32 * ratio &&
+                            (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32));
         p->jsplit = (jt % 2 == 0) ? 2 : 1;
         p->cw = 1;
     }
@@ -246,7 +251,7 @@ int sxfir_set_kernel(sxfir_plan *p, int kernel)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
     if (kernel < SXFIR_KERNEL_AUTO || kernel > SXFIR_KERNEL_GENERIC) return fail(SXFIR_EINVAL, "bad kernel id");
-    if (kernel == SXFIR_KERNEL_TILED && !p->tile_capable && !p->multi_capable)
+    if (kernel == SXFIR_KERNEL_TILED && !p->tile_capable && !p->multi_capable && !p->itile_capable)
         return fail(SXFIR_EUNSUPPORTED, "no tiled kernel for ntaps=%d ratio=%d fmt=%d mode=%d", p->ntaps,
                     p->ratio, p->fmt, p->mode);
     p->kernel = kernel;
@@ -470,6 +475,43 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     if (rc) return rc;
     if (n_in == 0) return SXFIR_OK;
     HIPCHECK(hipSetDevice(p->device));
+    const bool tiled = p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && ((uintptr_t)out_dev % 16 == 0) &&
+                       (p->nchan == 1 || out_stride % 2 == 0);
+    if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
+        return fail(SXFIR_EUNSUPPORTED, "tiled interpolator needs a 16-byte aligned output and even strides");
+    if (tiled) {
+        sxfir::InterpTileArgs t;
+        t.in = (const float *)in_dev;
+        t.hist = (const float *)p->hist_dev;
+        t.hist_out = (float *)p->hist_alt;
+        t.out = (float *)out_dev;
+        t.taps = p->taps_dev;
+        t.n_in = (long long)n_in;
+        t.in_stride = (long long)in_stride;
+        t.out_stride = (long long)out_stride;
+        t.hist_stride = p->hist_len;
+        const int qt = 4 * 4 * (32 / (p->ratio / 4));          // InterpTile<L>::TILE_IN
+        const long long n_tiles = ((long long)n_in + qt - 1) / qt;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        long long groups = ((long long)p->compute_units * 16 * p->oversub) / p->nchan;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        t.n_tiles = (int)n_tiles;
+        t.n_groups = (int)groups;
+        dim3 grid((unsigned)groups, (unsigned)p->nchan);
+        switch (p->ratio) {
+        case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, S(stream), t); break;
+        case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, S(stream), t); break;
+        case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, S(stream), t); break;
+        default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, S(stream), t); break;
+        }
+        HIPCHECK(hipGetLastError());
+        std::swap(p->hist_dev, p->hist_alt);
+        p->consumed += (long long)n_in;
+        p->produced += n_out;
+        if (n_out_p) *n_out_p = (size_t)n_out;
+        return SXFIR_OK;
+    }
     sxfir::GenericArgs a;
     a.in = in_dev;
     a.hist = p->hist_dev;

@@ -133,17 +133,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT>
 __device__ __forceinline__ void store_tile(const DecimTileCtx<NT> &c, int tile, const float (&oi)[4],
-                                           const float (&oq)[4])
+                                           const float (&oq)[4], f32x4 *xbuf)
 {
     using C = DecimTile4<NT>;
-    // 4 complex outputs (32 contiguous bytes) per lane
-    const long long m = (long long)tile * C::TILE_OUT + 8 * c.g + 4 * c.p;
-    float *dst = c.out + 2 * m;
-    if (m + 4 <= c.n_out) {
-        // written once, never re-read by this kernel: non-temporal (measured +2-3 % on the 4:1 stream)
-        __builtin_nontemporal_store((f32x4){oi[0], oq[0], oi[1], oq[1]}, reinterpret_cast<f32x4 *>(dst));
-        __builtin_nontemporal_store((f32x4){oi[2], oq[2], oi[3], oq[3]}, reinterpret_cast<f32x4 *>(dst + 4));
+    // A lane holds 4 consecutive outputs (32 bytes); stored directly that is two instructions that
+    // each write 16 of every 32 bytes.  Through LDS instead (the tile image is dead by now and this
+    // wave owns it): chunk 4g + 2p + {0,1} of the tile's 128 output chunks, read back linearly, so
+    // that each global store instruction writes 1 KiB of consecutive addresses (whole lines).
+    const long long m0 = (long long)tile * C::TILE_OUT;
+    if (m0 + C::TILE_OUT <= c.n_out) {
+        const int oc = 4 * c.g + 2 * c.p;
+        xbuf[oc] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
+        xbuf[oc + 1] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
+        f32x4 *dst = reinterpret_cast<f32x4 *>(c.out + 2 * m0);
+        const f32x4 v0 = xbuf[c.lane], v1 = xbuf[64 + c.lane];
+        __builtin_nontemporal_store(v0, dst + c.lane);
+        __builtin_nontemporal_store(v1, dst + 64 + c.lane);
     } else {
+        const long long m = m0 + 8 * c.g + 4 * c.p;
+        float *dst = c.out + 2 * m;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (m + i < c.n_out) { dst[2 * i] = oi[i]; dst[2 * i + 1] = oq[i]; }
@@ -155,7 +163,7 @@ __device__ __forceinline__ void store_tile(const DecimTileCtx<NT> &c, int tile, 
 // IEEE fused multiply-adds per instruction, so results are bit-identical.
 template <int NT>
 __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,
-                                                const float (&h)[NT / 2])
+                                                const float (&h)[NT / 2], f32x4 *xbuf)
 {
     using C = DecimTile4<NT>;
     f32x2 acc[C::R];
@@ -184,12 +192,12 @@ __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int t
         oi[i] = __fadd_rn(a0, a1);
         oq[i] = __fadd_rn(b0, b1);
     }
-    store_tile<NT>(c, tile, oi, oq);
+    store_tile<NT>(c, tile, oi, oq, xbuf);
 }
 
 template <int NT>
 __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,
-                                             const float (&h)[NT / 2])
+                                             const float (&h)[NT / 2], f32x4 *xbuf)
 {
     using C = DecimTile4<NT>;
     // window sample w (ascending) meets output i at local tap kl = 4*i + TPL - w;
@@ -230,7 +238,7 @@ __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile
         oq[i] = __fadd_rn(aq[i], aq[i + 4]);
     }
 
-    store_tile<NT>(c, tile, oi, oq);
+    store_tile<NT>(c, tile, oi, oq, xbuf);
 }
 
 // History carry-over fused into the launch (no second kernel): the wave that owns the last tile
@@ -312,9 +320,9 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
             SXFIR_WAIT_VMCNT(0);
             if constexpr (ABL == 3) {
-                compute_tile_pk<NT>(c, tile, win0, h);
+                compute_tile_pk<NT>(c, tile, win0, h, lds);
             } else if constexpr (ABL != 1) {
-                compute_tile<NT>(c, tile, win0, h);
+                compute_tile<NT>(c, tile, win0, h, lds);
             } else {
                 const f32x4 v0 = win0[0], v1 = win0[17];
                 const long long m = (long long)tile * C::TILE_OUT + 8 * c.g + 4 * c.p;
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             } else {
                 SXFIR_WAIT_VMCNT(0);
             }
-            compute_tile<NT>(c, tile, win0, h);
+            compute_tile<NT>(c, tile, win0, h, lds);
             if ((tile += tile_step) >= tile_end) break;
             // odd phase: compute from buffer 1, prefetch into buffer 0
             if (tile + tile_step < tile_end) {
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             } else {
                 SXFIR_WAIT_VMCNT(0);
             }
-            compute_tile<NT>(c, tile, win1, h);
+            compute_tile<NT>(c, tile, win1, h, lds + C::BUF_SLOTS);
             if ((tile += tile_step) >= tile_end) break;
         }
     }

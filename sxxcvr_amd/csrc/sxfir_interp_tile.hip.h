@@ -1,0 +1,178 @@
+// LDS-tiled polyphase FIR interpolator for gfx950: interpolate-by-L, L = 4*NPH
+// (4, 8, 16, 32), 32 taps per phase (NT = 32*L): the TX half of BASELINE
+// config 3 (256 taps, x8).  New code: in the reference the SX1255 interpolates
+// what snd_pcm_writei hands it (SoapySX.cpp:1093); here it is
+//     y[q*L + r] = sum_j h[j*L + r] * x[q - j].
+//
+// One wave = one workgroup; a tile is KT sub-tiles of QT = 128/NPH input samples
+// (512 outputs each), staged by one LDS-DMA round trip and computed one after
+// the other.  Lane = (p, c, g): tap-row half p (lane bit 5: j in
+// [16p, 16p+16)), phase group c (phases 4c..4c+3; lane bits below p), input
+// group g (4 consecutive inputs).  A lane holds its 64 taps in VGPRs and 32
+// accumulators (4 inputs x 4 phases x I/Q); its window is 10 ds_read_b128
+// (the tile is tiny: <= 1.3 KiB of LDS, staged by LDS-DMA) for 512 v_fmac.
+// The two row-half partials are exchanged with v_permlane32_swap and added
+// once: the low lane keeps inputs 0-1, the high lane inputs 2-3, so each lane
+// stores 2 x 4 consecutive outputs.
+//
+// Numeric contract: partial_p = fmaf chain from +0.0f over j
+// DESCENDING in [16p, 16p+16); y = partial_0 + partial_1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sxfir_decim_tile.hip.h"
+
+namespace sxfir {
+
+struct InterpTileArgs {
+    const float *in;        // channel 0, sample 0 of this call (8-byte aligned)
+    const float *hist;      // 32 samples preceding `in`
+    float *hist_out;
+    float *out;             // 16-byte aligned
+    const float *taps;
+    long long n_in;         // input samples per channel (outputs = n_in * L)
+    long long in_stride, out_stride, hist_stride;
+    int n_tiles, n_groups;
+};
+
+template <int L>
+struct InterpTile {
+    static constexpr int NT = 32 * L;
+    static constexpr int NPH = L / 4;                     // phase groups
+    static constexpr int GW = 32 / NPH;                   // input groups per wave
+    static constexpr int QT = 4 * GW;                     // input samples per sub-tile
+    static constexpr int KT = 4;                          // sub-tiles per staged tile
+    static constexpr int TILE_IN = KT * QT;
+    static constexpr int HIST = 32;
+    static constexpr int CHUNKS = (TILE_IN + 32) / 2;     // staged: samples [q0 - 32, q0 + TILE_IN)
+    static constexpr int NLOAD = (CHUNKS + 63) / 64;
+    static_assert(L % 4 == 0 && (NPH & (NPH - 1)) == 0 && NPH <= 8, "L must be 4, 8, 16 or 32");
+};
+
+template <int L>
+__global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
+{
+    using C = InterpTile<L>;
+    // input image, then a 512-output (4 KiB) transpose buffer with one pad chunk after every 16
+    __shared__ __attribute__((aligned(16))) f32x4 lds[C::NLOAD * 64 + 256 + 16];
+    f32x4 *obuf = lds + C::NLOAD * 64;
+
+    const int lane = threadIdx.x;
+    const int p = lane >> 5;
+    int c = 0;                                             // phase group: lane bits just below p
+    if (C::NPH >= 2) c |= (lane >> 4) & 1;
+    if (C::NPH >= 4) c |= ((lane >> 3) & 1) << 1;
+    if (C::NPH >= 8) c |= ((lane >> 2) & 1) << 2;
+    const int g = lane & (C::GW - 1);
+    const int ch = blockIdx.y;
+
+    const float *in = a.in + 2 * a.in_stride * ch;
+    const float *hist = a.hist + 2 * a.hist_stride * ch;
+    float *out = a.out + 2 * a.out_stride * ch;
+
+    // lane taps: h[4*jj + rr] = taps[(16p + jj)*L + 4c + rr]
+    float h[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) h[k] = a.taps[(16 * p + (k >> 2)) * L + 4 * c + (k & 3)];
+
+    // window: samples q0 + 4g - 16p - 16 + w, w = 0..19  ->  LDS sample index (+32) 4g - 16p + 16 + w
+    const f32x4 *win = lds + (2 * g - 8 * p + 8);
+
+    if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && lane < C::HIST) {
+        const long long s = a.n_in - C::HIST + lane;
+        const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
+                                : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
+        reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
+    }
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
+        const long long q0 = (long long)tile * C::TILE_IN;
+        const bool interior = (q0 >= 32) && (q0 + C::TILE_IN <= a.n_in);
+        // ---- stage samples [q0 - 32, q0 + TILE_IN) ----------------------------
+#pragma unroll
+        for (int i = 0; i < C::NLOAD; ++i) {
+            int cc = 64 * i + lane;
+            cc = cc < C::CHUNKS ? cc : C::CHUNKS - 1;
+            const long long s = q0 - 32 + 2 * cc;
+            if (interior) {
+                glds16(in + 2 * s, lds + 64 * i);
+            } else {
+                float2 v0, v1;
+                const long long last = a.n_in - 1;
+                if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
+                else v0 = reinterpret_cast<const float2 *>(hist)[s + C::HIST];
+                if (s + 1 >= 0) v1 = reinterpret_cast<const float2 *>(in)[s + 1 <= last ? s + 1 : last];
+                else v1 = reinterpret_cast<const float2 *>(hist)[s + 1 + C::HIST];
+                lds[64 * i + lane] = (f32x4){v0.x, v0.y, v1.x, v1.y};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll 1
+        for (int kt = 0; kt < C::KT; ++kt) {
+        const f32x4 *wk = win + kt * (C::QT / 2);
+        // ---- compute: window sample w meets input qi at row jj = qi + 16 - w ---
+        float ai[4][4], aq[4][4];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { ai[qi][rr] = 0.0f; aq[qi][rr] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const f32x4 v = wk[t];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int w = 2 * t + s;
+                const float xi = s ? v.z : v.x;
+                const float xq = s ? v.w : v.y;
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const int jj = qi + 16 - w;
+                    if (jj >= 0 && jj < 16) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            ai[qi][rr] = __builtin_fmaf(h[4 * jj + rr], xi, ai[qi][rr]);
+                            aq[qi][rr] = __builtin_fmaf(h[4 * jj + rr], xq, aq[qi][rr]);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- reduce over p: low half-wave keeps inputs 0-1, high half-wave inputs 2-3
+        float oi[2][4], oq[2][4];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                permlane32_swap(ai[qi][rr], ai[qi + 2][rr]);
+                permlane32_swap(aq[qi][rr], aq[qi + 2][rr]);
+                oi[qi][rr] = __fadd_rn(ai[qi][rr], ai[qi + 2][rr]);
+                oq[qi][rr] = __fadd_rn(aq[qi][rr], aq[qi + 2][rr]);
+            }
+
+        // ---- store.  A lane holds outputs (ql*L + 4c .. +3) of the sub-tile for ql = 4g + 2p + {0, 1}:
+        // 16-byte pieces scattered over the 4 KiB the wave produces.  They go through LDS so that
+        // every global store instruction writes 1 KiB of consecutive addresses (whole lines).
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int oc = ((4 * g + 2 * p + qi) * L + 4 * c) >> 1;          // chunk index inside the sub-tile
+            obuf[oc + (oc >> 4)] = (f32x4){oi[qi][0], oq[qi][0], oi[qi][1], oq[qi][1]};
+            obuf[oc + 1 + ((oc + 1) >> 4)] = (f32x4){oi[qi][2], oq[qi][2], oi[qi][3], oq[qi][3]};
+        }
+        const long long o0 = (q0 + kt * C::QT) * L;                          // first output of the sub-tile
+        const long long o_end = a.n_in * L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oc = 64 * k + lane;
+            const f32x4 v = obuf[oc + (oc >> 4)];
+            const long long o = o0 + 2 * oc;
+            if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
+        }
+        }   // kt
+    }
+}
+
+}  // namespace sxfir
