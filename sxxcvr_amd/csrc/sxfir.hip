@@ -16,6 +16,7 @@
 #include "sxfir_decim_tile.hip.h"
 #include "sxfir_decim_multi.hip.h"
 #include "sxfir_interp_tile.hip.h"
+#include "sxfir_decim_sgpr.hip.h"
 #include "sxfir_kernels.hip.h"
 
 namespace {
@@ -58,6 +59,7 @@ struct sxfir_plan {
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
     int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
     int oversub;           // waves launched = CUs * occupancy * oversub
+    int sgpr_r;            // experiment: SGPR-tap variant with R outputs per lane (0 = off)
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int compute_units;
@@ -173,6 +175,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->oversub = 16;
     p->ablate = 0;
     p->sched = 0;
+    p->sgpr_r = 0;
     // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
     // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
     p->multi_waves = ratio == 8 ? 1 : (ratio == 16 ? 2 : 4);
@@ -203,7 +206,16 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kdb, 64, 0) == hipSuccess && nb > 0) p->occ_db = nb;
         // experiment knobs (profiling only; defaults are what ships)
-        if (const char *v = getenv("SXFIR_TILE_VARIANT")) p->tile_dbuf = (strcmp(v, "sb") != 0);
+        if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
+            p->tile_dbuf = (strcmp(v, "db") == 0);
+            p->sgpr_r = strcmp(v, "sg") == 0 ? 8 : (strcmp(v, "sg4") == 0 ? 4 : 0);
+            if (p->sgpr_r && ntaps == 128) {
+                const void *k = p->sgpr_r == 8 ? (const void *)sxfir::decim4_sgpr_kernel<8>
+                                               : (const void *)sxfir::decim4_sgpr_kernel<4>;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0)
+                    p->occ_sb = nb;
+            }
+        }
         if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
         if (const char *v = getenv("SXFIR_SCHED")) p->sched = atoi(v);
         if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
@@ -372,7 +384,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.in_stride = (long long)in_stride;
         a.out_stride = (long long)out_stride;
         a.hist_stride = p->hist_len;
-        const int tile_out = 256;
+        const int tile_out = (p->sgpr_r && p->ntaps == 128) ? 64 * p->sgpr_r : 256;
         const long long n_tiles = (n_out + tile_out - 1) / tile_out;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
         // One resident generation of waves: every wave owns a contiguous run of tiles, so there is
@@ -385,7 +397,11 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_waves = (int)per_chan;
         a.sched = p->sched;
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
-        if (p->ntaps == 128 && p->ablate == 1) {
+        if (p->ntaps == 128 && p->sgpr_r == 8) {
+            hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<8>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->sgpr_r == 4) {
+            hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<4>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 1) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 1>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->ablate == 2) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 2>), grid, dim3(64), 0, st, a);
