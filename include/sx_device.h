@@ -25,7 +25,7 @@
  *   sx_device_get_info ............. getDriverKey, getHardwareKey, getHardwareInfo,
  *                                    getStreamFormats, getNativeStreamFormat
  *                                                               SX.cpp:1567-1616
- *   sx_device_set/get_frequency, _gain, _antenna .............. SX.cpp:1225-1466 (inert here)
+ *   sx_device_set/get_frequency, _gain, _antenna .............. SX.cpp:1225-1466 (register shadow)
  *   sx_device_write/read_setting ... writeSetting               SX.cpp:1472-1493
  *
  * Error model: where the C++ method throws (std::runtime_error in the
@@ -95,6 +95,13 @@ int sx_device_set_gain(sx_device *dev, int direction, size_t channel, double db)
 double sx_device_get_gain(sx_device *dev, int direction, size_t channel);
 int sx_device_set_antenna(sx_device *dev, int direction, size_t channel, const char *name);
 int sx_device_get_antenna(sx_device *dev, int direction, size_t channel, char *out, size_t cap);
+
+/* named gain elements ("LNA", "PGA", "DAC", "MIXER") and raw SX1255 register shadow, SX.cpp:1279-1368, :1501-1561 */
+int sx_device_set_gain_element(sx_device *dev, int direction, size_t channel, const char *name, double db);
+double sx_device_get_gain_element(sx_device *dev, int direction, size_t channel, const char *name);
+int sx_device_list(sx_device *dev, const char *what, int direction, char *out, size_t cap); /* "gains", "antennas" */
+int sx_device_write_registers(sx_device *dev, const char *name, unsigned addr, const unsigned *values, size_t n);
+int sx_device_read_registers(sx_device *dev, const char *name, unsigned addr, unsigned *values, size_t n);
 
 int sx_device_write_setting(sx_device *dev, const char *key, const char *value);
 int sx_device_read_setting(sx_device *dev, const char *key, char *out, size_t cap);

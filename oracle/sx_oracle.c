@@ -524,3 +524,49 @@ void sxo_tx_step(int64_t position, int64_t pcm_avail, int64_t pcm_delay, uint64_
     r->length = (int64_t)length;
     r->position = position;
 }
+
+/* ------------------------------------------------------------------------- */
+/* f-4: gain distribution and tuning word, SoapySX.cpp:50-63, :1236-1394.     */
+/* ------------------------------------------------------------------------- */
+static int range_quantize(double lo, double hi, double step, double value)
+{
+    double v = value < lo ? lo : value;
+    v = v > hi ? hi : v;
+    return (int)round((v - lo) / step);
+}
+
+static double range_value(double lo, double hi, double step, int q)
+{
+    double v = lo + step * (double)q;
+    v = v < lo ? lo : v;
+    return v > hi ? hi : v;
+}
+
+void sxo_gain_split(int direction, double value, double *coarse_db, double *fine_db)
+{
+    if (direction == 1) {
+        /* LNA: 3-bit field, not linear: q <= 6 -> field 6 - q/2, q == 7 -> 2, q == 8 -> 1 (:1320-1327);
+         * read back through map {0,8,7,6,4,2,0,0} (:1355) */
+        static const int map[8] = {0, 8, 7, 6, 4, 2, 0, 0};
+        const int q = range_quantize(0.0, 48.0, 6.0, value - 12.0);
+        const int field = q <= 6 ? 6 - q / 2 : (q == 7 ? 2 : 1);
+        const double lna = range_value(0.0, 48.0, 6.0, map[field]);
+        const int pq = range_quantize(0.0, 30.0, 2.0, value - lna) & 0xF;     /* 4-bit PGA field */
+        *coarse_db = lna;
+        *fine_db = range_value(0.0, 30.0, 2.0, pq);
+    } else {
+        const int q = range_quantize(0.0, 9.0, 3.0, value - 26.0) & 0x7;      /* 3-bit DAC field */
+        const double dac = range_value(0.0, 9.0, 3.0, q);
+        const int mq = range_quantize(0.0, 30.0, 2.0, value - dac) & 0xF;     /* 4-bit MIXER field */
+        *coarse_db = dac;
+        *fine_db = range_value(0.0, 30.0, 2.0, mq);
+    }
+}
+
+double sxo_quantize_frequency(double master_clock, double frequency, unsigned *word)
+{
+    const double step = master_clock * (1.0 / 1048576.0);
+    const unsigned w = (unsigned)range_quantize(0.0, step * 16777215.0, step, frequency);
+    if (word) *word = w;
+    return step * (double)w;
+}

@@ -100,6 +100,14 @@ void sxo_tx_step(int64_t position, int64_t pcm_avail, int64_t pcm_delay, uint64_
                  size_t num_elems, int flags, long long time_ns, long timeout_us,
                  double rate, sxo_stream_result *r);
 
+/* ---- f-4: overall gain -> element gains (SoapySX.cpp:1291-1394) ----
+ * direction: 1 = RX (coarse "LNA" 0..48 step 6, fine "PGA" 0..30 step 2, PGA target 12 dB),
+ *            0 = TX (coarse "DAC" 0..9 step 3, fine "MIXER" 0..30 step 2, MIXER target 26 dB).
+ * Returns the element gains the reference ends up with, incl. the non-linear LNA field. */
+void sxo_gain_split(int direction, double value, double *coarse_db, double *fine_db);
+/* frequency -> 24-bit tuning word -> frequency (SoapySX.cpp:1236-1272) */
+double sxo_quantize_frequency(double master_clock, double frequency, unsigned *word);
+
 /* ---- CPU baseline helper: multi-threaded oracle B (OpenMP over output blocks) ---- */
 int sxo_decim_f32_mt(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                      size_t n_x, int64_t m0, size_t n_out, float *y, int threads);

@@ -11,9 +11,11 @@
 //   getHardwareTime / hasHardwareTime .......................... :1107-1139, :1618-1623
 //   sample-rate table and validation ........................... :180-208, :1145-1219
 //   formats / channels / keys / registration ................... :1567-1656
+//   frequency / gain / antenna / raw register API .............. :1225-1561
+//       kept as a register SHADOW: the same bit fields of the same SX1255
+//       registers are updated and read back, nothing is sent over SPI
 // Not carried over (no counterpart without the Raspberry Pi HAT): SPI, GPIO,
-// SX1255 register programming, clock detection, HAT EEPROM.  Frequency, gain
-// and antenna are inert cached values so that probing tools keep working.
+// chip reset, clock detection, HAT EEPROM.
 //
 // New device arguments (the reference ignores its device args, :711):
 //   gpu=<n>            HIP device (default 0)
@@ -52,6 +54,26 @@ struct sampleRateDiv {
 const sampleRateDiv sample_rates[] = {{1536}, {768}, {512}, {256}, {128}, {64}};
 const size_t N_SAMPLE_RATES = sizeof(sample_rates) / sizeof(sample_rates[0]);
 
+// SX1255 register shadow: 0x00-0x13 start from the values the reference writes at start-up
+// (datasheet defaults, 433.92 MHz, narrow RX filters, I2S dividers; SoapySX.cpp:145-176).
+const unsigned MAX_REGS = 0x80;
+const uint8_t init_registers[0x14] = {
+    0x01, 0xD8, 0xF5, 0xC3, 0xD8, 0xF5, 0xC3, 0x11, 0x2E, 0x24,
+    0x30, 0x02, 0x3F, 0x3B, 0x06, 0x00, 0x02, 0x00, 0x22, 0x2C,
+};
+
+// Clamp to the range, offset to its minimum, scale by its step, round (SoapySX.cpp:50-63).
+int32_t scale_from_range(SoapySDR::Range range, double value)
+{
+    return (int)std::round((std::min(std::max(value, range.minimum()), range.maximum()) - range.minimum()) /
+                           range.step());
+}
+
+double scale_to_range(SoapySDR::Range range, int32_t value)
+{
+    return std::min(std::max(range.minimum() + range.step() * (double)value, range.minimum()), range.maximum());
+}
+
 int pcm_error_to_soapy_rx(int err) { return err == -EPIPE ? SOAPY_SDR_OVERFLOW : SOAPY_SDR_STREAM_ERROR; }
 int pcm_error_to_soapy_tx(int err) { return err == -EPIPE ? SOAPY_SDR_UNDERFLOW : SOAPY_SDR_STREAM_ERROR; }
 
@@ -82,10 +104,30 @@ private:
     std::unique_ptr<sx::TxChain> tx_chain;
     int64_t tx_ptt_samples;     // written samples at or above the TX threshold (PTT bit of :132-133)
 
-    // inert front-end state
-    double frequency[2];
-    double gain[2];
-    std::string antenna[2];
+    // Values of the SX1255 registers as the reference would have written them (SoapySX.cpp:546-550);
+    // there is no chip behind them here.
+    uint8_t regs[MAX_REGS];
+
+    void set_register_bits(size_t address, unsigned lowestbit, unsigned nbits, unsigned value)
+    {
+        if (address >= MAX_REGS) throw std::runtime_error("Invalid register address");
+        const unsigned mask = ((1u << nbits) - 1) << lowestbit;
+        regs[address] = (uint8_t)((regs[address] & (~mask)) | ((value << lowestbit) & mask));
+    }
+
+    unsigned get_cached_register_bits(size_t address, unsigned lowestbit, unsigned nbits) const
+    {
+        if (address >= MAX_REGS) throw std::runtime_error("Invalid register address");
+        const unsigned mask = ((1u << nbits) - 1) << lowestbit;
+        return (regs[address] & mask) >> lowestbit;
+    }
+
+    // bounds rule of write_registers_to_chip (SoapySX.cpp:596-597); the SPI burst itself is gone
+    void check_register_range(size_t firstreg, size_t nregs) const
+    {
+        if ((firstreg >= MAX_REGS) || (nregs > MAX_REGS) || (firstreg > MAX_REGS - nregs))
+            throw std::runtime_error("Invalid register address");
+    }
 
     int64_t timestamp_to_samples(long long timestamp) const { return SoapySDR::timeNsToTicks(timestamp, sampleRate); }
     long long samples_to_timestamp(int64_t samples) const { return SoapySDR::ticksToTimeNs(samples, sampleRate); }
@@ -122,10 +164,11 @@ public:
         int ndev = 0;
         if (sxfir_device_count(&ndev) != SXFIR_OK || ndev < 1)
             throw std::runtime_error(std::string("No MI355X visible: ") + sxfir_last_error());
-        frequency[0] = frequency[1] = 433.92e6;     // :663-664
-        gain[0] = gain[1] = 0.0;
-        antenna[SOAPY_SDR_RX] = "RX";
-        antenna[SOAPY_SDR_TX] = "TX";
+        for (unsigned i = 0; i < MAX_REGS; ++i) regs[i] = 0;
+        for (unsigned i = 0; i < sizeof(init_registers); ++i) regs[i] = init_registers[i];   // init_chip, :620-627
+        set_register_bits(0, 1, 3, 0b111);
+        setFrequency(SOAPY_SDR_RX, 0, 433.92e6, {});   // :663-664
+        setFrequency(SOAPY_SDR_TX, 0, 433.92e6, {});
         rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, 0));
         tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536));
     }
@@ -441,54 +484,178 @@ public:
     }
 
     /*******************************************************************
-     * Inert RF front-end state (no SX1255 behind this build)
+     * RF front-end control surface on the register shadow (SoapySX.cpp:1225-1561)
      ******************************************************************/
 
-    void setFrequency(const int direction, const size_t channel, const double f, const SoapySDR::Kwargs &)
+    void setFrequency(const int direction, const size_t channel, const double frequency, const SoapySDR::Kwargs &args)
     {
-        (void)channel;
+        (void)channel; (void)args;
         std::scoped_lock lock(reg_mutex);
-        // tuning step masterClock / 2^20, :1236-1239
-        const double step = masterClock / 1048576.0;
-        frequency[direction == SOAPY_SDR_RX ? 1 : 0] = round(f / step) * step;
+        // 24-bit tuning word in steps of masterClock / 2^20
+        const double step = masterClock * (1.0 / (double)(1L << 20));
+        const uint32_t quantized =
+            (uint32_t)scale_from_range(SoapySDR::Range(0, step * (double)((1L << 24) - 1), step), frequency);
+        const size_t base = direction == SOAPY_SDR_RX ? 0x01 : 0x04;
+        set_register_bits(base, 0, 8, quantized >> 16);
+        set_register_bits(base + 1, 0, 8, (quantized >> 8) & 0xFF);
+        set_register_bits(base + 2, 0, 8, quantized & 0xFF);
     }
+
     double getFrequency(const int direction, const size_t channel) const
     {
         (void)channel;
         std::scoped_lock lock(reg_mutex);
-        return frequency[direction == SOAPY_SDR_RX ? 1 : 0];
+        const double step = masterClock * (1.0 / (double)(1L << 20));
+        const size_t base = direction == SOAPY_SDR_RX ? 0x01 : 0x04;
+        return step * ((((uint32_t)regs[base]) << 16) | (((uint32_t)regs[base + 1]) << 8) | ((uint32_t)regs[base + 2]));
     }
+
+    std::vector<std::string> listGains(const int direction, const size_t channel) const
+    {
+        (void)channel;
+        if (direction == SOAPY_SDR_RX) return {"LNA", "PGA"};
+        return {"DAC", "MIXER"};
+    }
+
+    SoapySDR::Range getGainRange(const int direction, const size_t channel, const std::string &name) const
+    {
+        (void)channel;
+        if (direction == SOAPY_SDR_RX) {
+            if (name == "LNA") return {0.0, 48.0, 6.0};
+            if (name == "PGA") return {0.0, 30.0, 2.0};
+        } else {
+            if (name == "DAC") return {0.0, 9.0, 3.0};
+            if (name == "MIXER") return {0.0, 30.0, 2.0};
+        }
+        return {0, 0, 0};
+    }
+
+    void setGain(const int direction, const size_t channel, const std::string &name, const double value)
+    {
+        std::scoped_lock lock(reg_mutex);
+        const int32_t quantized = scale_from_range(getGainRange(direction, channel, name), value);
+        if (direction == SOAPY_SDR_RX) {
+            if (name == "LNA") {
+                // the LNA field is not linear in dB (:1320-1327)
+                if (quantized <= 6) set_register_bits(0x0C, 5, 3, 6 - quantized / 2);
+                else if (quantized == 7) set_register_bits(0x0C, 5, 3, 2);
+                else set_register_bits(0x0C, 5, 3, 1);
+            } else if (name == "PGA") {
+                set_register_bits(0x0C, 1, 4, quantized);
+            }
+        } else {
+            if (name == "DAC") set_register_bits(0x08, 4, 3, quantized);
+            else if (name == "MIXER") set_register_bits(0x08, 0, 4, quantized);
+        }
+    }
+
+    double getGain(const int direction, const size_t channel, const std::string &name) const
+    {
+        std::scoped_lock lock(reg_mutex);
+        int32_t quantized = 0;
+        if (direction == SOAPY_SDR_RX) {
+            if (name == "LNA") {
+                const int32_t map[8] = {0, 8, 7, 6, 4, 2, 0, 0};
+                quantized = map[get_cached_register_bits(0x0C, 5, 3)];
+            } else if (name == "PGA") {
+                quantized = get_cached_register_bits(0x0C, 1, 4);
+            }
+        } else {
+            if (name == "DAC") quantized = get_cached_register_bits(0x08, 4, 3);
+            else if (name == "MIXER") quantized = get_cached_register_bits(0x08, 0, 4);
+        }
+        return scale_to_range(getGainRange(direction, channel, name), quantized);
+    }
+
+    // Overall gain: coarse element first, the finer one takes the rest (:1370-1394).
     void setGain(const int direction, const size_t channel, const double value)
     {
-        (void)channel;
         std::scoped_lock lock(reg_mutex);
-        gain[direction == SOAPY_SDR_RX ? 1 : 0] = value;
+        if (direction == SOAPY_SDR_RX) {
+            const double pga_gain_target = 12.0;
+            setGain(direction, channel, "LNA", value - pga_gain_target);
+            const double lna_gain = getGain(direction, channel, "LNA");
+            setGain(direction, channel, "PGA", value - lna_gain);
+        } else {
+            const double mixer_gain_target = 26.0;
+            setGain(direction, channel, "DAC", value - mixer_gain_target);
+            const double dac_gain = getGain(direction, channel, "DAC");
+            setGain(direction, channel, "MIXER", value - dac_gain);
+        }
     }
+
+    // SoapySDR's default overall getGain: the sum of the elements
     double getGain(const int direction, const size_t channel) const
     {
-        (void)channel;
-        std::scoped_lock lock(reg_mutex);
-        return gain[direction == SOAPY_SDR_RX ? 1 : 0];
+        double total = 0.0;
+        for (const auto &name : listGains(direction, channel)) total += getGain(direction, channel, name);
+        return total;
     }
+
     std::vector<std::string> listAntennas(const int direction, const size_t channel) const
     {
         (void)channel;
-        if (direction == SOAPY_SDR_RX) return {"RX", "LB", "DLB"};
+        if (direction == SOAPY_SDR_RX) return {"RX", "LB"};
         return {"TX", "NONE"};
     }
+
     void setAntenna(const int direction, const size_t channel, const std::string &name)
     {
         (void)channel;
-        const auto names = listAntennas(direction, 0);
-        if (std::find(names.begin(), names.end(), name) == names.end()) throw std::runtime_error("Unknown antenna");
         std::scoped_lock lock(reg_mutex);
-        antenna[direction == SOAPY_SDR_RX ? SOAPY_SDR_RX : SOAPY_SDR_TX] = name;
+        if (direction == SOAPY_SDR_RX) {
+            if (name == "RX") set_register_bits(0x10, 2, 2, 0);
+            else if (name == "LB") set_register_bits(0x10, 2, 2, 1);
+            else if (name == "DLB") set_register_bits(0x10, 2, 2, 3);
+        } else {
+            if (name == "TX") set_register_bits(0x00, 3, 1, 1);
+            else if (name == "NONE") set_register_bits(0x00, 3, 1, 0);
+        }
     }
+
     std::string getAntenna(const int direction, const size_t channel) const
     {
         (void)channel;
         std::scoped_lock lock(reg_mutex);
-        return antenna[direction == SOAPY_SDR_RX ? SOAPY_SDR_RX : SOAPY_SDR_TX];
+        if (direction == SOAPY_SDR_RX) {
+            const unsigned lb = get_cached_register_bits(0x10, 2, 2);
+            if (lb & 2) return "DLB";
+            if (lb & 1) return "LB";
+            return "RX";
+        }
+        return get_cached_register_bits(0x00, 3, 1) ? "TX" : "NONE";
+    }
+
+    // Raw register access: reads come from the shadow (on the HAT they come from the chip);
+    // 0x11 reports both PLLs locked, which is what the start-up code polls for (:635-636).
+    std::vector<unsigned> readRegisters(const std::string &name, const unsigned addr, const size_t length) const
+    {
+        (void)name;
+        std::scoped_lock lock(reg_mutex);
+        std::vector<unsigned> result(length, 0);
+        for (size_t i = 0; i < length; i++) {
+            const size_t r = (addr + i) & (MAX_REGS - 1);   // the SPI address counter is 7 bits wide
+            result[i] = r == 0x11 ? 3u : regs[r];
+        }
+        return result;
+    }
+
+    unsigned readRegister(const std::string &name, const unsigned addr) const { return readRegisters(name, addr, 1).at(0); }
+
+    void writeRegisters(const std::string &name, const unsigned addr, const std::vector<unsigned> &value)
+    {
+        (void)name;
+        std::scoped_lock lock(reg_mutex);
+        for (size_t i = 0; i < value.size(); i++) set_register_bits(addr + i, 0, 8, value[i]);
+        check_register_range(addr, value.size());
+    }
+
+    void writeRegister(const std::string &name, const unsigned addr, const unsigned value)
+    {
+        (void)name;
+        std::scoped_lock lock(reg_mutex);
+        set_register_bits(addr, 0, 8, value);
+        check_register_range(addr, 1);
     }
 
     /*******************************************************************

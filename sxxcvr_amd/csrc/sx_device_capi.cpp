@@ -230,6 +230,54 @@ int sx_device_get_antenna(sx_device *dev, int direction, size_t channel, char *o
     SX_TRY(SX_DEVICE_EXCEPTION, { return copy_out(D(dev)->getAntenna(direction, channel), out, cap); })
 }
 
+int sx_device_set_gain_element(sx_device *dev, int direction, size_t channel, const char *name, double db)
+{
+    SX_TRY(SX_DEVICE_EXCEPTION, {
+        D(dev)->setGain(direction, channel, std::string(name ? name : ""), db);
+        return 0;
+    })
+}
+
+double sx_device_get_gain_element(sx_device *dev, int direction, size_t channel, const char *name)
+{
+    SX_TRY(-1.0, { return D(dev)->getGain(direction, channel, std::string(name ? name : "")); })
+}
+
+int sx_device_list(sx_device *dev, const char *what, int direction, char *out, size_t cap)
+{
+    SX_TRY(SX_DEVICE_EXCEPTION, {
+        const std::string w(what ? what : "");
+        std::vector<std::string> items;
+        if (w == "gains") items = D(dev)->listGains(direction, 0);
+        else if (w == "antennas") items = D(dev)->listAntennas(direction, 0);
+        else {
+            g_error = "unknown list";
+            return SX_DEVICE_EXCEPTION;
+        }
+        std::string s;
+        for (const auto &i : items) s += (s.empty() ? "" : ",") + i;
+        copy_out(s, out, cap);
+        return (int)items.size();
+    })
+}
+
+int sx_device_write_registers(sx_device *dev, const char *name, unsigned addr, const unsigned *values, size_t n)
+{
+    SX_TRY(SX_DEVICE_EXCEPTION, {
+        D(dev)->writeRegisters(name ? name : "", addr, std::vector<unsigned>(values, values + n));
+        return 0;
+    })
+}
+
+int sx_device_read_registers(sx_device *dev, const char *name, unsigned addr, unsigned *values, size_t n)
+{
+    SX_TRY(SX_DEVICE_EXCEPTION, {
+        const auto r = D(dev)->readRegisters(name ? name : "", addr, n);
+        for (size_t i = 0; i < n && i < r.size(); ++i) values[i] = r[i];
+        return (int)r.size();
+    })
+}
+
 int sx_device_write_setting(sx_device *dev, const char *key, const char *value)
 {
     SX_TRY(SX_DEVICE_EXCEPTION, {

@@ -66,6 +66,11 @@ def _load():
         "sx_device_get_gain": (dbl, [vp, ci, sz]),
         "sx_device_set_antenna": (ci, [vp, ci, sz, cs]),
         "sx_device_get_antenna": (ci, [vp, ci, sz, cs, sz]),
+        "sx_device_set_gain_element": (ci, [vp, ci, sz, cs, dbl]),
+        "sx_device_get_gain_element": (dbl, [vp, ci, sz, cs]),
+        "sx_device_list": (ci, [vp, cs, ci, cs, sz]),
+        "sx_device_write_registers": (ci, [vp, cs, C.c_uint, P(C.c_uint), sz]),
+        "sx_device_read_registers": (ci, [vp, cs, C.c_uint, P(C.c_uint), sz]),
         "sx_device_write_setting": (ci, [vp, cs, cs]),
         "sx_device_read_setting": (ci, [vp, cs, cs, sz]),
         "sx_device_tx_capture": (ci, [vp, ll, sz, vp]),
@@ -207,11 +212,39 @@ class Device:
     def getFrequency(self, direction, channel):
         return self._lib.sx_device_get_frequency(self._dev, direction, channel)
 
-    def setGain(self, direction, channel, value):
-        self._chk(self._lib.sx_device_set_gain(self._dev, direction, channel, float(value)))
+    def setGain(self, direction, channel, *args):
+        """setGain(dir, ch, value) or setGain(dir, ch, name, value), as in SoapySDR."""
+        if len(args) == 1:
+            self._chk(self._lib.sx_device_set_gain(self._dev, direction, channel, float(args[0])))
+        else:
+            self._chk(self._lib.sx_device_set_gain_element(self._dev, direction, channel, args[0].encode(),
+                                                           float(args[1])))
 
-    def getGain(self, direction, channel):
-        return self._lib.sx_device_get_gain(self._dev, direction, channel)
+    def getGain(self, direction, channel, name=None):
+        if name is None:
+            return self._lib.sx_device_get_gain(self._dev, direction, channel)
+        return self._lib.sx_device_get_gain_element(self._dev, direction, channel, name.encode())
+
+    def listGains(self, direction, channel):
+        return self._str(self._lib.sx_device_list, b"gains", direction).split(",")
+
+    def listAntennas(self, direction, channel):
+        return self._str(self._lib.sx_device_list, b"antennas", direction).split(",")
+
+    def readRegisters(self, name, addr, length):
+        arr = (C.c_uint * length)()
+        self._chk(self._lib.sx_device_read_registers(self._dev, name.encode(), addr, arr, length))
+        return list(arr)
+
+    def readRegister(self, name, addr):
+        return self.readRegisters(name, addr, 1)[0]
+
+    def writeRegisters(self, name, addr, values):
+        arr = (C.c_uint * len(values))(*values)
+        self._chk(self._lib.sx_device_write_registers(self._dev, name.encode(), addr, arr, len(values)))
+
+    def writeRegister(self, name, addr, value):
+        self.writeRegisters(name, addr, [value])
 
     def setAntenna(self, direction, channel, name):
         self._chk(self._lib.sx_device_set_antenna(self._dev, direction, channel, name.encode()))

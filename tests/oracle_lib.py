@@ -67,6 +67,9 @@ def _load(name):
     lib.sxo_max_threads.restype = C.c_int
     lib.sxo_f32_to_f16.argtypes = [vp, vp, sz]
     lib.sxo_f16_to_f32.argtypes = [vp, vp, sz]
+    lib.sxo_gain_split.argtypes = [C.c_int, dbl, C.POINTER(dbl), C.POINTER(dbl)]
+    lib.sxo_quantize_frequency.restype = dbl
+    lib.sxo_quantize_frequency.argtypes = [dbl, dbl, C.POINTER(C.c_uint)]
     lib.sxo_rx_step.argtypes = [i64, i64, u64, u64, sz, C.c_long, dbl, C.POINTER(StreamResult)]
     lib.sxo_tx_step.argtypes = [i64, i64, i64, u64, sz, C.c_int, ll, C.c_long, dbl, C.POINTER(StreamResult)]
     return lib
@@ -161,6 +164,17 @@ class Oracle:
         out = np.empty(a.shape, dtype=np.float32)
         self.lib.sxo_f16_to_f32(_fp(a), _fp(out), a.size)
         return out
+
+    # -- control surface ----------------------------------------------------
+    def gain_split(self, direction, value):
+        a, b = C.c_double(), C.c_double()
+        self.lib.sxo_gain_split(direction, float(value), C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def quantize_frequency(self, master_clock, frequency):
+        w = C.c_uint()
+        f = self.lib.sxo_quantize_frequency(float(master_clock), float(frequency), C.byref(w))
+        return f, w.value
 
     # -- stream rules -------------------------------------------------------
     def rx_step(self, position, avail, period, buffer, num_elems, timeout_us, rate):

@@ -332,3 +332,45 @@ def test_wall_clock_mode():
     t1 = dev.getHardwareTime()
     time.sleep(0.05)
     assert dev.getHardwareTime() - t1 >= 40_000_000
+
+
+def test_control_surface_register_shadow(oracle):
+    """SoapySX/test/test.py and test_gains.py as assertions: tuning word, gain split, antennas,
+    raw register access on the SX1255 register shadow (SoapySX.cpp:1225-1561)."""
+    dev = make()
+    RX, TX = SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_TX
+    # start-up state: init_registers + RX/TX enabled, both synthesizers at 433.92 MHz
+    regs = dev.readRegisters("", 0, 0x14)
+    assert regs[0] == 0x0F and regs[7] == 0x11 and regs[0x11] == 3 and regs[0x12:0x14] == [0x22, 0x2C]
+    f0, w0 = oracle.quantize_frequency(38.4e6, 433.92e6)
+    assert dev.getFrequency(RX, 0) == f0 == dev.getFrequency(TX, 0)
+    assert (regs[1] << 16 | regs[2] << 8 | regs[3]) == w0
+    for f in (432.55e6, 434.55e6, 0.0, 1e9):
+        dev.setFrequency(RX, 0, f)
+        assert dev.getFrequency(RX, 0) == oracle.quantize_frequency(38.4e6, f)[0]
+    assert dev.getFrequency(TX, 0) == f0                                   # TX word untouched
+    # gain sweep of test_gains.py
+    assert dev.listGains(RX, 0) == ["LNA", "PGA"] and dev.listGains(TX, 0) == ["DAC", "MIXER"]
+    for g in range(-10, 90):
+        dev.setGain(RX, 0, float(g))
+        lna, pga = oracle.gain_split(1, g)
+        assert (dev.getGain(RX, 0, "LNA"), dev.getGain(RX, 0, "PGA")) == (lna, pga), g
+        assert dev.getGain(RX, 0) == lna + pga
+    for g in range(-10, 50):
+        dev.setGain(TX, 0, float(g))
+        assert (dev.getGain(TX, 0, "DAC"), dev.getGain(TX, 0, "MIXER")) == oracle.gain_split(0, g), g
+    dev.setGain(RX, 0, "PGA", 7.0)
+    assert dev.getGain(RX, 0, "PGA") == 8.0                                # round(3.5) = 4 steps of 2 dB
+    # antennas
+    assert dev.listAntennas(RX, 0) == ["RX", "LB"] and dev.listAntennas(TX, 0) == ["TX", "NONE"]
+    assert dev.getAntenna(RX, 0) == "RX" and dev.getAntenna(TX, 0) == "TX"
+    dev.setAntenna(RX, 0, "LB")
+    dev.setAntenna(TX, 0, "NONE")
+    assert dev.getAntenna(RX, 0) == "LB" and dev.getAntenna(TX, 0) == "NONE"
+    assert dev.readRegister("", 0x10) & 0x0C == 0x04 and dev.readRegister("", 0x00) & 0x08 == 0
+    # raw registers: test.py writes one register, then expects an exception for 3 registers at 0x7E
+    dev.writeRegister("", 0x0D, 0x2B)
+    assert dev.readRegister("", 0x0D) == 0x2B
+    with pytest.raises(RuntimeError, match="Invalid register address"):
+        dev.writeRegisters("", 0x7E, [1, 2, 3])
+    dev.writeSetting("PA", "AUTO")

@@ -1,0 +1,27 @@
+"""Through-the-Device throughput (readStream / writeStream incl. PCIe and launch overheads); API-parity
+figure for DESIGN.md, never the bench value."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import sxxcvr_amd.soapy as SoapySDR
+for blk in (256, 4096, 65536, 1 << 20):
+    dev = SoapySDR.Device({"driver": "sx", "clock": "virtual"})
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 600000.0)
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CF32", [0], {"period": str(min(blk, 65536))})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(min(blk, 65536))})
+    dev.activateStream(rx); dev.activateStream(tx)
+    buf = np.zeros(blk, dtype=np.complex64)
+    n = max(4, min(2000, (1 << 24) // blk))
+    dev.readStream(rx, [buf], blk)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = dev.readStream(rx, [buf], blk)
+        assert r.ret == blk
+    dt_rx = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = dev.writeStream(tx, [buf], blk)
+        assert r.ret == blk, r
+    dt_tx = (time.perf_counter() - t0) / n
+    print("block %8d: readStream %.1f us/call = %.2f MS/s out (%.2f MS/s wideband in) | writeStream %.1f us/call = %.2f MS/s" % (
+        blk, dt_rx * 1e6, blk / dt_rx / 1e6, 4 * blk / dt_rx / 1e6, dt_tx * 1e6, blk / dt_tx / 1e6))
