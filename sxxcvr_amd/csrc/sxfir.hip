@@ -147,7 +147,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
         p->tile_capable = (fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64));
-        p->multi_capable = (fmt == SXFIR_CF32 && ntaps == 32 * ratio && (ratio == 8 || ratio == 16 || ratio == 32));
+        // multi-column kernel: 32 taps per phase; CF32 at ratio 8/16/32, CF16 at ratio 4/8/16/32
+        p->multi_capable = (ntaps == 32 * ratio) &&
+                           ((fmt == SXFIR_CF32 && (ratio == 8 || ratio == 16 || ratio == 32)) ||
+                            (fmt == SXFIR_CF16 && (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32)));
         const int jt = (ntaps + ratio - 1) / ratio;
         if (ntaps % ratio == 0 && ratio % 4 == 0 && jt % 2 == 0) {
             p->jsplit = 2;
@@ -178,7 +181,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->sgpr_r = 0;
     // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
     // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
-    p->multi_waves = ratio == 8 ? 1 : (ratio == 16 ? 2 : 4);
+    p->multi_waves = ratio <= 8 ? 1 : (ratio == 16 ? 2 : 4);
     p->occ_multi = 2;
     if (p->multi_capable) {
         if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
@@ -186,12 +189,17 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const int W = p->multi_waves;
         int nb = 0;
         const void *k = nullptr;
-        switch (ratio * 100 + W) {
-        case 801: k = (const void *)sxfir::decim_multi_kernel<8, 1>; break;
-        case 804: k = (const void *)sxfir::decim_multi_kernel<8, 4>; break;
-        case 1602: k = (const void *)sxfir::decim_multi_kernel<16, 2>; break;
-        case 3204: k = (const void *)sxfir::decim_multi_kernel<32, 4>; break;
-        case 3208: k = (const void *)sxfir::decim_multi_kernel<32, 8>; break;
+        switch ((fmt == SXFIR_CF16 ? 10000 : 0) + ratio * 100 + W) {
+        case 801: k = (const void *)sxfir::decim_multi_kernel<8, 1, false>; break;
+        case 804: k = (const void *)sxfir::decim_multi_kernel<8, 4, false>; break;
+        case 1602: k = (const void *)sxfir::decim_multi_kernel<16, 2, false>; break;
+        case 3204: k = (const void *)sxfir::decim_multi_kernel<32, 4, false>; break;
+        case 3208: k = (const void *)sxfir::decim_multi_kernel<32, 8, false>; break;
+        case 10401: k = (const void *)sxfir::decim_multi_kernel<4, 1, true>; break;
+        case 10801: k = (const void *)sxfir::decim_multi_kernel<8, 1, true>; break;
+        case 11602: k = (const void *)sxfir::decim_multi_kernel<16, 2, true>; break;
+        case 13204: k = (const void *)sxfir::decim_multi_kernel<32, 4, true>; break;
+        case 13208: k = (const void *)sxfir::decim_multi_kernel<32, 8, true>; break;
         }
         if (k && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0)
             p->occ_multi = nb;
@@ -327,14 +335,14 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                  ((uintptr_t)in_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) &&
                  (p->nchan == 1 || (in_stride % 2 == 0 && out_stride % 2 == 0));
     const bool multi = p->multi_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
-                       ((uintptr_t)in_dev % 8 == 0) && ((uintptr_t)out_dev % 16 == 0) &&
-                       (p->nchan == 1 || out_stride % 2 == 0);
+                       ((uintptr_t)out_dev % 16 == 0) &&
+                       (p->nchan == 1 || out_stride % (p->fmt == SXFIR_CF16 ? 4 : 2) == 0);
     if (multi) {
         sxfir::DecimMultiArgs a;
-        a.in = (const float *)in_dev;
-        a.hist = (const float *)p->hist_dev;
-        a.hist_out = (float *)p->hist_alt;
-        a.out = (float *)out_dev;
+        a.in = in_dev;
+        a.hist = p->hist_dev;
+        a.hist_out = p->hist_alt;
+        a.out = out_dev;
         a.taps = p->taps_dev;
         a.n_in = (long long)n_in;
         a.n_out = n_out;
@@ -351,15 +359,20 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
-#define SXFIR_LAUNCH_MULTI(DD, WW) \
-        hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW>), grid, dim3(64 * WW), 0, st, a)
-        const int key = p->ratio * 100 + W;
+#define SXFIR_LAUNCH_MULTI(DD, WW, HH) \
+        hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH>), grid, dim3(64 * WW), 0, st, a)
+        const int key = (p->fmt == SXFIR_CF16 ? 10000 : 0) + p->ratio * 100 + W;
         switch (key) {
-        case 801: SXFIR_LAUNCH_MULTI(8, 1); break;
-        case 804: SXFIR_LAUNCH_MULTI(8, 4); break;
-        case 1602: SXFIR_LAUNCH_MULTI(16, 2); break;
-        case 3204: SXFIR_LAUNCH_MULTI(32, 4); break;
-        case 3208: SXFIR_LAUNCH_MULTI(32, 8); break;
+        case 801: SXFIR_LAUNCH_MULTI(8, 1, false); break;
+        case 804: SXFIR_LAUNCH_MULTI(8, 4, false); break;
+        case 1602: SXFIR_LAUNCH_MULTI(16, 2, false); break;
+        case 3204: SXFIR_LAUNCH_MULTI(32, 4, false); break;
+        case 3208: SXFIR_LAUNCH_MULTI(32, 8, false); break;
+        case 10401: SXFIR_LAUNCH_MULTI(4, 1, true); break;
+        case 10801: SXFIR_LAUNCH_MULTI(8, 1, true); break;
+        case 11602: SXFIR_LAUNCH_MULTI(16, 2, true); break;
+        case 13204: SXFIR_LAUNCH_MULTI(32, 4, true); break;
+        case 13208: SXFIR_LAUNCH_MULTI(32, 8, true); break;
         default: return fail(SXFIR_EUNSUPPORTED, "no multi kernel for ratio %d with %d waves", p->ratio, W);
         }
 #undef SXFIR_LAUNCH_MULTI

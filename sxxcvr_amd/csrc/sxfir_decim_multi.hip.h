@@ -26,15 +26,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <hip/hip_fp16.h>
+
 #include "sxfir_decim_tile.hip.h"
 
 namespace sxfir {
 
 struct DecimMultiArgs {
-    const float *in;        // channel 0, sample 0 of this call (8-byte aligned is enough)
-    const float *hist;      // NT samples preceding `in`
-    float *hist_out;
-    float *out;             // 16-byte aligned
+    const void *in;         // channel 0, sample 0 of this call (aligned to one complex sample)
+    const void *hist;       // NT samples preceding `in`
+    void *hist_out;
+    void *out;              // 16-byte aligned
     const float *taps;
     long long n_in, n_out;
     long long in_stride, out_stride, hist_stride;
@@ -42,8 +44,10 @@ struct DecimMultiArgs {
     int n_groups;           // workgroups per channel (strided passes over the tiles)
 };
 
-template <int D, int W>
+template <int D, int W, bool HALF = false>
 struct DecimMulti {
+    // HALF: IQ stored as IEEE half pairs (CF16, 4 bytes per sample; BASELINE config 5), fp32
+    // arithmetic.  A 16-byte piece is then a whole row (4 samples) instead of half a row.
     static constexpr int NT = 32 * D;
     static constexpr int NCOL = D / 4;
     static constexpr int GW = 32 / NCOL;                  // output groups per wave
@@ -51,20 +55,29 @@ struct DecimMulti {
     static constexpr int OW = GW * R;                     // outputs per wave
     static constexpr int TILE_OUT = W * OW;
     static constexpr int NROWS = TILE_OUT + 31;           // rows q in [M0 - 31, M0 + TILE_OUT)
-    static constexpr int CH = 2 * NROWS;                  // 16-byte chunks per sub-stream
-    static constexpr int SUBSL = CH + CH / 16 + 1;        // with one pad chunk after every 16
+    static constexpr int CPR = HALF ? 1 : 2;              // 16-byte chunks per row
+    static constexpr int SBYTES = HALF ? 4 : 8;           // bytes per complex sample
+    static constexpr int CH = CPR * NROWS;                // chunks per sub-stream
+    static constexpr int PADP = 8 * CPR;                  // lane stride in chunks; one pad chunk after every PADP
+    static constexpr int SUBSL = CH + CH / PADP + 1;
     // sub-stream pitch: a whole number of DMA instructions (64 slots) with room for the bank skew
     static constexpr int IPS = (SUBSL + (NCOL >= 4 ? 12 : 0) + 63) / 64;   // DMA instructions per sub-stream
     static constexpr int SUBSTRIDE = IPS * 64;
     static constexpr int NI = NCOL * IPS;                 // DMA instructions per tile (all waves together)
     static constexpr int LDS_SLOTS = NI * 64;
-    static constexpr int WCH = 46;                        // window chunks per lane: 23 rows
+    static constexpr int WCH = 23 * CPR;                  // window chunks per lane: 23 rows
     static_assert(D % 4 == 0 && (NCOL & (NCOL - 1)) == 0 && NCOL <= 8, "D must be 4, 8, 16 or 32");
-    static_assert(SUBSL < 4000, "the (r+1)/17 multiply-shift is exact below 4000 only");
+    static_assert(SUBSL < 4000, "the multiply-shift divisions below are exact below 4000 only");
     // bank skew per column group so that the 16 lanes of every ds_read_b128 group differ in slot
     static __device__ __forceinline__ int skew(int c)
     {
         return NCOL == 8 ? 8 * (c & 1) + 4 * ((c >> 1) & 1) : (NCOL == 4 ? 8 * (c & 1) : 0);
+    }
+    // physical slot r of a sub-stream image -> logical chunk (a pad slot repeats its left neighbour)
+    static __device__ __forceinline__ int logical(int r)
+    {
+        return HALF ? r - (((r + 1) * 7282) >> 16)        // (r+1)/9
+                    : r - (((r + 1) * 3856) >> 16);       // (r+1)/17
     }
 };
 
@@ -74,10 +87,21 @@ __device__ __forceinline__ void permlane16_swap(float &vdst, float &src)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(vdst), "+v"(src));
 }
 
-template <int D, int W>
+__device__ __forceinline__ float half_bits_to_float(unsigned bits16)
+{
+    return __half2float(__ushort_as_half((unsigned short)bits16));
+}
+
+__device__ __forceinline__ unsigned pack_half2(float i, float q)
+{
+    const __half2 h = __floats2half2_rn(i, q);
+    return *reinterpret_cast<const unsigned *>(&h);
+}
+
+template <int D, int W, bool HALF = false>
 __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArgs a)
 {
-    using C = DecimMulti<D, W>;
+    using C = DecimMulti<D, W, HALF>;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
     const int tid = threadIdx.x;
@@ -92,9 +116,10 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
     const int g = lane & (C::GW - 1);
     const int ch = blockIdx.y;
 
-    const float *in = a.in + 2 * a.in_stride * ch;
-    const float *hist = a.hist + 2 * a.hist_stride * ch;
-    float *out = a.out + 2 * a.out_stride * ch;
+    // byte views: samples are 8 (CF32) or 4 (CF16) bytes
+    const char *in = reinterpret_cast<const char *>(a.in) + (long long)C::SBYTES * a.in_stride * ch;
+    const char *hist = reinterpret_cast<const char *>(a.hist) + (long long)C::SBYTES * a.hist_stride * ch;
+    char *out = reinterpret_cast<char *>(a.out) + (long long)C::SBYTES * a.out_stride * ch;
 
     // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16p + jj) + 4c + rr
     float h[64];
@@ -102,21 +127,22 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
     for (int kl = 0; kl < 64; ++kl) h[kl] = a.taps[D * (16 * p + (kl >> 2)) + 4 * c + (kl & 3)];
 
     const int G = ww * C::GW + g;                          // output group inside the workgroup tile
-    const int cc0 = 16 * (G - 2 * p + 2);                  // first window chunk in the sub-stream (multiple of 16)
-    const f32x4 *win = lds + (c * C::SUBSTRIDE + C::skew(c) + cc0 + (cc0 >> 4));
+    const int cc0 = C::PADP * (G - 2 * p + 2);             // first window chunk in the sub-stream (multiple of PADP)
+    const f32x4 *win = lds + (c * C::SUBSTRIDE + C::skew(c) + cc0 + cc0 / C::PADP);
 
-    // fused history carry-over: workgroup 0's last wave (channel ch) copies the tail of (hist ++ in)
+    // fused history carry-over: the last wave of the workgroup that owns the last tile copies the
+    // tail of (hist ++ in) into the plan's other history buffer
     if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && ww == W - 1) {
-        float *ho = a.hist_out + 2 * a.hist_stride * ch;
+        char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)C::SBYTES * a.hist_stride * ch;
         for (int j = lane; j < C::NT; j += 64) {
             const long long s = a.n_in - C::NT + j;
-            const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
-                                    : reinterpret_cast<const float2 *>(hist)[s + C::NT];
-            reinterpret_cast<float2 *>(ho)[j] = v;
+            const char *src = s >= 0 ? in + C::SBYTES * s : hist + C::SBYTES * (s + C::NT);
+            if constexpr (HALF) reinterpret_cast<unsigned *>(ho)[j] = *reinterpret_cast<const unsigned *>(src);
+            else reinterpret_cast<float2 *>(ho)[j] = *reinterpret_cast<const float2 *>(src);
         }
     }
 
-    // Tile-invariant part of the staging: byte offset (from the tile's first row, sample
+    // Tile-invariant part of the staging: sample offset (from the tile's first row, sample
     // x[D*(M0-31)]) of the 16-byte piece each of this wave's DMA instructions fetches for this lane.
     constexpr int NIW = (C::NI + W - 1) / W;
     int poff[NIW];
@@ -128,9 +154,10 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
         const int kb = o / C::NCOL, cs = o % C::NCOL;      // sub-stream (column group) of this instruction
         int r = 64 * kb + lane - C::skew(cs);              // slot inside the sub-stream image
         r = r < 0 ? 0 : (r >= C::SUBSL - 1 ? C::SUBSL - 2 : r);
-        const int cc = r - (((r + 1) * 3856) >> 16);       // logical chunk (pad slots dup a neighbour)
-        // piece = samples x[D*q - 4c - 3 + 2*half], +1 with q = M0 - 31 + (cc >> 1), half = cc & 1
-        poff[i0] = 8 * (D * (cc >> 1) - 4 * cs - 3 + 2 * (cc & 1));
+        const int cc = C::logical(r);
+        // CF32: piece = samples x[D*q - 4c - 3 + 2*half], +1 with q = M0 - 31 + (cc >> 1), half = cc & 1
+        // CF16: piece = the whole row x[D*q - 4c - 3 .. D*q - 4c] with q = M0 - 31 + cc
+        poff[i0] = HALF ? D * cc - 4 * cs - 3 : D * (cc >> 1) - 4 * cs - 3 + 2 * (cc & 1);
     }
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
@@ -138,7 +165,7 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
         // samples of the tile: [D*(M0-32)+1, D*(M0+TILE_OUT-1)]; interior = all inside `in`
         const bool interior = (M0 >= 32) && (D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1);
         const long long s_base = D * (M0 - 31);
-        const char *base = reinterpret_cast<const char *>(in) + 8 * s_base;
+        const char *base = in + C::SBYTES * s_base;
 
         __syncthreads();                                   // everyone is done reading the previous tile
         // ---- stage: the W waves share the NI DMA instructions -------------------
@@ -148,18 +175,25 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
             if (o < C::NI) {
                 const int i = (o % C::NCOL) * C::IPS + o / C::NCOL;      // instruction's place in the LDS image
                 if (interior) {
-                    glds16(base + poff[i0], lds + 64 * i);
+                    glds16(base + C::SBYTES * poff[i0], lds + 64 * i);
                 } else {
                     // edge tiles (first / last of a call): through registers, sample by sample
-                    const long long s = s_base + (poff[i0] >> 3);
-                    float2 v0, v1;
-                    const long long s1 = s + 1;
                     const long long last = a.n_in - 1;
-                    if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
-                    else v0 = (s + C::NT >= 0) ? reinterpret_cast<const float2 *>(hist)[s + C::NT] : make_float2(0.f, 0.f);
-                    if (s1 >= 0) v1 = reinterpret_cast<const float2 *>(in)[s1 <= last ? s1 : last];
-                    else v1 = (s1 + C::NT >= 0) ? reinterpret_cast<const float2 *>(hist)[s1 + C::NT] : make_float2(0.f, 0.f);
-                    lds[64 * i + lane] = (f32x4){v0.x, v0.y, v1.x, v1.y};
+                    unsigned wds[4];
+#pragma unroll
+                    for (int e = 0; e < 16 / C::SBYTES; ++e) {
+                        const long long s = s_base + poff[i0] + e;
+                        const char *src = s >= 0 ? in + C::SBYTES * (s <= last ? s : last)
+                                                 : hist + C::SBYTES * (s + C::NT >= 0 ? s + C::NT : 0);
+                        if constexpr (HALF) {
+                            wds[e] = *reinterpret_cast<const unsigned *>(src);
+                        } else {
+                            wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
+                            wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
+                        }
+                    }
+                    lds[64 * i + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]),
+                                                 __uint_as_float(wds[2]), __uint_as_float(wds[3])};
                 }
             }
         }
@@ -172,12 +206,20 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
         for (int i = 0; i < 8; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
 #pragma unroll
         for (int t = 0; t < C::WCH; ++t) {
-            const f32x4 v = win[t + (t >> 4)];
+            const f32x4 v = win[t + t / C::PADP];
+            constexpr int SPC = HALF ? 4 : 2;              // samples per chunk
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int w = 2 * t + s;
-                const float xi = s ? v.z : v.x;
-                const float xq = s ? v.w : v.y;
+            for (int s = 0; s < SPC; ++s) {
+                const int w = SPC * t + s;
+                float xi, xq;
+                if constexpr (HALF) {
+                    const unsigned bits = __float_as_uint(s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)));
+                    xi = half_bits_to_float(bits & 0xFFFFu);
+                    xq = half_bits_to_float(bits >> 16);
+                } else {
+                    xi = s ? v.z : v.x;
+                    xq = s ? v.w : v.y;
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int kl = 4 * i + 63 - w;
@@ -200,14 +242,24 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
         }
         const long long mw = M0 + (long long)ww * C::OW + 8 * g + 4 * p;
         if constexpr (C::NCOL == 1) {
-            float *dst = out + 2 * mw;
+            char *dst = out + C::SBYTES * mw;
             if (mw + 4 <= a.n_out) {
-                __builtin_nontemporal_store((f32x4){oi[0], oq[0], oi[1], oq[1]}, reinterpret_cast<f32x4 *>(dst));
-                __builtin_nontemporal_store((f32x4){oi[2], oq[2], oi[3], oq[3]}, reinterpret_cast<f32x4 *>(dst + 4));
+                if constexpr (HALF) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((u32x4){pack_half2(oi[0], oq[0]), pack_half2(oi[1], oq[1]),
+                                                        pack_half2(oi[2], oq[2]), pack_half2(oi[3], oq[3])},
+                                                reinterpret_cast<u32x4 *>(dst));
+                } else {
+                    __builtin_nontemporal_store((f32x4){oi[0], oq[0], oi[1], oq[1]}, reinterpret_cast<f32x4 *>(dst));
+                    __builtin_nontemporal_store((f32x4){oi[2], oq[2], oi[3], oq[3]}, reinterpret_cast<f32x4 *>(dst + 16));
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (mw + i < a.n_out) { dst[2 * i] = oi[i]; dst[2 * i + 1] = oq[i]; }
+                    if (mw + i < a.n_out) {
+                        if constexpr (HALF) reinterpret_cast<unsigned *>(dst)[i] = pack_half2(oi[i], oq[i]);
+                        else reinterpret_cast<float2 *>(dst)[i] = make_float2(oi[i], oq[i]);
+                    }
             }
         } else {
             // ---- reduce over column bit 0 (lane bit 4): even rows keep outputs 0-1, odd rows 2-3
@@ -237,12 +289,18 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
             const long long m = mw + 2 * ((lane >> 4) & 1);
             const bool writer = (C::NCOL < 4 || ((lane >> 3) & 1) == 0) && (C::NCOL < 8 || ((lane >> 2) & 1) == 0);
             if (writer) {
-                float *dst = out + 2 * m;
+                char *dst = out + C::SBYTES * m;
                 if (m + 2 <= a.n_out) {
-                    __builtin_nontemporal_store((f32x4){ri[0], rq[0], ri[1], rq[1]}, reinterpret_cast<f32x4 *>(dst));
+                    if constexpr (HALF) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store((u32x2){pack_half2(ri[0], rq[0]), pack_half2(ri[1], rq[1])},
+                                                    reinterpret_cast<u32x2 *>(dst));
+                    } else {
+                        __builtin_nontemporal_store((f32x4){ri[0], rq[0], ri[1], rq[1]}, reinterpret_cast<f32x4 *>(dst));
+                    }
                 } else if (m < a.n_out) {
-                    dst[0] = ri[0];
-                    dst[1] = rq[0];
+                    if constexpr (HALF) reinterpret_cast<unsigned *>(dst)[0] = pack_half2(ri[0], rq[0]);
+                    else reinterpret_cast<float2 *>(dst)[0] = make_float2(ri[0], rq[0]);
                 }
             }
         }

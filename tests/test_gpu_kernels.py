@@ -142,3 +142,29 @@ def test_tiled_interpolator_bit_exact(oracle, L, n_in):
     gen = sxxcvr_amd.Resampler(INTERPOLATE, h, L)
     gen.set_kernel(KERNEL_GENERIC)
     assert_bit_exact(to_cpu(gen.process(to_gpu(x))), ref, "generic interp L=%d" % L)
+
+
+@pytest.mark.parametrize("D,n_in", [(32, 1 << 18), (32, 4096 * 5 + 32 * 3), (8, 1 << 17), (4, 1 << 16), (16, 50000)])
+def test_cf16_tiled_decimators(oracle, D, n_in):
+    """CF16 storage through the LDS-tiled multi-column kernel: bit-exact against the oracle applied
+    to the half-rounded input, output rounded to half once (RNE)."""
+    from sxxcvr_amd.resampler import KERNEL_GENERIC, KERNEL_TILED
+    n_in -= n_in % D
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    x = oracle.synth_iq(SEED, 17, 0, n_in + 4096)
+    x16 = oracle.f32_to_f16(x.view(np.float32))                     # uint16 pairs
+    xq = oracle.f16_to_f32(x16).view(np.complex64)
+    words = to_gpu(x16.view(np.uint32).view(np.int32))
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
+    plan.set_kernel(KERNEL_TILED)
+    y1 = plan.process(words[:n_in].clone())
+    y2 = plan.process(words[n_in:].clone())                        # fused history carry-over, CF16
+    _sync()
+    got = np.concatenate([to_cpu(y1), to_cpu(y2)]).view(np.uint16)
+    want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, *plan.contract).view(np.float32))
+    assert np.array_equal(got, want), "CF16 tiled D=%d" % D
+    gen = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
+    gen.set_kernel(KERNEL_GENERIC)
+    yg = gen.process(words.clone())
+    _sync()
+    assert np.array_equal(to_cpu(yg).view(np.uint16), want)
