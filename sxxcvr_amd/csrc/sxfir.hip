@@ -182,6 +182,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
     // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
     p->multi_waves = ratio <= 8 ? 1 : (ratio == 16 ? 2 : 4);
+    if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
+        if (strcmp(v, "mu") == 0 && mode == SXFIR_DECIMATE && fmt == SXFIR_CF32 && ratio == 4 && ntaps == 128) {
+            p->multi_capable = true;        // A/B: the multi-column kernel at D = 4 instead of decim4_tile_kernel
+            p->tile_capable = false;
+        }
+    }
     p->occ_multi = 2;
     if (p->multi_capable) {
         if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
@@ -190,6 +196,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         const void *k = nullptr;
         switch ((fmt == SXFIR_CF16 ? 10000 : 0) + ratio * 100 + W) {
+        case 401: k = (const void *)sxfir::decim_multi_kernel<4, 1, false>; break;
+        case 404: k = (const void *)sxfir::decim_multi_kernel<4, 4, false>; break;
         case 801: k = (const void *)sxfir::decim_multi_kernel<8, 1, false>; break;
         case 804: k = (const void *)sxfir::decim_multi_kernel<8, 4, false>; break;
         case 1602: k = (const void *)sxfir::decim_multi_kernel<16, 2, false>; break;
@@ -363,6 +371,8 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH>), grid, dim3(64 * WW), 0, st, a)
         const int key = (p->fmt == SXFIR_CF16 ? 10000 : 0) + p->ratio * 100 + W;
         switch (key) {
+        case 401: SXFIR_LAUNCH_MULTI(4, 1, false); break;
+        case 404: SXFIR_LAUNCH_MULTI(4, 4, false); break;
         case 801: SXFIR_LAUNCH_MULTI(8, 1, false); break;
         case 804: SXFIR_LAUNCH_MULTI(8, 4, false); break;
         case 1602: SXFIR_LAUNCH_MULTI(16, 2, false); break;

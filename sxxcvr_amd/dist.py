@@ -64,13 +64,21 @@ def gather_channels(local, n_channels, dst=0, group=None):
     is_complex = send.is_complex()
     wire = torch.view_as_real(send) if is_complex else send
     wire = wire.contiguous()
-    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
+    full = None
+    bufs = None
+    if rank == dst:
+        # one destination tensor, the collective writes straight into its per-rank slices
+        full = torch.empty((world * widest,) + tuple(wire.shape[1:]), dtype=wire.dtype, device=wire.device)
+        bufs = list(full.split(widest, dim=0))
     dist.gather(wire, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    parts = []
-    for r in range(world):
-        rlo, rhi = shard_channels(n_channels, world, r)
-        b = bufs[r][: rhi - rlo]
-        parts.append(torch.view_as_complex(b) if is_complex else b)
-    return torch.cat(parts, dim=0)
+    if n_channels == world * widest:                      # equal shards: already in global channel order
+        out = full
+    else:
+        parts = []
+        for r in range(world):
+            rlo, rhi = shard_channels(n_channels, world, r)
+            parts.append(bufs[r][: rhi - rlo])
+        out = torch.cat(parts, dim=0)
+    return torch.view_as_complex(out) if is_complex else out
