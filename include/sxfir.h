@@ -59,8 +59,12 @@ enum {
 
 enum { SXFIR_DECIMATE = 0, SXFIR_INTERPOLATE = 1 };
 
-/* IQ storage format in HBM.  Arithmetic is always fp32. */
-enum { SXFIR_CF32 = 0, SXFIR_CF16 = 1 };
+/* IQ storage format in HBM.  Arithmetic is always fp32.
+ * SXFIR_S32 is the reference's on-wire format (S32_LE I2S words, I then Q, 8 bytes per sample) fused
+ * into the resampling kernels: a DECIMATE plan reads S32 words (value = 2^-31 * word, convert_rx_buffer,
+ * SX.cpp:103-112) and writes CF32; an INTERPOLATE plan reads CF32 and writes S32 words with the
+ * transmitter-keying bits of convert_tx_buffer (SX.cpp:116-137; threshold: sxfir_set_tx_threshold). */
+enum { SXFIR_CF32 = 0, SXFIR_CF16 = 1, SXFIR_S32 = 2 };
 
 /* Kernel selection (for tests / profiling).  AUTO picks the LDS-tiled kernel
  * whenever the shape allows it and the generic one-output-per-thread kernel
@@ -88,6 +92,9 @@ int sxfir_create(sxfir_plan **plan, int mode, const float *taps, int ntaps, int 
 int sxfir_destroy(sxfir_plan *plan);
 int sxfir_reset(sxfir_plan *plan, void *stream);
 int sxfir_set_kernel(sxfir_plan *plan, int kernel);
+/* Squared-magnitude threshold above which an SXFIR_S32 interpolator sets the two low bits of the I
+ * word (tx_threshold2 of SX.cpp:540-542, :132-133).  Default 1e-6 (threshold 1e-3, SX.cpp:767). */
+int sxfir_set_tx_threshold(sxfir_plan *plan, float tx_threshold2);
 
 /* The numeric contract of this plan, for an order-matched CPU check:
  * decimator: taps split into `jsplit` contiguous ranges of polyphase rows j

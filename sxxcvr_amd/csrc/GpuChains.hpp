@@ -56,13 +56,15 @@ private:
 
 class RxChain {
 public:
-    RxChain(int gpu, int decim, int taps_per_phase, uint64_t seed, uint32_t channel)
-        : decim_(decim), ntaps_(decim * taps_per_phase), seed_(seed), channel_(channel), plan_(nullptr), next_(-1)
+    // wire_s32: the synthetic ADC stream is S32_LE I2S words and the decimator converts them on
+    // load (the reference's wire format, SoapySX.cpp:103-112); otherwise CF32 end to end.
+    RxChain(int gpu, int decim, int taps_per_phase, uint64_t seed, uint32_t channel, bool wire_s32)
+        : decim_(decim), ntaps_(decim * taps_per_phase), seed_(seed), channel_(channel),
+          fmt_(wire_s32 ? SXFIR_S32 : SXFIR_CF32), plan_(nullptr), next_(-1)
     {
         std::vector<float> taps((size_t)ntaps_);
         gpu_check(sxfir_design_lowpass(ntaps_, decim_, 8.0, 1.0, taps.data()), "sxfir_design_lowpass");
-        gpu_check(sxfir_create(&plan_, SXFIR_DECIMATE, taps.data(), ntaps_, decim_, 1, SXFIR_CF32, gpu),
-                  "sxfir_create(rx)");
+        gpu_check(sxfir_create(&plan_, SXFIR_DECIMATE, taps.data(), ntaps_, decim_, 1, fmt_, gpu), "sxfir_create(rx)");
     }
     ~RxChain() { sxfir_destroy(plan_); }
     RxChain(const RxChain &) = delete;
@@ -100,8 +102,7 @@ private:
     void run(int64_t pos, size_t m)
     {
         size_t n_out = 0;
-        gpu_check(sxfir_synth_fill(in_.get(), m * (size_t)decim_, 0, 1, seed_, channel_, pos * decim_, SXFIR_CF32,
-                                   nullptr),
+        gpu_check(sxfir_synth_fill(in_.get(), m * (size_t)decim_, 0, 1, seed_, channel_, pos * decim_, fmt_, nullptr),
                   "sxfir_synth_fill");
         gpu_check(sxfir_decimate(plan_, in_.get(), m * (size_t)decim_, 0, out_.get(), 0, &n_out, nullptr),
                   "sxfir_decimate");
@@ -118,8 +119,8 @@ private:
         in_.reserve(sizeof(float) * 2 * (size_t)(warm * decim_));
         out_.reserve(sizeof(float) * 2 * (size_t)warm);
         size_t n_out = 0;
-        gpu_check(sxfir_synth_fill(in_.get(), (size_t)(warm * decim_), 0, 1, seed_, channel_, from * decim_,
-                                   SXFIR_CF32, nullptr),
+        gpu_check(sxfir_synth_fill(in_.get(), (size_t)(warm * decim_), 0, 1, seed_, channel_, from * decim_, fmt_,
+                                   nullptr),
                   "sxfir_synth_fill");
         gpu_check(sxfir_decimate(plan_, in_.get(), (size_t)(warm * decim_), 0, out_.get(), 0, &n_out, nullptr),
                   "sxfir_decimate(prime)");
@@ -128,6 +129,7 @@ private:
     int decim_, ntaps_;
     uint64_t seed_;
     uint32_t channel_;
+    int fmt_;
     sxfir_plan *plan_;
     DeviceBuffer in_, out_;
     int64_t next_;
@@ -135,14 +137,17 @@ private:
 
 class TxChain {
 public:
-    TxChain(int gpu, int interp, int taps_per_phase, size_t ring_frames)
+    // wire_s32: the DAC-rate sink holds S32_LE I2S words with the transmitter-keying bits
+    // (convert_tx_buffer, SoapySX.cpp:116-137, fused into the interpolator's store).
+    TxChain(int gpu, int interp, int taps_per_phase, size_t ring_frames, bool wire_s32)
         : interp_(interp), ntaps_(interp * taps_per_phase), plan_(nullptr), ring_len_(ring_frames * (size_t)interp),
           next_(0), written_(0)
     {
         std::vector<float> taps((size_t)ntaps_);
         // gain = interp: unity pass-band gain after zero stuffing
         gpu_check(sxfir_design_lowpass(ntaps_, interp_, 8.0, (double)interp_, taps.data()), "sxfir_design_lowpass");
-        gpu_check(sxfir_create(&plan_, SXFIR_INTERPOLATE, taps.data(), ntaps_, interp_, 1, SXFIR_CF32, gpu),
+        gpu_check(sxfir_create(&plan_, SXFIR_INTERPOLATE, taps.data(), ntaps_, interp_, 1,
+                               wire_s32 ? SXFIR_S32 : SXFIR_CF32, gpu),
                   "sxfir_create(tx)");
         ring_.reserve(sizeof(float) * 2 * ring_len_);
         zeros_.assign(2 * 4096, 0.0f);
@@ -153,6 +158,7 @@ public:
 
     int interp() const { return interp_; }
     int64_t written() const { return written_; }
+    void set_threshold2(float thr2) { gpu_check(sxfir_set_tx_threshold(plan_, thr2), "sxfir_set_tx_threshold"); }
 
     void reset()
     {

@@ -25,6 +25,9 @@
 //   interp=<L>         TX interpolation done on the GPU (default 4)
 //   taps_per_phase=<n> filter length = n * ratio (default 32)
 //   seed=<u64>         synthetic source seed (default 0x51255)
+//   wire=cf32|s32      sample format on the synthetic chip side of the GPU kernels (default cf32);
+//                      s32 = the reference's S32_LE I2S words: the RX decimator converts them on load
+//                      (:103-112), the TX interpolator writes them with the keying bits (:116-137)
 #include <SoapySDR/Device.hpp>
 #include <SoapySDR/Logger.hpp>
 #include <SoapySDR/Registry.hpp>
@@ -100,6 +103,7 @@ private:
     int gpu;
     int decim, interp, taps_per_phase;
     uint64_t seed;
+    bool wire_s32;
     std::unique_ptr<sx::RxChain> rx_chain;
     std::unique_ptr<sx::TxChain> tx_chain;
     int64_t tx_ptt_samples;     // written samples at or above the TX threshold (PTT bit of :132-133)
@@ -155,6 +159,7 @@ public:
           interp(std::stoi(arg(args, "interp", "4"))),
           taps_per_phase(std::stoi(arg(args, "taps_per_phase", "32"))),
           seed(std::stoull(arg(args, "seed", "0x51255"), nullptr, 0)),
+          wire_s32(arg(args, "wire", "cf32") == "s32"),
           tx_ptt_samples(0)
     {
         SoapySDR_logf(SOAPY_SDR_INFO, "Initializing SoapySX (MI355X synthetic-IQ build)");
@@ -169,8 +174,8 @@ public:
         set_register_bits(0, 1, 3, 0b111);
         setFrequency(SOAPY_SDR_RX, 0, 433.92e6, {});   // :663-664
         setFrequency(SOAPY_SDR_TX, 0, 433.92e6, {});
-        rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, 0));
-        tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536));
+        rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, 0, wire_s32));
+        tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, wire_s32));
     }
 
     ~SoapySXHip(void) { SoapySDR_logf(SOAPY_SDR_INFO, "Uninitializing SoapySX"); }
@@ -197,6 +202,7 @@ public:
             const float tx_threshold =
                 (args.count("threshold") > 0) ? std::stof(args.at("threshold")) : tx_threshold_default;
             tx_threshold2 = tx_threshold * tx_threshold;
+            tx_chain->set_threshold2(tx_threshold2);
         }
 
         const bool arg_link = (args.count("link") > 0 && args.at("link") == "1");

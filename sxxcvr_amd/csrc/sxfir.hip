@@ -42,7 +42,7 @@ int fail(int code, const char *fmt, ...)
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-inline size_t sample_bytes(int fmt) { return fmt == SXFIR_CF16 ? 4 : 8; }
+inline size_t sample_bytes(int fmt) { return fmt == SXFIR_CF16 ? 4 : 8; }   // CF32 and S32 words: 8 bytes
 
 }  // namespace
 
@@ -59,6 +59,7 @@ struct sxfir_plan {
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
     int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
     int oversub;           // waves launched = CUs * occupancy * oversub
+    float thr2;            // S32 interpolator: transmitter-keying threshold (squared magnitude)
     int sgpr_r;            // experiment: SGPR-tap variant with R outputs per lane (0 = off)
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
@@ -112,7 +113,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     if (ntaps < 1 || ntaps > 65536) return fail(SXFIR_EINVAL, "ntaps %d out of range", ntaps);
     if (ratio < 1 || ratio > 4096) return fail(SXFIR_EINVAL, "ratio %d out of range", ratio);
     if (nchan < 1 || nchan > 65535) return fail(SXFIR_EINVAL, "nchan %d out of range", nchan);
-    if (fmt != SXFIR_CF32 && fmt != SXFIR_CF16) return fail(SXFIR_EINVAL, "bad format %d", fmt);
+    if (fmt != SXFIR_CF32 && fmt != SXFIR_CF16 && fmt != SXFIR_S32) return fail(SXFIR_EINVAL, "bad format %d", fmt);
     if (mode == SXFIR_INTERPOLATE && ntaps % ratio)
         return fail(SXFIR_EINVAL, "interpolator needs ntaps %% ratio == 0 (%d, %d)", ntaps, ratio);
 
@@ -146,7 +147,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
-        p->tile_capable = (fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64));
+        p->tile_capable = ((fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64)) ||
+                           (fmt == SXFIR_S32 && ratio == 4 && ntaps == 128));
         // multi-column kernel: 32 taps per phase; CF32 at ratio 8/16/32, CF16 at ratio 4/8/16/32
         p->multi_capable = (ntaps == 32 * ratio) &&
                            ((fmt == SXFIR_CF32 && (ratio == 8 || ratio == 16 || ratio == 32)) ||
@@ -164,7 +166,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         p->hist_len = (jt + 1) & ~1;
         p->tile_capable = false;
         p->multi_capable = false;
-        p->itile_capable = (fmt == SXFIR_CF32 && ntaps == 32 * ratio &&
+        p->itile_capable = ((fmt == SXFIR_CF32 || fmt == SXFIR_S32) && ntaps == 32 * ratio &&
                             (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32));
         p->jsplit = (jt % 2 == 0) ? 2 : 1;
         p->cw = 1;
@@ -179,6 +181,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->ablate = 0;
     p->sched = 0;
     p->sgpr_r = 0;
+    p->thr2 = 1.0e-3f * 1.0e-3f;
     // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
     // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
     p->multi_waves = ratio <= 8 ? 1 : (ratio == 16 ? 2 : 4);
@@ -286,6 +289,13 @@ int sxfir_set_kernel(sxfir_plan *p, int kernel)
     return SXFIR_OK;
 }
 
+int sxfir_set_tx_threshold(sxfir_plan *p, float tx_threshold2)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    p->thr2 = tx_threshold2;
+    return SXFIR_OK;
+}
+
 int sxfir_contract(const sxfir_plan *p, int *jsplit, int *cw)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
@@ -320,7 +330,7 @@ int sxfir_outputs_for(const sxfir_plan *p, size_t n_in, size_t *n_out)
 
 static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, hipStream_t st)
 {
-    if (p->fmt == SXFIR_CF32)
+    if (p->fmt != SXFIR_CF16)
         hipLaunchKernelGGL(sxfir::history_kernel<float2>, dim3(p->nchan), dim3(256), 0, st,
                            (float2 *)p->hist_dev, (const float2 *)in_dev, (long long)n_in, (long long)in_stride,
                            (long long)p->hist_len, p->hist_len);
@@ -420,7 +430,9 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_waves = (int)per_chan;
         a.sched = p->sched;
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
-        if (p->ntaps == 128 && p->sgpr_r == 8) {
+        if (p->fmt == SXFIR_S32) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->sgpr_r == 8) {
             hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<8>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->sgpr_r == 4) {
             hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<4>), grid, dim3(64), 0, st, a);
@@ -455,10 +467,13 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.jsplit = p->jsplit;
         a.cw = p->cw;
         dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
+        a.thr2 = p->thr2;
         if (p->fmt == SXFIR_CF32)
             hipLaunchKernelGGL(sxfir::decim_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, st, a);
-        else
+        else if (p->fmt == SXFIR_CF16)
             hipLaunchKernelGGL(sxfir::decim_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((sxfir::decim_generic_kernel<sxfir::S32, sxfir::CF32>), grid, dim3(256), 0, st, a);
     }
     HIPCHECK(hipGetLastError());
     return SXFIR_OK;
@@ -537,12 +552,22 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
         if (groups > n_tiles) groups = n_tiles;
         t.n_tiles = (int)n_tiles;
         t.n_groups = (int)groups;
+        t.thr2 = p->thr2;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
-        switch (p->ratio) {
-        case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, S(stream), t); break;
-        case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, S(stream), t); break;
-        case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, S(stream), t); break;
-        default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, S(stream), t); break;
+        if (p->fmt == SXFIR_S32) {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, S(stream), t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, S(stream), t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true>), grid, dim3(64), 0, S(stream), t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true>), grid, dim3(64), 0, S(stream), t); break;
+            }
+        } else {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, S(stream), t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, S(stream), t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, S(stream), t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, S(stream), t); break;
+            }
         }
         HIPCHECK(hipGetLastError());
         std::swap(p->hist_dev, p->hist_alt);
@@ -568,10 +593,13 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     a.jsplit = p->jsplit;
     a.cw = p->cw;
     dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
+    a.thr2 = p->thr2;
     if (p->fmt == SXFIR_CF32)
         hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, S(stream), a);
-    else
+    else if (p->fmt == SXFIR_CF16)
         hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, S(stream), a);
+    else
+        hipLaunchKernelGGL((sxfir::interp_generic_kernel<sxfir::CF32, sxfir::S32>), grid, dim3(256), 0, S(stream), a);
     HIPCHECK(hipGetLastError());
     rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
     if (rc) return rc;
@@ -625,6 +653,9 @@ int sxfir_synth_fill(void *out_dev, size_t n, size_t stride, int nchan, uint64_t
                            (long long)stride, seed, first_channel, (long long)start);
     else if (fmt == SXFIR_CF16)
         hipLaunchKernelGGL(sxfir::synth_kernel<sxfir::CF16>, grid, dim3(256), 0, S(stream), out_dev, (long long)n,
+                           (long long)stride, seed, first_channel, (long long)start);
+    else if (fmt == SXFIR_S32)
+        hipLaunchKernelGGL(sxfir::synth_s32_kernel, grid, dim3(256), 0, S(stream), (int2 *)out_dev, (long long)n,
                            (long long)stride, seed, first_channel, (long long)start);
     else
         return fail(SXFIR_EINVAL, "bad format");

@@ -195,7 +195,7 @@ __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int t
     store_tile<NT>(c, tile, oi, oq, xbuf);
 }
 
-template <int NT>
+template <int NT, bool S32IN = false>
 __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,
                                              const float (&h)[NT / 2], f32x4 *xbuf)
 {
@@ -208,7 +208,14 @@ __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile
 
 #pragma unroll
     for (int t = 0; t < C::WCH; ++t) {
-        const f32x4 v = win[t + (t >> 4)];
+        f32x4 v = win[t + (t >> 4)];
+        if constexpr (S32IN) {
+            // S32_LE wire words (convert_rx_buffer, SoapySX.cpp:103-112): only the int->float conversion
+            // happens here; the exact 2^-31 scale is folded into the taps by the caller, which gives the
+            // same bits as scaling every sample (a power of two commutes with the fused multiply-add)
+            v = (f32x4){(float)__float_as_int(v.x), (float)__float_as_int(v.y), (float)__float_as_int(v.z),
+                        (float)__float_as_int(v.w)};
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int w = 2 * t + s;
@@ -261,7 +268,8 @@ __device__ __forceinline__ void write_history(const DecimTileCtx<NT> &c, float *
 
 // ABL (profiling builds only; 3 = packed-FMA arithmetic): 0 = the real kernel, 1 = stage + store but no FIR arithmetic
 // (memory side alone), 2 = FIR arithmetic on whatever LDS holds, no staging (compute side alone).
-template <int NT, bool DBUF, int ABL = 0>
+// S32IN: the input (and the history) are S32_LE I2S wire words instead of CF32.
+template <int NT, bool DBUF, int ABL = 0, bool S32IN = false>
 __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
 {
     using C = DecimTile4<NT>;
@@ -281,7 +289,8 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     // taps of this lane's half, h[kl] = taps[TPL*p + kl]
     float h[C::TPL];
 #pragma unroll
-    for (int k = 0; k < C::TPL; ++k) h[k] = a.taps[C::TPL * c.p + k];
+    for (int k = 0; k < C::TPL; ++k)
+        h[k] = S32IN ? __fmul_rn(a.taps[C::TPL * c.p + k], 4.656612873077393e-10f) : a.taps[C::TPL * c.p + k];
 
     // this lane's window chunk 0 inside a buffer
     const int u0c = 16 * c.g - (NT / 4) * c.p + NT / 4;   // logical chunk, multiple of 16
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             if constexpr (ABL == 3) {
                 compute_tile_pk<NT>(c, tile, win0, h, lds);
             } else if constexpr (ABL != 1) {
-                compute_tile<NT>(c, tile, win0, h, lds);
+                compute_tile<NT, S32IN>(c, tile, win0, h, lds);
             } else {
                 const f32x4 v0 = win0[0], v1 = win0[17];
                 const long long m = (long long)tile * C::TILE_OUT + 8 * c.g + 4 * c.p;

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "sxfir_decim_tile.hip.h"
+#include "sxfir_kernels.hip.h"
 
 namespace sxfir {
 
@@ -35,6 +36,7 @@ struct InterpTileArgs {
     long long n_in;         // input samples per channel (outputs = n_in * L)
     long long in_stride, out_stride, hist_stride;
     int n_tiles, n_groups;
+    float thr2;             // S32 output: transmitter-keying threshold (squared magnitude)
 };
 
 template <int L>
@@ -51,7 +53,8 @@ struct InterpTile {
     static_assert(L % 4 == 0 && (NPH & (NPH - 1)) == 0 && NPH <= 8, "L must be 4, 8, 16 or 32");
 };
 
-template <int L>
+// S32OUT: outputs leave as S32_LE I2S wire words with the keying bits (convert_tx_buffer, SoapySX.cpp:116-137)
+template <int L, bool S32OUT = false>
 __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 {
     using C = InterpTile<L>;
@@ -167,7 +170,11 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int oc = 64 * k + lane;
-            const f32x4 v = obuf[oc + (oc >> 4)];
+            f32x4 v = obuf[oc + (oc >> 4)];
+            if constexpr (S32OUT) {
+                const int2 w0 = tx_words(v.x, v.y, a.thr2), w1 = tx_words(v.z, v.w, a.thr2);
+                v = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
+            }
             const long long o = o0 + 2 * oc;
             if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
         }

@@ -16,7 +16,7 @@ struct CF32 {
     {
         return reinterpret_cast<const float2 *>(base)[idx];
     }
-    static __device__ __forceinline__ void store(void *base, long long idx, float2 v)
+    static __device__ __forceinline__ void store(void *base, long long idx, float2 v, float)
     {
         reinterpret_cast<float2 *>(base)[idx] = v;
     }
@@ -28,9 +28,48 @@ struct CF16 {
     {
         return __half22float2(reinterpret_cast<const __half2 *>(base)[idx]);
     }
-    static __device__ __forceinline__ void store(void *base, long long idx, float2 v)
+    static __device__ __forceinline__ void store(void *base, long long idx, float2 v, float)
     {
         reinterpret_cast<__half2 *>(base)[idx] = __floats2half2_rn(v.x, v.y);
+    }
+};
+
+// convert_tx_buffer, SoapySX.cpp:116-137.  float->int32 saturates and maps NaN to 0
+// (v_cvt_i32_f32 semantics = the ARM behaviour of the reference's real platform; the C++ source
+// leaves 2^31 * 1.0f undefined).
+__device__ __forceinline__ int tx_word(float f)
+{
+    float c = (1.0f < f) ? 1.0f : f;         // std::min(f, 1.0f)
+    c = (c < -1.0f) ? -1.0f : c;             // std::max(., -1.0f)
+    const float v = __fmul_rn(2147483648.0f, c);
+    int r;
+    if (v != v) r = 0;
+    else if (v >= 2147483648.0f) r = 2147483647;
+    else if (v <= -2147483648.0f) r = (int)0x80000000;
+    else r = (int)v;
+    return r & (int)0xFFFFFFFC;
+}
+
+__device__ __forceinline__ int2 tx_words(float fi, float fq, float thr2)
+{
+    int vi = tx_word(fi);
+    const int vq = tx_word(fq);
+    const float mag = __fadd_rn(__fmul_rn(fi, fi), __fmul_rn(fq, fq));
+    if (mag >= thr2) vi |= 3;
+    return make_int2(vi, vq);
+}
+
+// S32_LE I2S wire words: load = convert_rx_buffer (SoapySX.cpp:103-112), store = convert_tx_buffer.
+struct S32 {
+    typedef int2 storage;
+    static __device__ __forceinline__ float2 load(const void *base, long long idx)
+    {
+        const int2 v = reinterpret_cast<const int2 *>(base)[idx];
+        return make_float2(__fmul_rn(4.656612873077393e-10f, (float)v.x), __fmul_rn(4.656612873077393e-10f, (float)v.y));
+    }
+    static __device__ __forceinline__ void store(void *base, long long idx, float2 v, float thr2)
+    {
+        reinterpret_cast<int2 *>(base)[idx] = tx_words(v.x, v.y, thr2);
     }
 };
 
@@ -45,6 +84,7 @@ struct GenericArgs {
                             // interp: phase offset (always 0 here)
     int ntaps, ratio, hist_len;
     int jsplit, cw;         // numeric contract
+    float thr2;             // S32 output only: transmitter-keying threshold (squared magnitude)
 };
 
 template <typename F>
@@ -58,7 +98,7 @@ __device__ __forceinline__ float2 sample_at(const GenericArgs &a, const void *in
 // One output per thread, any ntaps / ratio / alignment.  Same contract as the
 // tiled kernels: partial[c][p] over rows j descending and phases r descending,
 // adjacent-pair trees over p then c.  (jsplit, cw <= 32 partials each.)
-template <typename F>
+template <typename F, typename FO = F>
 __global__ __launch_bounds__(256) void decim_generic_kernel(const GenericArgs a)
 {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,7 +106,7 @@ __global__ __launch_bounds__(256) void decim_generic_kernel(const GenericArgs a)
     const int ch = blockIdx.y;
     const char *in = (const char *)a.in + sizeof(typename F::storage) * a.in_stride * ch;
     const char *hist = (const char *)a.hist + sizeof(typename F::storage) * a.hist_stride * ch;
-    char *out = (char *)a.out + sizeof(typename F::storage) * a.out_stride * ch;
+    char *out = (char *)a.out + sizeof(typename FO::storage) * a.out_stride * ch;
 
     const int D = a.ratio;
     const int jt = (a.ntaps + D - 1) / D;
@@ -105,12 +145,12 @@ __global__ __launch_bounds__(256) void decim_generic_kernel(const GenericArgs a)
             ci[i] = __fadd_rn(ci[2 * i], ci[2 * i + 1]);
             cq[i] = __fadd_rn(cq[2 * i], cq[2 * i + 1]);
         }
-    F::store(out, m, make_float2(ci[0], cq[0]));
+    FO::store(out, m, make_float2(ci[0], cq[0]), a.thr2);
 }
 
 // Interpolator, one output per thread: y[n] = sum_j h[j*L + n%L] x[n/L - j],
 // jsplit contiguous ranges of j, chain over descending j, adjacent-pair tree.
-template <typename F>
+template <typename F, typename FO = F>
 __global__ __launch_bounds__(256) void interp_generic_kernel(const GenericArgs a)
 {
     const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,7 +158,7 @@ __global__ __launch_bounds__(256) void interp_generic_kernel(const GenericArgs a
     const int ch = blockIdx.y;
     const char *in = (const char *)a.in + sizeof(typename F::storage) * a.in_stride * ch;
     const char *hist = (const char *)a.hist + sizeof(typename F::storage) * a.hist_stride * ch;
-    char *out = (char *)a.out + sizeof(typename F::storage) * a.out_stride * ch;
+    char *out = (char *)a.out + sizeof(typename FO::storage) * a.out_stride * ch;
 
     const int L = a.ratio;
     const int jt = a.ntaps / L;
@@ -142,7 +182,7 @@ __global__ __launch_bounds__(256) void interp_generic_kernel(const GenericArgs a
             pi[i] = __fadd_rn(pi[2 * i], pi[2 * i + 1]);
             pq[i] = __fadd_rn(pq[2 * i], pq[2 * i + 1]);
         }
-    F::store(out, n, make_float2(pi[0], pq[0]));
+    FO::store(out, n, make_float2(pi[0], pq[0]), a.thr2);
 }
 
 // History carry-over: hist <- last hist_len samples of (hist ++ in[0, n_in)).
@@ -191,7 +231,22 @@ __global__ __launch_bounds__(256) void synth_kernel(void *out, long long n, long
     char *o = (char *)out + sizeof(typename F::storage) * stride * ch;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
-        F::store(o, i, synth_sample(key, start + i));
+        F::store(o, i, synth_sample(key, start + i), 0.0f);
+}
+
+// The same source as S32_LE wire words: the 24-bit grid value v has the exact word v * 2^31
+// (24-bit integer << 8), so convert_rx of these words reproduces the CF32 source bit for bit.
+__global__ __launch_bounds__(256) void synth_s32_kernel(int2 *out, long long n, long long stride, uint64_t seed,
+                                                        uint32_t first_channel, long long start)
+{
+    const int ch = blockIdx.y;
+    const uint64_t key = sm64_finalize(seed + 0x9E3779B97F4A7C15ULL * ((uint64_t)(first_channel + ch) + 1));
+    int2 *o = out + stride * ch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = synth_sample(key, start + i);
+        o[i] = make_int2((int)(v.x * 8388608.0f) * 256, (int)(v.y * 8388608.0f) * 256);
+    }
 }
 
 // ---- S32_LE I2S wire format (SoapySX.cpp:103-137) --------------------------
@@ -206,32 +261,12 @@ __global__ __launch_bounds__(256) void convert_rx_kernel(const int2 *src, float2
     }
 }
 
-// convert_tx_buffer, SoapySX.cpp:116-137.  float->int32 saturates and maps NaN
-// to 0 (v_cvt_i32_f32 semantics = the ARM behaviour of the reference's real
-// platform; the C++ source leaves 2^31 * 1.0f undefined).
-__device__ __forceinline__ int tx_word(float f)
-{
-    float c = (1.0f < f) ? 1.0f : f;         // std::min(f, 1.0f)
-    c = (c < -1.0f) ? -1.0f : c;             // std::max(., -1.0f)
-    const float v = __fmul_rn(2147483648.0f, c);
-    int r;
-    if (v != v) r = 0;
-    else if (v >= 2147483648.0f) r = 2147483647;
-    else if (v <= -2147483648.0f) r = (int)0x80000000;
-    else r = (int)v;
-    return r & (int)0xFFFFFFFC;
-}
-
 __global__ __launch_bounds__(256) void convert_tx_kernel(const float2 *src, int2 *dst, long long n, float thr2)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const float2 f = src[i];
-        int vi = tx_word(f.x);
-        const int vq = tx_word(f.y);
-        const float mag = __fadd_rn(__fmul_rn(f.x, f.x), __fmul_rn(f.y, f.y));
-        if (mag >= thr2) vi |= 3;
-        dst[i] = make_int2(vi, vq);
+        dst[i] = tx_words(f.x, f.y, thr2);
     }
 }
 

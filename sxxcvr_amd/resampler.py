@@ -11,9 +11,9 @@ import numpy as np
 from ._native import check, load_sxfir
 
 DECIMATE, INTERPOLATE = 0, 1
-CF32, CF16 = 0, 1
+CF32, CF16, S32 = 0, 1, 2
 KERNEL_AUTO, KERNEL_TILED, KERNEL_GENERIC = 0, 1, 2
-_FMT = {"CF32": CF32, "CF16": CF16, CF32: CF32, CF16: CF16}
+_FMT = {"CF32": CF32, "CF16": CF16, "S32": S32, CF32: CF32, CF16: CF16, S32: S32}
 
 
 def design_lowpass(ntaps, ratio, beta=8.0, gain=1.0):
@@ -82,6 +82,9 @@ class Resampler:
     def set_kernel(self, kernel):
         check(self._lib.sxfir_set_kernel(self._plan, kernel))
 
+    def set_tx_threshold(self, threshold2):
+        check(self._lib.sxfir_set_tx_threshold(self._plan, float(threshold2)))
+
     def reset(self, stream=None):
         check(self._lib.sxfir_reset(self._plan, C.c_void_p(stream or 0)))
 
@@ -101,7 +104,20 @@ class Resampler:
 
     # -- torch tensors --------------------------------------------------------
     def process(self, x, out=None):
-        """x: CUDA tensor [nchan, n] or [n]; complex64 (CF32) or int32 words (CF16)."""
+        """x: CUDA tensor [nchan, n] or [n]; complex64 (CF32) or int32 words (CF16).
+        S32 plans: a decimator takes int32 wire words [.., n, 2] (I, Q) and returns complex64; an
+        interpolator takes complex64 and returns int32 wire words [.., n_out, 2]."""
+        import torch
+        if self.fmt == S32:
+            if self.mode == DECIMATE:
+                xc = torch.view_as_complex(x.view(torch.float32))          # same 8 bytes per sample
+                return self._process(xc, out, torch.complex64)
+            y = self._process(x, None if out is None else torch.view_as_complex(out.view(torch.float32)),
+                              torch.complex64)
+            return torch.view_as_real(y).view(torch.int32)
+        return self._process(x, out, x.dtype)
+
+    def _process(self, x, out, out_dtype):
         import torch
         squeeze = x.dim() == 1
         x2 = x.unsqueeze(0) if squeeze else x
@@ -110,7 +126,7 @@ class Resampler:
         n_in = x2.shape[1]
         n_out = self.outputs_for(n_in)
         if out is None:
-            out = torch.empty((self.nchan, n_out), dtype=x2.dtype, device=x2.device)
+            out = torch.empty((self.nchan, n_out), dtype=out_dtype, device=x2.device)
         o2 = out.unsqueeze(0) if out.dim() == 1 else out
         got = self.process_ptr(x2.data_ptr(), n_in, x2.stride(0) if self.nchan > 1 else n_in, o2.data_ptr(),
                                o2.stride(0) if self.nchan > 1 else max(n_out, 1),

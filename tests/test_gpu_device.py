@@ -374,3 +374,31 @@ def test_control_surface_register_shadow(oracle):
     with pytest.raises(RuntimeError, match="Invalid register address"):
         dev.writeRegisters("", 0x7E, [1, 2, 3])
     dev.writeSetting("PA", "AUTO")
+
+
+def test_s32_wire_mode(oracle):
+    """Device arg wire=s32: the synthetic chip side speaks the reference's S32_LE I2S words; what the
+    application sees through readStream is unchanged (the source words convert back exactly) and the
+    synthetic DAC holds convert_tx_buffer words with the keying bits."""
+    dev = make(wire="s32")
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"threshold": "0.05"})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    ref = rx_reference(oracle, 4, 2048)
+    buf = np.zeros(1024, dtype=np.complex64)
+    sent = np.zeros(2048, dtype=np.complex64)
+    for i in range(2):
+        assert dev.readStream(rx, [buf], 1024).ret == 1024
+        assert_bit_exact(buf, ref[1024 * i:1024 * (i + 1)], "s32 wire rx block %d" % i)
+        assert dev.writeStream(tx, [buf], 1024).ret == 1024
+        sent[1024 * i:1024 * (i + 1)] = buf
+    L = int(dev.readSetting("TX_INTERP"))
+    start = int(dev.readSetting("TX_POSITION")) - 2048          # first write began after the startup underrun skip
+    stream = np.zeros(start + 2048, dtype=np.complex64)
+    stream[start:] = sent
+    words = dev.txCapture(0, len(stream) * L).view(np.int32)
+    thr2 = np.float32(0.05) * np.float32(0.05)
+    assert np.array_equal(words, oracle.convert_tx(tx_reference(oracle, L, stream), thr2))
+    keyed = (words[0::2] & 3) == 3
+    assert keyed.any() and not keyed[: (start - 40) * L].any()

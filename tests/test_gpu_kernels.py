@@ -168,3 +168,46 @@ def test_cf16_tiled_decimators(oracle, D, n_in):
     yg = gen.process(words.clone())
     _sync()
     assert np.array_equal(to_cpu(yg).view(np.uint16), want)
+
+
+def test_s32_wire_front_and_back_end(oracle):
+    """f-3: the reference's S32_LE I2S wire format fused into the resampling kernels.  RX: the decimator
+    reads wire words (convert_rx_buffer, SX.cpp:103-112, inside the kernel); TX: the interpolator writes
+    wire words with the keying bits (convert_tx_buffer, SX.cpp:116-137).  Bit-exact against the oracle's
+    composition, tiled and generic kernels."""
+    import torch
+    from sxxcvr_amd.resampler import KERNEL_GENERIC, KERNEL_TILED
+    rng = np.random.default_rng(11)
+    n = (1 << 16) + 4 * 33
+    words = rng.integers(-2 ** 31, 2 ** 31, size=2 * (n + 4096), dtype=np.int64).astype(np.int32)
+    words[:8] = [2 ** 31 - 1, -2 ** 31, 1, -1, 0, 0x7FFFFF80, 3, -4]
+    x = oracle.convert_rx(words)
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    ref = oracle.decim_f32(h, 4, x, 2, 4)
+    for kern in (KERNEL_TILED, KERNEL_GENERIC):
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, fmt="S32")
+        plan.set_kernel(kern)
+        wg = to_gpu(words.reshape(-1, 2))
+        y1 = to_cpu(plan.process(wg[:n].clone()))
+        y2 = to_cpu(plan.process(wg[n:].clone()))
+        assert_bit_exact(np.concatenate([y1, y2]), ref, "S32 decimator kernel %d" % kern)
+    # synthetic source as wire words == the CF32 source
+    s32 = torch.empty((5000, 2), dtype=torch.int32, device="cuda")
+    sxxcvr_amd.synth_fill(torch.view_as_complex(s32.view(torch.float32)), SEED, 3, 100, fmt="S32")
+    _sync()
+    assert_bit_exact(oracle.convert_rx(to_cpu(s32).ravel()), oracle.synth_iq(SEED, 3, 100, 5000), "S32 synthetic source")
+    # TX back end
+    L = 8
+    ht = sxxcvr_amd.design_lowpass(32 * L, L, 8.0, float(L))
+    xt = (oracle.synth_iq(SEED, 21, 0, 5000) * np.float32(1.3)).astype(np.complex64)     # some samples clip
+    xt[100:200] *= np.float32(1e-4)                                                     # some fall below the threshold
+    thr2 = np.float32(1e-3) * np.float32(1e-3)
+    want = oracle.convert_tx(oracle.interp_f32(ht, L, xt, 2), thr2)
+    for kern in (KERNEL_TILED, KERNEL_GENERIC):
+        plan = sxxcvr_amd.Resampler(INTERPOLATE, ht, L, fmt="S32")
+        plan.set_kernel(kern)
+        plan.set_tx_threshold(float(thr2))
+        got = to_cpu(plan.process(to_gpu(xt))).ravel()
+        assert np.array_equal(got, want), "S32 interpolator kernel %d" % kern
+    keyed = (want[0::2] & 3) == 3
+    assert keyed.any() and (~keyed).any()
