@@ -42,6 +42,7 @@
 #include <string>
 
 #include "GpuChains.hpp"
+#include "Sx1255Shadow.hpp"
 #include "SynthPcm.hpp"
 
 const char *SoapySXHip_tag = "sx-mi355x";
@@ -56,26 +57,6 @@ struct sampleRateDiv {
 // The six SX1255 I2S rates the reference supports (SoapySX.cpp:196-208).
 const sampleRateDiv sample_rates[] = {{1536}, {768}, {512}, {256}, {128}, {64}};
 const size_t N_SAMPLE_RATES = sizeof(sample_rates) / sizeof(sample_rates[0]);
-
-// SX1255 register shadow: 0x00-0x13 start from the values the reference writes at start-up
-// (datasheet defaults, 433.92 MHz, narrow RX filters, I2S dividers; SoapySX.cpp:145-176).
-const unsigned MAX_REGS = 0x80;
-const uint8_t init_registers[0x14] = {
-    0x01, 0xD8, 0xF5, 0xC3, 0xD8, 0xF5, 0xC3, 0x11, 0x2E, 0x24,
-    0x30, 0x02, 0x3F, 0x3B, 0x06, 0x00, 0x02, 0x00, 0x22, 0x2C,
-};
-
-// Clamp to the range, offset to its minimum, scale by its step, round (SoapySX.cpp:50-63).
-int32_t scale_from_range(SoapySDR::Range range, double value)
-{
-    return (int)std::round((std::min(std::max(value, range.minimum()), range.maximum()) - range.minimum()) /
-                           range.step());
-}
-
-double scale_to_range(SoapySDR::Range range, int32_t value)
-{
-    return std::min(std::max(range.minimum() + range.step() * (double)value, range.minimum()), range.maximum());
-}
 
 int pcm_error_to_soapy_rx(int err) { return err == -EPIPE ? SOAPY_SDR_OVERFLOW : SOAPY_SDR_STREAM_ERROR; }
 int pcm_error_to_soapy_tx(int err) { return err == -EPIPE ? SOAPY_SDR_UNDERFLOW : SOAPY_SDR_STREAM_ERROR; }
@@ -107,31 +88,7 @@ private:
     std::unique_ptr<sx::RxChain> rx_chain;
     std::unique_ptr<sx::TxChain> tx_chain;
     int64_t tx_ptt_samples;     // written samples at or above the TX threshold (PTT bit of :132-133)
-
-    // Values of the SX1255 registers as the reference would have written them (SoapySX.cpp:546-550);
-    // there is no chip behind them here.
-    uint8_t regs[MAX_REGS];
-
-    void set_register_bits(size_t address, unsigned lowestbit, unsigned nbits, unsigned value)
-    {
-        if (address >= MAX_REGS) throw std::runtime_error("Invalid register address");
-        const unsigned mask = ((1u << nbits) - 1) << lowestbit;
-        regs[address] = (uint8_t)((regs[address] & (~mask)) | ((value << lowestbit) & mask));
-    }
-
-    unsigned get_cached_register_bits(size_t address, unsigned lowestbit, unsigned nbits) const
-    {
-        if (address >= MAX_REGS) throw std::runtime_error("Invalid register address");
-        const unsigned mask = ((1u << nbits) - 1) << lowestbit;
-        return (regs[address] & mask) >> lowestbit;
-    }
-
-    // bounds rule of write_registers_to_chip (SoapySX.cpp:596-597); the SPI burst itself is gone
-    void check_register_range(size_t firstreg, size_t nregs) const
-    {
-        if ((firstreg >= MAX_REGS) || (nregs > MAX_REGS) || (firstreg > MAX_REGS - nregs))
-            throw std::runtime_error("Invalid register address");
-    }
+    sx::Sx1255Shadow chip;      // RF front-end control surface: register values only, no SPI
 
     int64_t timestamp_to_samples(long long timestamp) const { return SoapySDR::timeNsToTicks(timestamp, sampleRate); }
     long long samples_to_timestamp(int64_t samples) const { return SoapySDR::ticksToTimeNs(samples, sampleRate); }
@@ -160,7 +117,8 @@ public:
           taps_per_phase(std::stoi(arg(args, "taps_per_phase", "32"))),
           seed(std::stoull(arg(args, "seed", "0x51255"), nullptr, 0)),
           wire_s32(arg(args, "wire", "cf32") == "s32"),
-          tx_ptt_samples(0)
+          tx_ptt_samples(0),
+          chip(masterClock)
     {
         SoapySDR_logf(SOAPY_SDR_INFO, "Initializing SoapySX (MI355X synthetic-IQ build)");
         if (masterClock != 32.0e6 && masterClock != 38.4e6)
@@ -169,11 +127,6 @@ public:
         int ndev = 0;
         if (sxfir_device_count(&ndev) != SXFIR_OK || ndev < 1)
             throw std::runtime_error(std::string("No MI355X visible: ") + sxfir_last_error());
-        for (unsigned i = 0; i < MAX_REGS; ++i) regs[i] = 0;
-        for (unsigned i = 0; i < sizeof(init_registers); ++i) regs[i] = init_registers[i];   // init_chip, :620-627
-        set_register_bits(0, 1, 3, 0b111);
-        setFrequency(SOAPY_SDR_RX, 0, 433.92e6, {});   // :663-664
-        setFrequency(SOAPY_SDR_TX, 0, 433.92e6, {});
         rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, 0, wire_s32));
         tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, wire_s32));
     }
@@ -490,107 +443,55 @@ public:
     }
 
     /*******************************************************************
-     * RF front-end control surface on the register shadow (SoapySX.cpp:1225-1561)
+     * RF front-end control surface (SoapySX.cpp:1225-1561) on the register
+     * shadow: same registers and bit fields, no SPI traffic (Sx1255Shadow.hpp)
      ******************************************************************/
 
-    void setFrequency(const int direction, const size_t channel, const double frequency, const SoapySDR::Kwargs &args)
-    {
-        (void)channel; (void)args;
-        std::scoped_lock lock(reg_mutex);
-        // 24-bit tuning word in steps of masterClock / 2^20
-        const double step = masterClock * (1.0 / (double)(1L << 20));
-        const uint32_t quantized =
-            (uint32_t)scale_from_range(SoapySDR::Range(0, step * (double)((1L << 24) - 1), step), frequency);
-        const size_t base = direction == SOAPY_SDR_RX ? 0x01 : 0x04;
-        set_register_bits(base, 0, 8, quantized >> 16);
-        set_register_bits(base + 1, 0, 8, (quantized >> 8) & 0xFF);
-        set_register_bits(base + 2, 0, 8, quantized & 0xFF);
-    }
-
-    double getFrequency(const int direction, const size_t channel) const
-    {
-        (void)channel;
-        std::scoped_lock lock(reg_mutex);
-        const double step = masterClock * (1.0 / (double)(1L << 20));
-        const size_t base = direction == SOAPY_SDR_RX ? 0x01 : 0x04;
-        return step * ((((uint32_t)regs[base]) << 16) | (((uint32_t)regs[base + 1]) << 8) | ((uint32_t)regs[base + 2]));
-    }
-
-    std::vector<std::string> listGains(const int direction, const size_t channel) const
-    {
-        (void)channel;
-        if (direction == SOAPY_SDR_RX) return {"LNA", "PGA"};
-        return {"DAC", "MIXER"};
-    }
-
-    SoapySDR::Range getGainRange(const int direction, const size_t channel, const std::string &name) const
-    {
-        (void)channel;
-        if (direction == SOAPY_SDR_RX) {
-            if (name == "LNA") return {0.0, 48.0, 6.0};
-            if (name == "PGA") return {0.0, 30.0, 2.0};
-        } else {
-            if (name == "DAC") return {0.0, 9.0, 3.0};
-            if (name == "MIXER") return {0.0, 30.0, 2.0};
-        }
-        return {0, 0, 0};
-    }
-
-    void setGain(const int direction, const size_t channel, const std::string &name, const double value)
+    void setFrequency(const int direction, const size_t, const double frequency, const SoapySDR::Kwargs &)
     {
         std::scoped_lock lock(reg_mutex);
-        const int32_t quantized = scale_from_range(getGainRange(direction, channel, name), value);
-        if (direction == SOAPY_SDR_RX) {
-            if (name == "LNA") {
-                // the LNA field is not linear in dB (:1320-1327)
-                if (quantized <= 6) set_register_bits(0x0C, 5, 3, 6 - quantized / 2);
-                else if (quantized == 7) set_register_bits(0x0C, 5, 3, 2);
-                else set_register_bits(0x0C, 5, 3, 1);
-            } else if (name == "PGA") {
-                set_register_bits(0x0C, 1, 4, quantized);
-            }
-        } else {
-            if (name == "DAC") set_register_bits(0x08, 4, 3, quantized);
-            else if (name == "MIXER") set_register_bits(0x08, 0, 4, quantized);
-        }
+        chip.tune(direction == SOAPY_SDR_RX, frequency);
     }
 
-    double getGain(const int direction, const size_t channel, const std::string &name) const
+    double getFrequency(const int direction, const size_t) const
     {
         std::scoped_lock lock(reg_mutex);
-        int32_t quantized = 0;
-        if (direction == SOAPY_SDR_RX) {
-            if (name == "LNA") {
-                const int32_t map[8] = {0, 8, 7, 6, 4, 2, 0, 0};
-                quantized = map[get_cached_register_bits(0x0C, 5, 3)];
-            } else if (name == "PGA") {
-                quantized = get_cached_register_bits(0x0C, 1, 4);
-            }
-        } else {
-            if (name == "DAC") quantized = get_cached_register_bits(0x08, 4, 3);
-            else if (name == "MIXER") quantized = get_cached_register_bits(0x08, 0, 4);
-        }
-        return scale_to_range(getGainRange(direction, channel, name), quantized);
+        return chip.tuned(direction == SOAPY_SDR_RX);
     }
 
-    // Overall gain: coarse element first, the finer one takes the rest (:1370-1394).
-    void setGain(const int direction, const size_t channel, const double value)
+    std::vector<std::string> listGains(const int direction, const size_t) const
+    {
+        std::vector<std::string> names;
+        for (const auto &e : sx::Sx1255Shadow::elements())
+            if (e.rx == (direction == SOAPY_SDR_RX)) names.push_back(e.name);
+        return names;
+    }
+
+    SoapySDR::Range getGainRange(const int direction, const size_t, const std::string &name) const
+    {
+        const auto *e = sx::Sx1255Shadow::find(direction == SOAPY_SDR_RX, name);
+        return e ? SoapySDR::Range(e->lo, e->hi, e->step) : SoapySDR::Range(0, 0, 0);
+    }
+
+    void setGain(const int direction, const size_t, const std::string &name, const double value)
     {
         std::scoped_lock lock(reg_mutex);
-        if (direction == SOAPY_SDR_RX) {
-            const double pga_gain_target = 12.0;
-            setGain(direction, channel, "LNA", value - pga_gain_target);
-            const double lna_gain = getGain(direction, channel, "LNA");
-            setGain(direction, channel, "PGA", value - lna_gain);
-        } else {
-            const double mixer_gain_target = 26.0;
-            setGain(direction, channel, "DAC", value - mixer_gain_target);
-            const double dac_gain = getGain(direction, channel, "DAC");
-            setGain(direction, channel, "MIXER", value - dac_gain);
-        }
+        chip.set_gain(direction == SOAPY_SDR_RX, name, value);
     }
 
-    // SoapySDR's default overall getGain: the sum of the elements
+    double getGain(const int direction, const size_t, const std::string &name) const
+    {
+        std::scoped_lock lock(reg_mutex);
+        return chip.gain(direction == SOAPY_SDR_RX, name);
+    }
+
+    void setGain(const int direction, const size_t, const double value)
+    {
+        std::scoped_lock lock(reg_mutex);
+        chip.set_overall_gain(direction == SOAPY_SDR_RX, value);
+    }
+
+    // SoapySDR's default for the overall gain: the sum of the elements
     double getGain(const int direction, const size_t channel) const
     {
         double total = 0.0;
@@ -598,70 +499,42 @@ public:
         return total;
     }
 
-    std::vector<std::string> listAntennas(const int direction, const size_t channel) const
+    std::vector<std::string> listAntennas(const int direction, const size_t) const
     {
-        (void)channel;
+        // digital loop-back ("DLB") can be selected but is not advertised, as in the reference (:1407-1408)
         if (direction == SOAPY_SDR_RX) return {"RX", "LB"};
         return {"TX", "NONE"};
     }
 
-    void setAntenna(const int direction, const size_t channel, const std::string &name)
+    void setAntenna(const int direction, const size_t, const std::string &name)
     {
-        (void)channel;
         std::scoped_lock lock(reg_mutex);
-        if (direction == SOAPY_SDR_RX) {
-            if (name == "RX") set_register_bits(0x10, 2, 2, 0);
-            else if (name == "LB") set_register_bits(0x10, 2, 2, 1);
-            else if (name == "DLB") set_register_bits(0x10, 2, 2, 3);
-        } else {
-            if (name == "TX") set_register_bits(0x00, 3, 1, 1);
-            else if (name == "NONE") set_register_bits(0x00, 3, 1, 0);
-        }
+        chip.set_antenna(direction == SOAPY_SDR_RX, name);
     }
 
-    std::string getAntenna(const int direction, const size_t channel) const
+    std::string getAntenna(const int direction, const size_t) const
     {
-        (void)channel;
         std::scoped_lock lock(reg_mutex);
-        if (direction == SOAPY_SDR_RX) {
-            const unsigned lb = get_cached_register_bits(0x10, 2, 2);
-            if (lb & 2) return "DLB";
-            if (lb & 1) return "LB";
-            return "RX";
-        }
-        return get_cached_register_bits(0x00, 3, 1) ? "TX" : "NONE";
+        return chip.antenna(direction == SOAPY_SDR_RX);
     }
 
-    // Raw register access: reads come from the shadow (on the HAT they come from the chip);
-    // 0x11 reports both PLLs locked, which is what the start-up code polls for (:635-636).
-    std::vector<unsigned> readRegisters(const std::string &name, const unsigned addr, const size_t length) const
+    std::vector<unsigned> readRegisters(const std::string &, const unsigned addr, const size_t length) const
     {
-        (void)name;
         std::scoped_lock lock(reg_mutex);
-        std::vector<unsigned> result(length, 0);
-        for (size_t i = 0; i < length; i++) {
-            const size_t r = (addr + i) & (MAX_REGS - 1);   // the SPI address counter is 7 bits wide
-            result[i] = r == 0x11 ? 3u : regs[r];
-        }
-        return result;
+        return chip.read(addr, length);
     }
 
     unsigned readRegister(const std::string &name, const unsigned addr) const { return readRegisters(name, addr, 1).at(0); }
 
-    void writeRegisters(const std::string &name, const unsigned addr, const std::vector<unsigned> &value)
+    void writeRegisters(const std::string &, const unsigned addr, const std::vector<unsigned> &value)
     {
-        (void)name;
         std::scoped_lock lock(reg_mutex);
-        for (size_t i = 0; i < value.size(); i++) set_register_bits(addr + i, 0, 8, value[i]);
-        check_register_range(addr, value.size());
+        chip.write(addr, value);
     }
 
     void writeRegister(const std::string &name, const unsigned addr, const unsigned value)
     {
-        (void)name;
-        std::scoped_lock lock(reg_mutex);
-        set_register_bits(addr, 0, 8, value);
-        check_register_range(addr, 1);
+        writeRegisters(name, addr, std::vector<unsigned>{value});
     }
 
     /*******************************************************************
