@@ -201,3 +201,36 @@ def test_multi_column_multichannel(oracle):
     y = _run(plan, x)
     for c in range(nchan):
         assert_bit_exact(y[c], oracle.decim_f32(h, D, x[c], 2, 4), "multi channel %d" % c)
+
+
+def test_unaligned_and_odd_stride_inputs(oracle, taps):
+    """Inputs that are only 8-byte aligned or have an odd channel stride: the tile kernel takes them
+    (LDS-DMA sources need no 16-byte alignment); a misaligned OUTPUT routes to the generic kernel."""
+    import torch
+    h = taps["n128_d4"]
+    n = 30000
+    x = oracle.synth_iq(SEED, 6, 0, n + 1)
+    xg = to_gpu(x)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4)
+    y = plan.process(xg[1:])                                   # data_ptr is 8 bytes off a 16-byte boundary
+    torch.cuda.synchronize()
+    assert_bit_exact(to_cpu(y), oracle.decim_f32(h, 4, x[1:], 2, 4), "unaligned input")
+    p2 = sxxcvr_amd.Resampler(DECIMATE, h, 4)
+    p2.set_kernel(KERNEL_TILED)
+    assert_bit_exact(to_cpu(p2.process(xg[1:])), oracle.decim_f32(h, 4, x[1:], 2, 4), "unaligned input, tile kernel")
+    out = torch.empty(n // 4 + 1, dtype=torch.complex64, device="cuda")
+    p3 = sxxcvr_amd.Resampler(DECIMATE, h, 4)
+    assert_bit_exact(to_cpu(p3.process(xg[1:], out=out[1:])), oracle.decim_f32(h, 4, x[1:], 2, 4), "unaligned output")
+    with pytest.raises(sxxcvr_amd.NativeError):
+        p4 = sxxcvr_amd.Resampler(DECIMATE, h, 4)
+        p4.set_kernel(KERNEL_TILED)
+        p4.process(xg[1:], out=out[1:])                        # forcing the tile kernel on a misaligned output is refused
+    # two channels, odd stride
+    buf = torch.zeros((2, n + 1), dtype=torch.complex64, device="cuda")
+    xs = np.stack([oracle.synth_iq(SEED, 30 + c, 0, n) for c in range(2)])
+    buf[:, :n] = to_gpu(xs)
+    plan2 = sxxcvr_amd.Resampler(DECIMATE, h, 4, nchan=2)
+    y2 = plan2.process(buf[:, :n])
+    torch.cuda.synchronize()
+    for c in range(2):
+        assert_bit_exact(to_cpu(y2[c]), oracle.decim_f32(h, 4, xs[c], 2, 4), "odd stride channel %d" % c)
