@@ -63,6 +63,10 @@ public:
         }
     }
 
+    // RX and TX may be driven from different threads (per-stream mutexes, SoapySX.cpp:373), but linked
+    // PCMs start and stop each other: those state changes are serialised here.
+    std::recursive_mutex &link_mutex() { return link_; }
+
     // The sample rate changed: keep the count, change the slope.
     void set_rate(double rate)
     {
@@ -85,6 +89,7 @@ private:
     int64_t base_;
     std::chrono::steady_clock::time_point t0_;
     mutable std::mutex m_;
+    std::recursive_mutex link_;
 };
 
 enum stream_mode { STREAM_MODE_NORMAL, STREAM_MODE_LINK };
@@ -112,7 +117,11 @@ public:
     }
 
     bool is_tx() const { return dir == PLAYBACK; }
-    State state() const { return state_; }
+    State state() const
+    {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+        return state_;
+    }
     int64_t appl() const { return appl_; }
 
     void link(SynthPcm *peer)
@@ -137,6 +146,7 @@ public:
     // drop + prepare + reset (SoapySX.cpp:419-432)
     int reset()
     {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
         state_ = PREPARED;
         appl_ = 0;
         hw_frozen_ = 0;
@@ -147,13 +157,18 @@ public:
     // snd_pcm_start; linked PCMs start on the same clock tick
     int start()
     {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
         const int64_t t = clock_->now();
         start_one(t);
         if (peer_) peer_->start_one(t);
         return 0;
     }
 
-    int64_t hw() const { return state_ == RUNNING ? clock_->now() - start_clock_ : hw_frozen_; }
+    int64_t hw() const
+    {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+        return state_ == RUNNING ? clock_->now() - start_clock_ : hw_frozen_;
+    }
 
     // snd_pcm_avail_delay.  Returns 0 or -EPIPE (stopped by an xrun, LINK mode).
     int avail_delay(int64_t *avail, int64_t *delay)
@@ -253,6 +268,7 @@ private:
     // LINK mode only: the ring overflowed (capture) or ran dry (playback).
     void check_xrun()
     {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
         if (state_ != RUNNING || stream_mode != STREAM_MODE_LINK) return;
         const int64_t h = clock_->now() - start_clock_;
         const bool xrun = (dir == CAPTURE) ? (h - appl_ >= (int64_t)hwp_buffer_size) : (appl_ - h <= 0);
