@@ -98,13 +98,21 @@ def main():
     from sxxcvr_amd import dist as sxdist
     from sxxcvr_amd.resampler import DECIMATE
 
-    rank, local_rank, world = sxdist.init_process_group()
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SXFIR_DIST_BACKEND=gloo is a dry-run aid: it lets N ranks share the GPUs that exist (rank -> GPU
+    # local_rank % device_count) and moves the collectives to the host, to exercise this code path on a
+    # 1-GPU box.  The real multi-GPU run uses the default: nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("SXFIR_DIST_BACKEND")
+    host_collectives = backend == "gloo"
+    rank, local_rank, world = sxdist.env_rank()
+    gpu_index = local_rank % torch.cuda.device_count() if host_collectives else local_rank
+    torch.cuda.set_device(gpu_index)
+    rank, local_rank, world = sxdist.init_process_group(backend=backend)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cuda", gpu_index)
+    cdev = torch.device("cpu") if host_collectives else dev
 
     per_gpu = 1 << args.log2_samples
     if world == 1:
@@ -119,7 +127,7 @@ def main():
     assert hi - lo == nchan_local
 
     taps = sxxcvr_amd.design_lowpass(NTAPS, DECIM)
-    plan = sxxcvr_amd.Resampler(DECIMATE, taps, DECIM, nchan=nchan_local, device=local_rank)
+    plan = sxxcvr_amd.Resampler(DECIMATE, taps, DECIM, nchan=nchan_local, device=gpu_index)
     x = torch.empty((nchan_local, n_in), dtype=torch.complex64, device=dev)
     sxxcvr_amd.synth_fill(x, SEED, first_channel=lo, start=0)
     y = torch.empty((nchan_local, n_in // DECIM), dtype=torch.complex64, device=dev)
@@ -145,7 +153,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -160,19 +168,20 @@ def main():
     gather = None
     if world > 1:
         # exchange step of config 4: decimated output of every rank to rank 0 over xGMI
+        yg = y.cpu() if host_collectives else y
         for _ in range(2):
-            sxdist.gather_channels(y, total_channels, dst=0)
+            sxdist.gather_channels(yg, total_channels, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            sxdist.gather_channels(y, total_channels, dst=0)
+            sxdist.gather_channels(yg, total_channels, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         g = (time.perf_counter() - g0) / reps
-        t = torch.tensor([g], dtype=torch.float64, device=dev)
+        t = torch.tensor([g], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         g = float(t.item())
         peer_bytes = y.numel() * 8
@@ -191,7 +200,7 @@ def main():
         value = world * per_gpu * args.steps / elapsed / 1e6
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and world == 1 and args.log2_samples == 28:     # measured for exactly this launch
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:

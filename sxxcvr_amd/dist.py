@@ -36,7 +36,7 @@ def init_process_group(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank)        # one GPU per rank
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
