@@ -154,6 +154,9 @@ int sxfir_stream_sync(void *stream);
 int sxfir_time_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
                         void *out_dev, size_t out_stride, int iters, void *stream, float *ms_per_pass);
 
+/* Diagnostic builds only (SXFIR_ABLATE=11/12): median in-kernel shader clock of the last launch. */
+int sxfir_debug_clock(sxfir_plan *plan, double *mhz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <utility>
 #include <vector>
@@ -59,6 +60,8 @@ struct sxfir_plan {
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
     int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
     int oversub;           // waves launched = CUs * occupancy * oversub
+    void *stamps_dev;      // diagnostic clock stamps (ABLATE 11/12 only)
+    size_t stamps_n;
     float thr2;            // S32 interpolator: transmitter-keying threshold (squared magnitude)
     int sgpr_r;            // experiment: SGPR-tap variant with R outputs per lane (0 = off)
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
@@ -182,6 +185,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->sched = 0;
     p->sgpr_r = 0;
     p->thr2 = 1.0e-3f * 1.0e-3f;
+    p->stamps_dev = nullptr;
+    p->stamps_n = 0;
     // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
     // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
     p->multi_waves = ratio <= 8 ? 1 : (ratio == 16 ? 2 : 4);
@@ -293,6 +298,21 @@ int sxfir_set_tx_threshold(sxfir_plan *p, float tx_threshold2)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
     p->thr2 = tx_threshold2;
+    return SXFIR_OK;
+}
+
+// Diagnostic (SXFIR_ABLATE=11/12 builds): median in-kernel shader clock in MHz of the last launch.
+int sxfir_debug_clock(sxfir_plan *p, double *mhz)
+{
+    if (!p || !mhz || !p->stamps_dev) return fail(SXFIR_EINVAL, "no stamps recorded");
+    std::vector<unsigned long long> h(2 * p->stamps_n);
+    HIPCHECK(hipMemcpy(h.data(), p->stamps_dev, 16 * p->stamps_n, hipMemcpyDeviceToHost));
+    std::vector<double> f;
+    for (size_t i = 0; i < p->stamps_n; ++i)
+        if (h[2 * i + 1] > 0) f.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+    if (f.empty()) return fail(SXFIR_EINVAL, "no stamps recorded");
+    std::sort(f.begin(), f.end());
+    *mhz = f[f.size() / 2];
     return SXFIR_OK;
 }
 
@@ -430,6 +450,13 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.n_waves = (int)per_chan;
         a.sched = p->sched;
+        a.stamps = nullptr;
+        if (p->ablate == 11 || p->ablate == 12) {
+            // diagnostic build: one {cycles, ticks} pair per wave, printed by sxfir_debug_clock()
+            if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 16 * (size_t)per_chan * p->nchan));
+            p->stamps_n = (size_t)per_chan * p->nchan;
+            a.stamps = (unsigned long long *)p->stamps_dev;
+        }
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
         if (p->fmt == SXFIR_S32) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
@@ -441,6 +468,18 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 1>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->ablate == 2) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 2>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 7) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 7>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 11) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 11>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 12) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 12>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 9) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 9>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 10) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 10>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 8) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 8>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->ablate == 3) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 3>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128) {

@@ -47,6 +47,7 @@ struct DecimTileArgs {
     int n_tiles;            // tiles per channel
     int n_waves;            // waves (workgroups) per channel
     int sched;              // 0 = strided passes (XCD-blocked), 1 = one contiguous run per wave
+    unsigned long long *stamps;   // diagnostic builds only (ABL 11/12): per-wave {shader cycles, 100 MHz ticks}
 };
 
 template <int NT>
@@ -195,7 +196,10 @@ __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int t
     store_tile<NT>(c, tile, oi, oq, xbuf);
 }
 
-template <int NT, bool S32IN = false>
+// WORK_DIV / WORK_MODE are profiling knobs (wrong results): WORK_DIV = 2 with mode 0 halves both the
+// LDS reads and the FMAs, mode 1 keeps all LDS reads but halves the FMAs, mode 2 halves the LDS reads
+// and keeps all FMAs (every chunk used twice).
+template <int NT, bool S32IN = false, int WORK_DIV = 1, int WORK_MODE = 0>
 __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,
                                              const float (&h)[NT / 2], f32x4 *xbuf)
 {
@@ -207,8 +211,15 @@ __device__ __forceinline__ void compute_tile(const DecimTileCtx<NT> &c, int tile
     for (int i = 0; i < C::R; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
 
 #pragma unroll
-    for (int t = 0; t < C::WCH; ++t) {
-        f32x4 v = win[t + (t >> 4)];
+    for (int t = 0; t < (WORK_MODE == 0 ? C::WCH / WORK_DIV : C::WCH); ++t) {
+        if constexpr (WORK_MODE == 1) {
+            if (t % WORK_DIV != 0) {                    // read but do not use
+                const f32x4 dead = win[t + (t >> 4)];
+                asm volatile("" ::"v"(dead.x), "v"(dead.y), "v"(dead.z), "v"(dead.w));
+                continue;
+            }
+        }
+        f32x4 v = win[WORK_MODE == 2 ? (t / WORK_DIV) * WORK_DIV + ((t / WORK_DIV) * WORK_DIV >> 4) : t + (t >> 4)];
         if constexpr (S32IN) {
             // S32_LE wire words (convert_rx_buffer, SoapySX.cpp:103-112): only the int->float conversion
             // happens here; the exact 2^-31 scale is folded into the taps by the caller, which gives the
@@ -323,12 +334,25 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     if (last >= tile_begin && last < tile_end && (last - tile_begin) % tile_step == 0)
         write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
 
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if constexpr (ABL == 11 || ABL == 12) {
+        st_c0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     if constexpr (!DBUF) {
         for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
-            if constexpr (ABL != 2) stage_tile<NT>(c, tile, lds);
+            if constexpr (ABL != 2 && ABL != 12) stage_tile<NT>(c, tile, lds);
             // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
             SXFIR_WAIT_VMCNT(0);
-            if constexpr (ABL == 3) {
+            if constexpr (ABL == 7) {
+                compute_tile<NT, false, 2>(c, tile, win0, h, lds);      // half the FMAs and LDS reads
+            } else if constexpr (ABL == 8) {
+                compute_tile<NT, false, 4>(c, tile, win0, h, lds);      // a quarter
+            } else if constexpr (ABL == 9) {
+                compute_tile<NT, false, 2, 1>(c, tile, win0, h, lds);   // all LDS reads, half the FMAs
+            } else if constexpr (ABL == 10) {
+                compute_tile<NT, false, 2, 2>(c, tile, win0, h, lds);   // half the LDS reads, all FMAs
+            } else if constexpr (ABL == 3) {
                 compute_tile_pk<NT>(c, tile, win0, h, lds);
             } else if constexpr (ABL != 1) {
                 compute_tile<NT, S32IN>(c, tile, win0, h, lds);
@@ -340,6 +364,15 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
                     *reinterpret_cast<f32x4 *>(dst) = v0 + h[0];
                     *reinterpret_cast<f32x4 *>(dst + 4) = v1 + h[63 % C::TPL];
                 }
+            }
+        }
+        if constexpr (ABL == 11 || ABL == 12) {
+            // in-kernel clock = shader cycles / (100 MHz ticks / 100 MHz); stamp values go only to a
+            // buffer nothing else reads
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            if (c.lane == 0 && a.stamps) {
+                a.stamps[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)] = c1 - st_c0;
+                a.stamps[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = r1 - st_r0;
             }
         }
     } else {

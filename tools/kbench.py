@@ -44,6 +44,12 @@ for r in range(rounds):
             chk = torch.view_as_real(y).view(torch.int32).sum(dtype=torch.int64).item()
             if ref is None: ref = chk
             print("config", c, "checksum", "same" if chk == ref else "DIFFERENT")
+import ctypes as C
+for c, p in zip(configs, plans):
+    if c[3] in (11, 12):
+        mhz = C.c_double()
+        if p._lib.sxfir_debug_clock(p._plan, C.byref(mhz)) == 0:
+            print("config %s in-kernel shader clock (median over waves): %.0f MHz" % (c, mhz.value))
 for c in configs:
     a = np.array(res[c])
     gbs = (8.0 + 8.0 / D) * (1 << log2n) / (a * 1e-3) / 1e9
