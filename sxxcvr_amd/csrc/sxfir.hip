@@ -16,6 +16,13 @@
 
 #include "sxfir_decim_tile.hip.h"
 #include "sxfir_decim_multi.hip.h"
+
+// Instantiated (ratio, waves per workgroup, CF16) variants of the multi-column decimator: one list for
+// the occupancy query in sxfir_create and the launch in launch_decim.
+#define SXFIR_MULTI_VARIANTS(X) \
+    X(4, 1, false) X(4, 4, false) X(8, 1, false) X(8, 2, false) X(8, 4, false) X(16, 2, false) X(16, 4, false) \
+    X(32, 4, false) X(32, 8, false) \
+    X(4, 1, true) X(8, 1, true) X(8, 2, true) X(16, 2, true) X(16, 4, true) X(32, 4, true) X(32, 8, true)
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_sgpr.hip.h"
 #include "sxfir_kernels.hip.h"
@@ -187,9 +194,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->thr2 = 1.0e-3f * 1.0e-3f;
     p->stamps_dev = nullptr;
     p->stamps_n = 0;
-    // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D): one wave
-    // per tile at D = 8, four at D = 32 where the 31-row halo is otherwise a quarter of the staging
-    p->multi_waves = ratio <= 8 ? 1 : (ratio == 16 ? 2 : 4);
+    // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D, specs "w1".."w8"):
+    // the choice that brings the LDS image down to 10 KiB per wave (16 waves per CU) while the 31-row
+    // halo stays a small part of the staging
+    p->multi_waves = ratio <= 4 ? 1 : (ratio == 8 ? 2 : 4);
     if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
         if (strcmp(v, "mu") == 0 && mode == SXFIR_DECIMATE && fmt == SXFIR_CF32 && ratio == 4 && ntaps == 128) {
             p->multi_capable = true;        // A/B: the multi-column kernel at D = 4 instead of decim4_tile_kernel
@@ -204,22 +212,18 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         const void *k = nullptr;
         switch ((fmt == SXFIR_CF16 ? 10000 : 0) + ratio * 100 + W) {
-        case 401: k = (const void *)sxfir::decim_multi_kernel<4, 1, false>; break;
-        case 404: k = (const void *)sxfir::decim_multi_kernel<4, 4, false>; break;
-        case 801: k = (const void *)sxfir::decim_multi_kernel<8, 1, false>; break;
-        case 804: k = (const void *)sxfir::decim_multi_kernel<8, 4, false>; break;
-        case 1602: k = (const void *)sxfir::decim_multi_kernel<16, 2, false>; break;
-        case 3204: k = (const void *)sxfir::decim_multi_kernel<32, 4, false>; break;
-        case 3208: k = (const void *)sxfir::decim_multi_kernel<32, 8, false>; break;
-        case 10401: k = (const void *)sxfir::decim_multi_kernel<4, 1, true>; break;
-        case 10801: k = (const void *)sxfir::decim_multi_kernel<8, 1, true>; break;
-        case 11602: k = (const void *)sxfir::decim_multi_kernel<16, 2, true>; break;
-        case 13204: k = (const void *)sxfir::decim_multi_kernel<32, 4, true>; break;
-        case 13208: k = (const void *)sxfir::decim_multi_kernel<32, 8, true>; break;
+#define SXFIR_X(DD, WW, HH) \
+        case (HH ? 10000 : 0) + DD * 100 + WW: k = (const void *)sxfir::decim_multi_kernel<DD, WW, HH>; break;
+            SXFIR_MULTI_VARIANTS(SXFIR_X)
+#undef SXFIR_X
         }
-        if (k && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0)
-            p->occ_multi = nb;
+        if (!k) {
+            delete p;
+            return fail(SXFIR_EUNSUPPORTED, "no multi-column kernel for ratio %d with %d waves per workgroup", ratio, W);
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0) p->occ_multi = nb;
         if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
+        if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
     }
     if (p->tile_capable) {
         int nb = 0;
@@ -398,25 +402,20 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
-#define SXFIR_LAUNCH_MULTI(DD, WW, HH) \
-        hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH>), grid, dim3(64 * WW), 0, st, a)
-        const int key = (p->fmt == SXFIR_CF16 ? 10000 : 0) + p->ratio * 100 + W;
+        const int key = (p->fmt == SXFIR_CF16 ? 10000 : 0) + p->ratio * 100 + W + 100000 * p->ablate;
         switch (key) {
-        case 401: SXFIR_LAUNCH_MULTI(4, 1, false); break;
-        case 404: SXFIR_LAUNCH_MULTI(4, 4, false); break;
-        case 801: SXFIR_LAUNCH_MULTI(8, 1, false); break;
-        case 804: SXFIR_LAUNCH_MULTI(8, 4, false); break;
-        case 1602: SXFIR_LAUNCH_MULTI(16, 2, false); break;
-        case 3204: SXFIR_LAUNCH_MULTI(32, 4, false); break;
-        case 3208: SXFIR_LAUNCH_MULTI(32, 8, false); break;
-        case 10401: SXFIR_LAUNCH_MULTI(4, 1, true); break;
-        case 10801: SXFIR_LAUNCH_MULTI(8, 1, true); break;
-        case 11602: SXFIR_LAUNCH_MULTI(16, 2, true); break;
-        case 13204: SXFIR_LAUNCH_MULTI(32, 4, true); break;
-        case 13208: SXFIR_LAUNCH_MULTI(32, 8, true); break;
+        case 100801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 1>), grid, dim3(64), 0, st, a); break;
+        case 200801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 2>), grid, dim3(64), 0, st, a); break;
+        case 103204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 1>), grid, dim3(256), 0, st, a); break;
+        case 203204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 2>), grid, dim3(256), 0, st, a); break;
+#define SXFIR_X(DD, WW, HH) \
+        case (HH ? 10000 : 0) + DD * 100 + WW: \
+            hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH>), grid, dim3(64 * WW), 0, st, a); \
+            break;
+            SXFIR_MULTI_VARIANTS(SXFIR_X)
+#undef SXFIR_X
         default: return fail(SXFIR_EUNSUPPORTED, "no multi kernel for ratio %d with %d waves", p->ratio, W);
         }
-#undef SXFIR_LAUNCH_MULTI
         HIPCHECK(hipGetLastError());
         *history_done = true;
         return SXFIR_OK;
@@ -482,6 +481,12 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 8>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->ablate == 3) {
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 3>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 17) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 17>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 18) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 18>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate == 19) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 19>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128) {
             if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
             else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);

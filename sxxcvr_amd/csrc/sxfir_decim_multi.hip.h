@@ -98,8 +98,9 @@ __device__ __forceinline__ unsigned pack_half2(float i, float q)
     return *reinterpret_cast<const unsigned *>(&h);
 }
 
-template <int D, int W, bool HALF = false>
-__global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArgs a)
+// ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging
+template <int D, int W, bool HALF = false, int ABL = 0>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) void decim_multi_kernel(const DecimMultiArgs a)
 {
     using C = DecimMulti<D, W, HALF>;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
     // Tile-invariant part of the staging: sample offset (from the tile's first row, sample
     // x[D*(M0-31)]) of the 16-byte piece each of this wave's DMA instructions fetches for this lane.
     constexpr int NIW = (C::NI + W - 1) / W;
-    int poff[NIW];
+    constexpr int PBIAS = 4 * (C::NCOL - 1) + 3;
+    unsigned poff[NIW];
 #pragma unroll
     for (int i0 = 0; i0 < NIW; ++i0) {
         // Issue order: row block kb of every sub-stream before row block kb+1, so the NCOL pieces
@@ -157,14 +159,15 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
         const int cc = C::logical(r);
         // CF32: piece = samples x[D*q - 4c - 3 + 2*half], +1 with q = M0 - 31 + (cc >> 1), half = cc & 1
         // CF16: piece = the whole row x[D*q - 4c - 3 .. D*q - 4c] with q = M0 - 31 + cc
-        poff[i0] = HALF ? D * cc - 4 * cs - 3 : D * (cc >> 1) - 4 * cs - 3 + 2 * (cc & 1);
+        // biased by PBIAS so that it is never negative: the DMA takes it as an unsigned 32-bit offset
+        poff[i0] = (HALF ? D * cc - 4 * cs - 3 : D * (cc >> 1) - 4 * cs - 3 + 2 * (cc & 1)) + PBIAS;
     }
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         // samples of the tile: [D*(M0-32)+1, D*(M0+TILE_OUT-1)]; interior = all inside `in`
         const bool interior = (M0 >= 32) && (D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1);
-        const long long s_base = D * (M0 - 31);
+        const long long s_base = D * (M0 - 31) - PBIAS;
         const char *base = in + C::SBYTES * s_base;
 
         __syncthreads();                                   // everyone is done reading the previous tile
@@ -172,17 +175,21 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
 #pragma unroll
         for (int i0 = 0; i0 < NIW; ++i0) {
             const int o = i0 * W + ww;
-            if (o < C::NI) {
+            if (o < C::NI && ABL != 2) {
                 const int i = (o % C::NCOL) * C::IPS + o / C::NCOL;      // instruction's place in the LDS image
+                // the empty asm keeps the offset a 32-bit value next to its use: the DMA then takes the
+                // SGPR-base + VGPR-offset form and nothing 64-bit is hoisted out of the tile loop
+                unsigned po = poff[i0];
+                asm volatile("" : "+v"(po));
                 if (interior) {
-                    glds16(base + C::SBYTES * poff[i0], lds + 64 * i);
+                    glds16(base + C::SBYTES * po, lds + 64 * i);
                 } else {
                     // edge tiles (first / last of a call): through registers, sample by sample
                     const long long last = a.n_in - 1;
                     unsigned wds[4];
 #pragma unroll
                     for (int e = 0; e < 16 / C::SBYTES; ++e) {
-                        const long long s = s_base + poff[i0] + e;
+                        const long long s = s_base + po + e;
                         const char *src = s >= 0 ? in + C::SBYTES * (s <= last ? s : last)
                                                  : hist + C::SBYTES * (s + C::NT >= 0 ? s + C::NT : 0);
                         if constexpr (HALF) {
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(64 * W) void decim_multi_kernel(const DecimMultiArg
         float ai[8], aq[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
+        if constexpr (ABL != 1)
 #pragma unroll
         for (int t = 0; t < C::WCH; ++t) {
             const f32x4 v = win[t + t / C::PADP];

@@ -91,6 +91,9 @@ struct DecimTileCtx {
     float *out;
     long long n_out, last_chunk;
     int lane, g, p;
+    // byte offset (from the tile's first staged chunk) of the chunk each DMA instruction fetches for
+    // this lane: tile-invariant, 32 bits, so that the DMA uses the SGPR-base + VGPR-offset form
+    unsigned boff[DecimTile4<NT>::NLOAD];
 };
 
 // HBM -> LDS for one tile, no VGPR round trip.  Slot q = 64*i + lane of the
@@ -103,21 +106,21 @@ __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, 
     const long long c0 = ((long long)tile * C::TILE_IN - C::HALO) >> 1;   // first chunk staged (may be < 0)
     const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk);
     if (interior) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(c.in) + c0;
+        const char *src = reinterpret_cast<const char *>(reinterpret_cast<const f32x4 *>(c.in) + c0);
 #pragma unroll
         for (int i = 0; i < C::NLOAD; ++i) {
-            const unsigned q = 64u * i + c.lane;
-            unsigned off = q - (((q + 1u) * 3856u) >> 16);                // (q+1)/17, exact for q < 4096
-            off = off < (unsigned)C::CHUNKS ? off : (unsigned)C::CHUNKS - 1u;
-            glds16(src + off, buf + 64 * i);
+            // the empty asm keeps the 32->64-bit extension next to the load (instruction selection
+            // works per basic block), which is what selects the SGPR-base + 32-bit VGPR offset form
+            unsigned b = c.boff[i];
+            asm volatile("" : "+v"(b));
+            glds16(src + b, buf + 64 * i);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < C::NLOAD; ++i) {
-            const unsigned q = 64u * i + c.lane;
-            unsigned off = q - (((q + 1u) * 3856u) >> 16);
-            off = off < (unsigned)C::CHUNKS ? off : (unsigned)C::CHUNKS - 1u;
-            long long ch = c0 + off;
+            unsigned b = c.boff[i];
+            asm volatile("" : "+v"(b));                  // edge tiles are rare: nothing of this hoisted out of the loop
+            long long ch = c0 + (b >> 4);
             const f32x4 *src;
             if (ch < 0) {
                 src = reinterpret_cast<const f32x4 *>(c.hist) + (ch + C::HIST / 2);
@@ -296,6 +299,13 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     c.out = a.out + 2 * a.out_stride * ch;
     c.n_out = a.n_out;
     c.last_chunk = (a.n_in - 1) >> 1;                 // last input chunk holding a valid sample
+#pragma unroll
+    for (int i = 0; i < C::NLOAD; ++i) {
+        const unsigned q = 64u * i + c.lane;
+        unsigned off = q - (((q + 1u) * 3856u) >> 16);                    // (q+1)/17, exact for q < 4096
+        off = off < (unsigned)C::CHUNKS ? off : (unsigned)C::CHUNKS - 1u;
+        c.boff[i] = 16u * off;
+    }
 
     // taps of this lane's half, h[kl] = taps[TPL*p + kl]
     float h[C::TPL];
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     }
     if constexpr (!DBUF) {
         for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
-            if constexpr (ABL != 2 && ABL != 12) stage_tile<NT>(c, tile, lds);
+            if constexpr (ABL != 2 && ABL != 12 && (ABL < 17 || ABL > 19)) stage_tile<NT>(c, tile, lds);
             // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
             SXFIR_WAIT_VMCNT(0);
             if constexpr (ABL == 7) {
@@ -352,6 +362,12 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
                 compute_tile<NT, false, 2, 1>(c, tile, win0, h, lds);   // all LDS reads, half the FMAs
             } else if constexpr (ABL == 10) {
                 compute_tile<NT, false, 2, 2>(c, tile, win0, h, lds);   // half the LDS reads, all FMAs
+            } else if constexpr (ABL == 17) {
+                compute_tile<NT, false, 2, 2>(c, tile, win0, h, lds);   // no staging, half the LDS reads, all FMAs
+            } else if constexpr (ABL == 18) {
+                compute_tile<NT, false, 2, 1>(c, tile, win0, h, lds);   // no staging, all LDS reads, half the FMAs
+            } else if constexpr (ABL == 19) {
+                compute_tile<NT, false, 8, 2>(c, tile, win0, h, lds);   // no staging, 1/8 of the LDS reads, all FMAs
             } else if constexpr (ABL == 3) {
                 compute_tile_pk<NT>(c, tile, win0, h, lds);
             } else if constexpr (ABL != 1) {

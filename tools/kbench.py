@@ -25,6 +25,8 @@ taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_TILE_VARIANT"] = v
+    if v[0] == "w" and v[1:].isdigit(): os.environ["SXFIR_MULTI_W"] = v[1:]      # "w4": multi kernel with 4 waves per workgroup
+    else: os.environ.pop("SXFIR_MULTI_W", None)
     os.environ["SXFIR_OVERSUB"] = str(ov)
     os.environ["SXFIR_ABLATE"] = str(abl)
     os.environ["SXFIR_SCHED"] = str(sched)
