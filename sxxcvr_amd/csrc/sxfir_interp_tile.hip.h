@@ -96,11 +96,14 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
         // ---- stage samples [q0 - 32, q0 + TILE_IN) ----------------------------
 #pragma unroll
         for (int i = 0; i < C::NLOAD; ++i) {
-            int cc = 64 * i + lane;
-            cc = cc < C::CHUNKS ? cc : C::CHUNKS - 1;
-            const long long s = q0 - 32 + 2 * cc;
+            // chunk index as an opaque 32-bit value: the DMA takes the SGPR-base + VGPR-offset form and no
+            // 64-bit per-lane address is kept across the tile loop
+            unsigned cc = 64 * i + lane;
+            cc = cc < (unsigned)C::CHUNKS ? cc : (unsigned)C::CHUNKS - 1u;
+            asm volatile("" : "+v"(cc));
+            const long long s = q0 - 32 + 2 * (long long)cc;
             if (interior) {
-                glds16(in + 2 * s, lds + 64 * i);
+                glds16(reinterpret_cast<const char *>(in + 2 * (q0 - 32)) + 16u * cc, lds + 64 * i);
             } else {
                 float2 v0, v1;
                 const long long last = a.n_in - 1;

@@ -13,8 +13,11 @@ def run(name, mode, ntaps, ratio, fmt, log2n, kernel=None, gain=1.0):
     x = torch.empty(n, dtype=dt_in, device="cuda"); sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=fmt)
     n_out = n // ratio if mode == DECIMATE else n * ratio
     y = torch.empty(n_out, dtype=dt_in, device="cuda")
-    for _ in range(5): p.process(x, out=y)
-    torch.cuda.synchronize(); iters = 30; t0 = time.perf_counter()
+    # warm up past the clock transient of the first launches ("measurement notes"); the slow
+    # generic kernels get fewer repetitions
+    fast = kernel is None
+    for _ in range(100 if fast else 3): p.process(x, out=y)
+    torch.cuda.synchronize(); iters = 100 if fast else 10; t0 = time.perf_counter()
     for _ in range(iters): p.process(x, out=y)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
     b = 8 if fmt == "CF32" else 4
