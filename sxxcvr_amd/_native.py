@@ -51,6 +51,7 @@ def load_sxfir():
         "sxfir_set_kernel": (ci, [vp, ci]),
         "sxfir_set_tx_threshold": (ci, [vp, C.c_float]),
         "sxfir_debug_clock": (ci, [vp, P(dbl)]),
+        "sxfir_debug_stamps": (ci, [vp, P(C.c_ulonglong), sz, P(sz)]),
         "sxfir_contract": (ci, [vp, P(ci), P(ci)]),
         "sxfir_position": (ci, [vp, P(i64), P(i64)]),
         "sxfir_outputs_for": (ci, [vp, sz, P(sz)]),

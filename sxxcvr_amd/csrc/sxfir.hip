@@ -20,9 +20,14 @@
 // Instantiated (ratio, waves per workgroup, CF16) variants of the multi-column decimator: one list for
 // the occupancy query in sxfir_create and the launch in launch_decim.
 #define SXFIR_MULTI_VARIANTS(X) \
-    X(4, 1, false) X(4, 4, false) X(8, 1, false) X(8, 2, false) X(8, 4, false) X(16, 2, false) X(16, 4, false) \
-    X(32, 4, false) X(32, 8, false) \
-    X(4, 1, true) X(8, 1, true) X(8, 2, true) X(16, 2, true) X(16, 4, true) X(32, 4, true) X(32, 8, true)
+    X(4, 1, false, 2) X(4, 4, false, 2) X(8, 1, false, 2) X(8, 2, false, 2) X(8, 4, false, 2) X(16, 2, false, 2) \
+    X(16, 4, false, 2) X(32, 4, false, 2) X(32, 8, false, 2) \
+    X(4, 1, true, 2) X(8, 1, true, 2) X(8, 2, true, 2) X(16, 2, true, 2) X(16, 4, true, 2) X(32, 4, true, 2) \
+    X(32, 8, true, 2) \
+    X(4, 2, false, 4) X(8, 2, false, 4) X(8, 4, false, 4) X(16, 4, false, 4) X(16, 8, false, 4) X(32, 8, false, 4) \
+    X(32, 16, false, 4) \
+    X(4, 2, true, 4) X(8, 4, true, 4) X(16, 8, true, 4) X(32, 8, true, 4)
+#define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_sgpr.hip.h"
 #include "sxfir_kernels.hip.h"
@@ -63,6 +68,7 @@ struct sxfir_plan {
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
     int multi_waves;       // waves per workgroup of the multi kernel
+    int multi_ps;          // lanes that share the 32 tap rows of one output (2 or 4) in the multi kernel
     int occ_multi;         // resident workgroups per CU of the multi kernel
     bool tile_dbuf;        // double-buffered LDS-DMA variant of the tile kernel
     int occ_sb, occ_db;    // resident waves per CU of the two tile-kernel variants
@@ -198,6 +204,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the choice that brings the LDS image down to 10 KiB per wave (16 waves per CU) while the 31-row
     // halo stays a small part of the staging
     p->multi_waves = ratio <= 4 ? 1 : (ratio == 8 ? 2 : 4);
+    p->multi_ps = 2;
     if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
         if (strcmp(v, "mu") == 0 && mode == SXFIR_DECIMATE && fmt == SXFIR_CF32 && ratio == 4 && ntaps == 128) {
             p->multi_capable = true;        // A/B: the multi-column kernel at D = 4 instead of decim4_tile_kernel
@@ -206,14 +213,17 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     }
     p->occ_multi = 2;
     if (p->multi_capable) {
+        if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
+        if (p->multi_ps == 4) p->multi_waves = ratio <= 4 ? 2 : (ratio == 8 ? 4 : 8);
         if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
+        p->jsplit = p->multi_ps;
         // resident workgroups per CU: LDS is the limiter (checked against the occupancy API below)
         const int W = p->multi_waves;
         int nb = 0;
         const void *k = nullptr;
-        switch ((fmt == SXFIR_CF16 ? 10000 : 0) + ratio * 100 + W) {
-#define SXFIR_X(DD, WW, HH) \
-        case (HH ? 10000 : 0) + DD * 100 + WW: k = (const void *)sxfir::decim_multi_kernel<DD, WW, HH>; break;
+        switch (SXFIR_MULTI_KEY(ratio, W, fmt == SXFIR_CF16, p->multi_ps)) {
+#define SXFIR_X(DD, WW, HH, PP) \
+        case SXFIR_MULTI_KEY(DD, WW, HH, PP): k = (const void *)sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>; break;
             SXFIR_MULTI_VARIANTS(SXFIR_X)
 #undef SXFIR_X
         }
@@ -320,6 +330,15 @@ int sxfir_debug_clock(sxfir_plan *p, double *mhz)
     return SXFIR_OK;
 }
 
+int sxfir_debug_stamps(sxfir_plan *p, unsigned long long *host, size_t capacity_records, size_t *n_records)
+{
+    if (!p || !host || !n_records || !p->stamps_dev || p->ablate != 3) return fail(SXFIR_EINVAL, "no stamps recorded");
+    const size_t n = p->stamps_n < capacity_records ? p->stamps_n : capacity_records;
+    HIPCHECK(hipMemcpy(host, p->stamps_dev, 40 * n, hipMemcpyDeviceToHost));
+    *n_records = n;
+    return SXFIR_OK;
+}
+
 int sxfir_contract(const sxfir_plan *p, int *jsplit, int *cw)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
@@ -393,7 +412,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.out_stride = (long long)out_stride;
         a.hist_stride = p->hist_len;
         const int W = p->multi_waves;
-        const int tile_out = W * 8 * (32 / (p->ratio / 4));
+        const int tile_out = W * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
         const long long n_tiles = (n_out + tile_out - 1) / tile_out;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
         long long groups = ((long long)p->compute_units * p->occ_multi * p->oversub) / p->nchan;
@@ -402,15 +421,29 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
-        const int key = (p->fmt == SXFIR_CF16 ? 10000 : 0) + p->ratio * 100 + W + 100000 * p->ablate;
+        a.stamps = nullptr;
+        if (p->ablate == 3) {
+            const size_t need = (size_t)groups * p->nchan * W;
+            if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
+            if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 40 * need));
+            p->stamps_n = need;
+            a.stamps = (unsigned long long *)p->stamps_dev;
+        }
+        const int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps) + 100000 * p->ablate;
         switch (key) {
         case 100801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 1>), grid, dim3(64), 0, st, a); break;
         case 200801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 2>), grid, dim3(64), 0, st, a); break;
         case 103204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 1>), grid, dim3(256), 0, st, a); break;
         case 203204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 2>), grid, dim3(256), 0, st, a); break;
-#define SXFIR_X(DD, WW, HH) \
-        case (HH ? 10000 : 0) + DD * 100 + WW: \
-            hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH>), grid, dim3(64 * WW), 0, st, a); \
+        case 403204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 4>), grid, dim3(256), 0, st, a); break;
+        case 503204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 5>), grid, dim3(256), 0, st, a); break;
+        case 303204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 3>), grid, dim3(256), 0, st, a); break;
+        case 303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3>), grid, dim3(512), 0, st, a); break;
+        case 1303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3, 4>), grid, dim3(512), 0, st, a); break;
+        case 300802: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 2, false, 3>), grid, dim3(128), 0, st, a); break;
+#define SXFIR_X(DD, WW, HH, PP) \
+        case SXFIR_MULTI_KEY(DD, WW, HH, PP): \
+            hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>), grid, dim3(64 * WW), 0, st, a); \
             break;
             SXFIR_MULTI_VARIANTS(SXFIR_X)
 #undef SXFIR_X

@@ -15,12 +15,14 @@
 // 16-byte piece (half a row) is fetched from wherever it lives; pieces start
 // on odd sample indices (8-byte aligned sources, verified on MI355X).
 //
-// Workgroup = W waves sharing one tile of W*1024 input samples (+ 31 halo
-// rows); every wave owns 1024 of them: lanes = (p, c, g): tap-row half p (lane
-// bit 5), column group c (next lane bits), output group g (8 outputs each).
-// Reduction: v_permlane32_swap over p, v_permlane16_swap over c bit 0, lane
-// xor 8 / xor 4 for c bits 1, 2: the adjacent-pair trees of the numeric
-// contract: first over the two row halves, then over the columns.
+// Workgroup = W waves sharing one tile of W*OW outputs (+ 31 halo rows); every wave owns OW of them:
+// lanes = (p, c, g): tap-row range p (top lane bits), column group c (next lane bits), output group g
+// (8 outputs each).  PS = 2 (shipped): two row halves, 64 taps and 1024 v_fmac per lane and tile.
+// PS = 4 (SXFIR_MULTI_PS=4, measured slower: DESIGN.md): four row quarters, 32 taps and 512 v_fmac, so
+// that twice as many, lighter waves share a tile.
+// Reduction: v_permlane32_swap / v_permlane16_swap over p and c bit 0, lane xor 8 / 4 / 2 for the
+// remaining column bits: the adjacent-pair trees of the numeric contract, first over the
+// row ranges (jsplit = PS), then over the columns (cw = 4).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,15 +44,21 @@ struct DecimMultiArgs {
     long long in_stride, out_stride, hist_stride;
     int n_tiles;            // workgroup tiles per channel
     int n_groups;           // workgroups per channel (strided passes over the tiles)
+    unsigned long long *stamps;   // diagnostic builds only (ABL 3): 5 counters per wave
 };
 
-template <int D, int W, bool HALF = false>
+template <int D, int W, bool HALF = false, int PS = 2>
 struct DecimMulti {
     // HALF: IQ stored as IEEE half pairs (CF16, 4 bytes per sample; BASELINE config 5), fp32
     // arithmetic.  A 16-byte piece is then a whole row (4 samples) instead of half a row.
+    // PS: the 32 tap rows are split over PS lanes (2 or 4); PS = 4 makes a wave half as heavy (32 taps,
+    // 512 v_fmac per lane and tile), so twice as many waves share a tile and hide each other's waits.
     static constexpr int NT = 32 * D;
     static constexpr int NCOL = D / 4;
-    static constexpr int GW = 32 / NCOL;                  // output groups per wave
+    static constexpr int JR = 32 / PS;                    // tap rows per lane
+    static constexpr int TPL = 4 * JR;                    // taps per lane
+    static constexpr int PB = PS == 4 ? 2 : 1;            // lane bits that select the row range
+    static constexpr int GW = 64 / (PS * NCOL);           // output groups per wave
     static constexpr int R = 8;                           // outputs per lane
     static constexpr int OW = GW * R;                     // outputs per wave
     static constexpr int TILE_OUT = W * OW;
@@ -65,8 +73,11 @@ struct DecimMulti {
     static constexpr int SUBSTRIDE = IPS * 64;
     static constexpr int NI = NCOL * IPS;                 // DMA instructions per tile (all waves together)
     static constexpr int LDS_SLOTS = NI * 64;
-    static constexpr int WCH = 23 * CPR;                  // window chunks per lane: 23 rows
+    static constexpr int WROWS = JR + 7;                  // window rows per lane
+    static constexpr int WCH = WROWS * CPR;               // window chunks per lane
     static_assert(D % 4 == 0 && (NCOL & (NCOL - 1)) == 0 && NCOL <= 8, "D must be 4, 8, 16 or 32");
+    static_assert(PS == 2 || PS == 4, "row split of 2 or 4");
+    static_assert(GW >= 1, "a wave holds at least one output group");
     static_assert(SUBSL < 4000, "the multiply-shift divisions below are exact below 4000 only");
     // bank skew per column group so that the 16 lanes of every ds_read_b128 group differ in slot
     static __device__ __forceinline__ int skew(int c)
@@ -98,22 +109,24 @@ __device__ __forceinline__ unsigned pack_half2(float i, float q)
     return *reinterpret_cast<const unsigned *>(&h);
 }
 
-// ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging
-template <int D, int W, bool HALF = false, int ABL = 0>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) void decim_multi_kernel(const DecimMultiArgs a)
+// ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
+// kernel with s_memtime stamps around its phases (a.stamps)
+template <int D, int W, bool HALF = false, int ABL = 0, int PS = 2>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 8))) void decim_multi_kernel(const DecimMultiArgs a)
 {
-    using C = DecimMulti<D, W, HALF>;
+    using C = DecimMulti<D, W, HALF, PS>;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int ww = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane >> 5;
-    // column group: c bit 0 = lane bit 4, c bit 1 = lane bit 3, c bit 2 = lane bit 2
+    // row range: the top PB lane bits (PS = 4: p = 2*bit5 + bit4); column group: the bits below,
+    // c bit 0 highest
+    const int p = lane >> (6 - C::PB);
     int c = 0;
-    if (C::NCOL >= 2) c |= (lane >> 4) & 1;
-    if (C::NCOL >= 4) c |= ((lane >> 3) & 1) << 1;
-    if (C::NCOL >= 8) c |= ((lane >> 2) & 1) << 2;
+    if (C::NCOL >= 2) c |= (lane >> (5 - C::PB)) & 1;
+    if (C::NCOL >= 4) c |= ((lane >> (4 - C::PB)) & 1) << 1;
+    if (C::NCOL >= 8) c |= ((lane >> (3 - C::PB)) & 1) << 2;
     const int g = lane & (C::GW - 1);
     const int ch = blockIdx.y;
 
@@ -122,13 +135,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const char *hist = reinterpret_cast<const char *>(a.hist) + (long long)C::SBYTES * a.hist_stride * ch;
     char *out = reinterpret_cast<char *>(a.out) + (long long)C::SBYTES * a.out_stride * ch;
 
-    // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16p + jj) + 4c + rr
-    float h[64];
+    // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(JR*p + jj) + 4c + rr
+    float h[C::TPL];
 #pragma unroll
-    for (int kl = 0; kl < 64; ++kl) h[kl] = a.taps[D * (16 * p + (kl >> 2)) + 4 * c + (kl & 3)];
+    for (int kl = 0; kl < C::TPL; ++kl) h[kl] = a.taps[D * (C::JR * p + (kl >> 2)) + 4 * c + (kl & 3)];
 
     const int G = ww * C::GW + g;                          // output group inside the workgroup tile
-    const int cc0 = C::PADP * (G - 2 * p + 2);             // first window chunk in the sub-stream (multiple of PADP)
+    // first window row: 8G - JR*p - JR + 1, counted from the tile's first row M0 - 31
+    const int cc0 = C::PADP * (G - (C::JR / 8) * p + 4 - C::JR / 8);   // first window chunk (multiple of PADP)
     const f32x4 *win = lds + (c * C::SUBSTRIDE + C::skew(c) + cc0 + cc0 / C::PADP);
 
     // fused history carry-over: the last wave of the workgroup that owns the last tile copies the
@@ -163,6 +177,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         poff[i0] = (HALF ? D * cc - 4 * cs - 3 : D * (cc >> 1) - 4 * cs - 3 + 2 * (cc & 1)) + PBIAS;
     }
 
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tk = 0;
+    if constexpr (ABL == 3) tk = __builtin_amdgcn_s_memtime();
+#define SXFIR_PHASE(k) \
+    if constexpr (ABL == 3) { \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+        ph[k] += t_now - tk; \
+        tk = t_now; \
+    }
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         // samples of the tile: [D*(M0-32)+1, D*(M0+TILE_OUT-1)]; interior = all inside `in`
@@ -171,6 +193,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const char *base = in + C::SBYTES * s_base;
 
         __syncthreads();                                   // everyone is done reading the previous tile
+        SXFIR_PHASE(4)
         // ---- stage: the W waves share the NI DMA instructions -------------------
 #pragma unroll
         for (int i0 = 0; i0 < NIW; ++i0) {
@@ -181,6 +204,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 // SGPR-base + VGPR-offset form and nothing 64-bit is hoisted out of the tile loop
                 unsigned po = poff[i0];
                 asm volatile("" : "+v"(po));
+                if constexpr (ABL == 4 || ABL == 5) po = 2u * ((64u * o + lane) % 2048u);   // linear sources (wrong data): TA cost probe
                 if (interior) {
                     glds16(base + C::SBYTES * po, lds + 64 * i);
                 } else {
@@ -204,14 +228,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
             }
         }
+        SXFIR_PHASE(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMAs landed ...
         __syncthreads();                                   // ... and everybody else's
+        SXFIR_PHASE(2)
 
-        // ---- compute: window sample w meets output i at local tap kl = 4*i + 63 - w ---
+        // ---- compute: window sample w meets output i at local tap kl = 4*i + TPL - 1 - w ---
         float ai[8], aq[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
-        if constexpr (ABL != 1)
+        if constexpr (ABL != 1 && ABL != 4)
 #pragma unroll
         for (int t = 0; t < C::WCH; ++t) {
             const f32x4 v = win[t + t / C::PADP];
@@ -230,8 +256,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int kl = 4 * i + 63 - w;
-                    if (kl >= 0 && kl < 64) {
+                    const int kl = 4 * i + C::TPL - 1 - w;
+                    if (kl >= 0 && kl < C::TPL) {
                         ai[i] = __builtin_fmaf(h[kl], xi, ai[i]);
                         aq[i] = __builtin_fmaf(h[kl], xq, aq[i]);
                     }
@@ -239,19 +265,36 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
         }
 
-        // ---- reduce over p: outputs 0-3 stay on the low half-wave, 4-7 on the high one
+        if constexpr (ABL == 3) asm volatile("" ::"v"(ai[0]), "v"(aq[7]));   // the arithmetic ends here
+        SXFIR_PHASE(3)
+        // ---- reductions, in the order of the numeric contract: adjacent-pair tree over the row
+        // ranges p, then over the column groups c.  A swap step halves the outputs a lane holds
+        // (v_permlane{16,32}_swap: no LDS); the remaining column bits are butterflies.
         float oi[4], oq[4];
+        if constexpr (PS == 2) {
+            // p = lane bit 5: outputs 0-3 stay on the low half-wave, 4-7 on the high one
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            permlane32_swap(ai[i], ai[i + 4]);
-            permlane32_swap(aq[i], aq[i + 4]);
-            oi[i] = __fadd_rn(ai[i], ai[i + 4]);
-            oq[i] = __fadd_rn(aq[i], aq[i + 4]);
+            for (int i = 0; i < 4; ++i) {
+                permlane32_swap(ai[i], ai[i + 4]);
+                permlane32_swap(aq[i], aq[i + 4]);
+                oi[i] = __fadd_rn(ai[i], ai[i + 4]);
+                oq[i] = __fadd_rn(aq[i], aq[i + 4]);
+            }
+        } else {
+            // p bit 0 = lane bit 4 (ranges 0+1, 2+3): even 16-lane rows keep outputs 0-3, odd rows 4-7
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                permlane16_swap(ai[i], ai[i + 4]);
+                permlane16_swap(aq[i], aq[i + 4]);
+                oi[i] = __fadd_rn(ai[i], ai[i + 4]);
+                oq[i] = __fadd_rn(aq[i], aq[i + 4]);
+            }
         }
-        const long long mw = M0 + (long long)ww * C::OW + 8 * g + 4 * p;
-        if constexpr (C::NCOL == 1) {
-            char *dst = out + C::SBYTES * mw;
-            if (mw + 4 <= a.n_out) {
+        const long long mw = M0 + (long long)ww * C::OW + 8 * g;
+        if constexpr (C::NCOL == 1 && PS == 2) {
+            const long long m = mw + 4 * p;
+            char *dst = out + C::SBYTES * m;
+            if (m + 4 <= a.n_out) {
                 if constexpr (HALF) {
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store((u32x4){pack_half2(oi[0], oq[0]), pack_half2(oi[1], oq[1]),
@@ -264,39 +307,44 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (mw + i < a.n_out) {
+                    if (m + i < a.n_out) {
                         if constexpr (HALF) reinterpret_cast<unsigned *>(dst)[i] = pack_half2(oi[i], oq[i]);
                         else reinterpret_cast<float2 *>(dst)[i] = make_float2(oi[i], oq[i]);
                     }
             }
         } else {
-            // ---- reduce over column bit 0 (lane bit 4): even rows keep outputs 0-1, odd rows 2-3
+            // ---- second swap step: PS = 2: column bit 0 (lane bit 4); PS = 4: p bit 1 (lane bit 5)
             float ri[2], rq[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                permlane16_swap(oi[i], oi[i + 2]);
-                permlane16_swap(oq[i], oq[i + 2]);
+                if constexpr (PS == 2) {
+                    permlane16_swap(oi[i], oi[i + 2]);
+                    permlane16_swap(oq[i], oq[i + 2]);
+                } else {
+                    permlane32_swap(oi[i], oi[i + 2]);
+                    permlane32_swap(oq[i], oq[i + 2]);
+                }
                 ri[i] = __fadd_rn(oi[i], oi[i + 2]);
                 rq[i] = __fadd_rn(oq[i], oq[i + 2]);
             }
             // ---- remaining column bits: butterflies (every lane of the group ends with the sum)
-            if constexpr (C::NCOL >= 4) {
+            constexpr int CB0 = PS == 2 ? 1 : 0;            // first column bit still to reduce
+            constexpr int CBITS = C::NCOL == 8 ? 3 : (C::NCOL == 4 ? 2 : (C::NCOL == 2 ? 1 : 0));
+            int wmask = 0;                                  // lane bits that must be 0 on a writer
+#pragma unroll
+            for (int k = CB0; k < CBITS; ++k) {
+                const int bit = 1 << (5 - C::PB - k);       // lane bit of column bit k
+                wmask |= bit;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    ri[i] = __fadd_rn(ri[i], __shfl_xor(ri[i], 8));
-                    rq[i] = __fadd_rn(rq[i], __shfl_xor(rq[i], 8));
+                    ri[i] = __fadd_rn(ri[i], __shfl_xor(ri[i], bit));
+                    rq[i] = __fadd_rn(rq[i], __shfl_xor(rq[i], bit));
                 }
             }
-            if constexpr (C::NCOL >= 8) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ri[i] = __fadd_rn(ri[i], __shfl_xor(ri[i], 4));
-                    rq[i] = __fadd_rn(rq[i], __shfl_xor(rq[i], 4));
-                }
-            }
-            const long long m = mw + 2 * ((lane >> 4) & 1);
-            const bool writer = (C::NCOL < 4 || ((lane >> 3) & 1) == 0) && (C::NCOL < 8 || ((lane >> 2) & 1) == 0);
-            if (writer) {
+            // outputs held: PS = 2: 4*bit5 + 2*bit4 + {0, 1};  PS = 4: 4*bit4 + 2*bit5 + {0, 1}
+            const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1;
+            const long long m = mw + (PS == 2 ? 4 * b5 + 2 * b4 : 4 * b4 + 2 * b5);
+            if ((lane & wmask) == 0) {
                 char *dst = out + C::SBYTES * m;
                 if (m + 2 <= a.n_out) {
                     if constexpr (HALF) {
@@ -312,7 +360,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
             }
         }
+        if constexpr (ABL == 3) ph[0] += 1;
     }
+    if constexpr (ABL == 3) {
+        if (lane == 0 && a.stamps) {
+            unsigned long long *rec = a.stamps + 5 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * W + ww);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rec[k] = ph[k];
+        }
+    }
+#undef SXFIR_PHASE
 }
 
 }  // namespace sxfir

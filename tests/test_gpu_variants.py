@@ -38,3 +38,33 @@ def test_variant_matches_oracle(oracle, monkeypatch, env):
     y2 = to_cpu(plan.process(to_gpu(x[n:])))                # exercises the fused history carry-over
     ref = oracle.decim_f32(h, 4, x, 2, 4)
     assert_bit_exact(np.concatenate([y1, y2]), ref, "variant %r" % env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,n_in", [(4, 70000), (8, 1 << 16), (16, 50000), (32, 4096 * 5 + 32 * 3)])
+def test_quarter_row_split_variant(oracle, monkeypatch, D, n_in):
+    """SXFIR_MULTI_PS=4: the multi-column decimator with the 32 tap rows split over four lanes.  The plan
+    then reports the contract (4, 4) and must match the oracle run with exactly that contract, across a
+    call boundary (fused history carry-over), CF32 and CF16."""
+    import sxxcvr_amd
+    from sxxcvr_amd.resampler import DECIMATE, KERNEL_TILED
+    monkeypatch.setenv("SXFIR_MULTI_PS", "4")
+    if D == 4:
+        monkeypatch.setenv("SXFIR_TILE_VARIANT", "mu")      # route /4 through the multi-column kernel
+    n_in -= n_in % D
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    x = oracle.synth_iq(0x51255, 21, 0, n_in + 2048)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
+    plan.set_kernel(KERNEL_TILED)
+    assert plan.contract == (4, 4)
+    y = np.concatenate([to_cpu(plan.process(to_gpu(x[:n_in]))), to_cpu(plan.process(to_gpu(x[n_in:])))])
+    assert_bit_exact(y, oracle.decim_f32(h, D, x, 4, 4), "quarter split D=%d" % D)
+    if D != 4:
+        x16 = oracle.f32_to_f16(x.view(np.float32))
+        xq = oracle.f16_to_f32(x16).view(np.complex64)
+        p16 = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
+        p16.set_kernel(KERNEL_TILED)
+        assert p16.contract == (4, 4)
+        got = to_cpu(p16.process(to_gpu(x16.view(np.uint32).view(np.int32)))).view(np.uint16)
+        want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, 4, 4).view(np.float32))
+        assert np.array_equal(got, want), "quarter split CF16 D=%d" % D

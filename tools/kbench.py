@@ -25,8 +25,11 @@ taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_TILE_VARIANT"] = v
-    if v[0] == "w" and v[1:].isdigit(): os.environ["SXFIR_MULTI_W"] = v[1:]      # "w4": multi kernel with 4 waves per workgroup
-    else: os.environ.pop("SXFIR_MULTI_W", None)
+    os.environ.pop("SXFIR_MULTI_W", None); os.environ.pop("SXFIR_MULTI_PS", None)
+    if v[0] == "w":                                  # "w4": multi kernel, 4 waves per workgroup; "w8p4": 4-way row split
+        w, _, ps = v[1:].partition("p")
+        os.environ["SXFIR_MULTI_W"] = w
+        if ps: os.environ["SXFIR_MULTI_PS"] = ps
     os.environ["SXFIR_OVERSUB"] = str(ov)
     os.environ["SXFIR_ABLATE"] = str(abl)
     os.environ["SXFIR_SCHED"] = str(sched)
@@ -52,6 +55,17 @@ for c, p in zip(configs, plans):
         mhz = C.c_double()
         if p._lib.sxfir_debug_clock(p._plan, C.byref(mhz)) == 0:
             print("config %s in-kernel shader clock (median over waves): %.0f MHz" % (c, mhz.value))
+for c, p in zip(configs, plans):
+    if c[3] == 3 and D != 4:
+        cap = 1 << 20
+        buf = (C.c_ulonglong * (5 * cap))(); nrec = C.c_size_t()
+        if p._lib.sxfir_debug_stamps(p._plan, buf, cap, C.byref(nrec)) == 0:
+            r = np.frombuffer(buf, dtype=np.uint64, count=5 * nrec.value).reshape(-1, 5).astype(np.float64)
+            r = r[r[:, 0] > 0]
+            per = r[:, 1:] / r[:, :1]
+            print("config %s phases, mean shader cycles per tile per wave over %d waves: stage %.0f | wait data %.0f | "
+                  "arithmetic %.0f | reduce+store+barrier %.0f | sum %.0f" % (
+                      c, len(r), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), per.sum(1).mean()))
 for c in configs:
     a = np.array(res[c])
     gbs = (8.0 + 8.0 / D) * (1 << log2n) / (a * 1e-3) / 1e9
