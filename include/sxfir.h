@@ -147,6 +147,16 @@ int sxfir_free(void *dev);
 int sxfir_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int sxfir_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 int sxfir_stream_sync(void *stream);
+/* Pinned (page-locked) host memory: staging buffers that hipMemcpyAsync really overlaps with kernels,
+ * and streams of the caller's own, so that e.g. an RX and a TX thread do not wait on each other's work
+ * (the reference's two PCMs are independent in the same way, SoapySX.cpp:373). */
+/* The helpers above and sxfir_synth_fill / the converters act on the calling thread's current GPU
+ * (plans remember their own): a host thread that did not create the plan selects it with this. */
+int sxfir_set_device(int device);
+int sxfir_host_alloc(void **host, size_t bytes);
+int sxfir_host_free(void *host);
+int sxfir_stream_create(void **stream);
+int sxfir_stream_destroy(void *stream);
 
 /* Timed launches for bench.py: runs `iters` back-to-back decimate passes of
  * the same buffers on `stream` bracketed by hipEvents ON THAT STREAM and

@@ -68,6 +68,11 @@ def load_sxfir():
         "sxfir_design_lowpass": (ci, [ci, ci, dbl, dbl, vp]),
         "sxfir_malloc": (ci, [P(vp), sz]),
         "sxfir_free": (ci, [vp]),
+        "sxfir_set_device": (ci, [ci]),
+        "sxfir_host_alloc": (ci, [P(vp), sz]),
+        "sxfir_host_free": (ci, [vp]),
+        "sxfir_stream_create": (ci, [P(vp)]),
+        "sxfir_stream_destroy": (ci, [vp]),
         "sxfir_memcpy_h2d": (ci, [vp, vp, sz, vp]),
         "sxfir_memcpy_d2h": (ci, [vp, vp, sz, vp]),
         "sxfir_stream_sync": (ci, [vp]),

@@ -83,6 +83,8 @@ private:
 
     int gpu;
     int decim, interp, taps_per_phase;
+    int nchan;                  // channels per direction (device argument `channels`; the reference has 1, :1591-1595)
+    int capture_channel;        // which TX channel tx_capture reads back (setting TX_CAPTURE_CHANNEL)
     uint64_t seed;
     bool wire_s32;
     std::unique_ptr<sx::RxChain> rx_chain;
@@ -115,6 +117,8 @@ public:
           decim(std::stoi(arg(args, "decim", "4"))),
           interp(std::stoi(arg(args, "interp", "4"))),
           taps_per_phase(std::stoi(arg(args, "taps_per_phase", "32"))),
+          nchan(std::stoi(arg(args, "channels", "1"))),
+          capture_channel(0),
           seed(std::stoull(arg(args, "seed", "0x51255"), nullptr, 0)),
           wire_s32(arg(args, "wire", "cf32") == "s32"),
           tx_ptt_samples(0),
@@ -124,11 +128,13 @@ public:
         if (masterClock != 32.0e6 && masterClock != 38.4e6)
             throw std::runtime_error("master_clock must be 32e6 or 38.4e6");
         if (decim < 1 || interp < 1 || taps_per_phase < 1) throw std::runtime_error("bad decim/interp/taps_per_phase");
+        if (nchan < 1 || nchan > 64) throw std::runtime_error("channels must be 1..64");
         int ndev = 0;
         if (sxfir_device_count(&ndev) != SXFIR_OK || ndev < 1)
             throw std::runtime_error(std::string("No MI355X visible: ") + sxfir_last_error());
-        rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, 0, wire_s32));
-        tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, wire_s32));
+        const uint32_t first_channel = (uint32_t)std::stoul(arg(args, "first_channel", "0"));
+        rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, first_channel, nchan, wire_s32));
+        tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, nchan, wire_s32));
     }
 
     ~SoapySXHip(void) { SoapySDR_logf(SOAPY_SDR_INFO, "Uninitializing SoapySX"); }
@@ -140,7 +146,13 @@ public:
     SoapySDR::Stream *setupStream(const int direction, const std::string &format, const std::vector<size_t> &channels,
                                   const SoapySDR::Kwargs &args)
     {
-        (void)channels;   // one channel per device, :747
+        // The reference has one channel and ignores the list (:747).  With `channels=N` a stream carries
+        // all N channels, buffs[c] = channel c: the list may be empty ("automatic") or name exactly those.
+        if (!channels.empty()) {
+            bool ok = channels.size() == (size_t)nchan;
+            for (size_t i = 0; ok && i < channels.size(); ++i) ok = channels[i] == i;
+            if (!ok) throw std::runtime_error("A stream carries all channels of the device: 0.." + std::to_string(nchan - 1));
+        }
         std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
 
         if (format != "CF32") throw std::runtime_error("Only CF32 format is currently supported");
@@ -278,7 +290,7 @@ public:
         try {
             // stream sample `first` == position before the read: the PCM frame
             // counter and `position` advance together
-            rx_chain->produce(first, (size_t)samples_read, static_cast<float *>(buffs[0]));
+            rx_chain->produce(first, (size_t)samples_read, reinterpret_cast<float *const *>(buffs));
         } catch (const std::exception &e) {
             SoapySDR_logf(SOAPY_SDR_ERROR, "rx chain: %s", e.what());
             return SOAPY_SDR_STREAM_ERROR;
@@ -376,7 +388,7 @@ public:
                 const float ii = fi * fi, qq = fq * fq;
                 if (ii + qq >= tx_threshold2) ++tx_ptt_samples;
             }
-            tx_chain->consume(first, (size_t)samples_written, src);
+            tx_chain->consume(first, (size_t)samples_written, reinterpret_cast<const float *const *>(buffs));
         } catch (const std::exception &e) {
             SoapySDR_logf(SOAPY_SDR_ERROR, "tx chain: %s", e.what());
             return SOAPY_SDR_STREAM_ERROR;
@@ -548,6 +560,10 @@ public:
             clock.advance(std::stoll(value));
         } else if (key == "PA") {
             if (value != "ON" && value != "OFF" && value != "AUTO") throw std::runtime_error("Unknown PA setting");
+        } else if (key == "TX_CAPTURE_CHANNEL") {
+            const int c = std::stoi(value);
+            if (c < 0 || c >= nchan) throw std::runtime_error("No such channel");
+            capture_channel = c;
         } else {
             throw std::runtime_error("Unknown setting");
         }
@@ -564,6 +580,7 @@ public:
         if (key == "TX_INTERP") return std::to_string(interp);
         if (key == "RX_NTAPS") return std::to_string(rx_chain->ntaps());
         if (key == "SEED") return std::to_string(seed);
+        if (key == "TX_CAPTURE_CHANNEL") return std::to_string(capture_channel);
         throw std::runtime_error("Unknown setting");
     }
 
@@ -571,7 +588,7 @@ public:
     void txCapture(long long dac_pos, size_t n, float *dst)
     {
         std::scoped_lock lock(pcm_tx.mutex);
-        tx_chain->capture(dac_pos, n, dst);
+        tx_chain->capture(dac_pos, n, dst, capture_channel);
     }
 
     /*******************************************************************
@@ -598,7 +615,7 @@ public:
         return args;
     }
 
-    size_t getNumChannels(const int direction) const { (void)direction; return 1; }
+    size_t getNumChannels(const int direction) const { (void)direction; return (size_t)nchan; }
 
     std::string getNativeStreamFormat(const int direction, const size_t channel, double &fullScale) const
     {

@@ -877,4 +877,41 @@ int sxfir_stream_sync(void *stream)
     return SXFIR_OK;
 }
 
+int sxfir_set_device(int device)
+{
+    HIPCHECK(hipSetDevice(device));
+    return SXFIR_OK;
+}
+
+int sxfir_host_alloc(void **host, size_t bytes)
+{
+    if (!host) return fail(SXFIR_EINVAL, "NULL argument");
+    *host = nullptr;
+    hipError_t e = hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return fail(SXFIR_ENOMEM, "hipHostMalloc(%zu) out of memory", bytes);
+    if (e != hipSuccess) return fail(SXFIR_EHIP, "hipHostMalloc: %s", hipGetErrorString(e));
+    return SXFIR_OK;
+}
+
+int sxfir_host_free(void *host)
+{
+    if (host) HIPCHECK(hipHostFree(host));
+    return SXFIR_OK;
+}
+
+int sxfir_stream_create(void **stream)
+{
+    if (!stream) return fail(SXFIR_EINVAL, "NULL argument");
+    hipStream_t st = nullptr;
+    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return SXFIR_OK;
+}
+
+int sxfir_stream_destroy(void *stream)
+{
+    if (stream) HIPCHECK(hipStreamDestroy(S(stream)));
+    return SXFIR_OK;
+}
+
 }  // extern "C"

@@ -444,3 +444,71 @@ def test_rx_and_tx_threads(oracle):
     ref = oracle.decim_f32(h, 4, oracle.synth_iq(SEED, 0, 0, 4 * nblk * blk), 2, 4)
     assert_bit_exact(got, ref, "threaded rx stream")
     assert int(dev.readSetting("TX_WRITTEN")) == nblk * blk
+
+
+def test_multi_channel_device(oracle):
+    """Device argument channels=N (the reference has one channel, SX.cpp:1591-1595; BASELINE config 4 puts
+    8 on a GPU): one stream carries all N channels, buffs[c] = channel c of the synthetic source, and the TX
+    sink keeps one ring per channel.  Every channel is checked against the oracle bit for bit."""
+    n = 4
+    dev = make(channels=str(n), first_channel="8", decim="4", interp="4")
+    assert dev.getNumChannels(SoapySDR.SOAPY_SDR_RX) == n and dev.getNumChannels(SoapySDR.SOAPY_SDR_TX) == n
+    with pytest.raises(RuntimeError, match="all channels"):
+        dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, list(range(n)), {})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [], {"threshold": "0"})
+    dev.activateStream(rx)
+    dev.activateStream(tx)
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    total, got = 0, [[] for _ in range(n)]
+    for block in (256, 256, 1000, 5000, 256):                    # crosses read-ahead batch boundaries (4096, ...)
+        bufs = [np.zeros(block, dtype=np.complex64) for _ in range(n)]
+        r = dev.readStream(rx, bufs, block)
+        assert r.ret == block and r.timeNs == oracle.ticks_to_time_ns(total, RATE)
+        for c in range(n):
+            got[c].append(bufs[c].copy())
+        total += block
+    for c in range(n):
+        ref = oracle.decim_f32(h, 4, oracle.synth_iq(SEED, 8 + c, 0, 4 * total), 2, 4)
+        assert_bit_exact(np.concatenate(got[c]), ref, "rx channel %d" % c)
+    # TX: a different block per channel, written at the stream position the device is at
+    ht = sxxcvr_amd.design_lowpass(128, 4, 8.0, 4.0)
+    blocks = [oracle.synth_iq(77, c, 0, 2048) * np.float32(0.5) for c in range(n)]
+    pos0 = int(dev.readSetting("TX_POSITION"))
+    w = dev.writeStream(tx, blocks, 2048)
+    assert w.ret == 2048
+    first = int(dev.readSetting("TX_POSITION")) - 2048
+    assert first >= pos0
+    for c in range(n):
+        dev.writeSetting("TX_CAPTURE_CHANNEL", str(c))
+        out = dev.txCapture(first * 4, 2048 * 4)
+        stream = np.concatenate([np.zeros(32, dtype=np.complex64), blocks[c]])
+        assert_bit_exact(out, oracle.interp_f32(ht, 4, stream, 2)[32 * 4:], "tx channel %d" % c)
+    with pytest.raises(RuntimeError, match="No such channel"):
+        dev.writeSetting("TX_CAPTURE_CHANNEL", str(n))
+
+
+def test_rx_read_ahead_is_invisible(oracle):
+    """The RX chain produces the stream in batches and keeps the next batch in flight; whatever the read
+    sizes, and across an overrun skip (a jump of the position drops the batches and re-primes the filter),
+    the samples are those of one pass of the oracle over the same stream positions."""
+    dev = make(decim="8")
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "256"})
+    dev.activateStream(rx)
+    ref = rx_reference(oracle, 8, 1 << 18)
+    pos = 0
+    rng = np.random.default_rng(5)
+    for n in [1, 255, 256, 4095, 4097, 70000] + [int(v) for v in rng.integers(1, 9000, size=25)]:
+        buf = np.zeros(n, dtype=np.complex64)
+        r = dev.readStream(rx, [buf], n)
+        assert r.ret == n and r.timeNs == oracle.ticks_to_time_ns(pos, RATE)
+        assert_bit_exact(buf, ref[pos:pos + n], "read of %d at %d" % (n, pos))
+        pos += n
+    # let the ring overflow: the next read skips ahead (SX.cpp:910-927) and the data follows the position
+    dev.writeSetting("CLOCK_ADVANCE", str(65536 + 3 * 256 + 17))
+    buf = np.zeros(300, dtype=np.complex64)
+    r = dev.readStream(rx, [buf], 300)
+    new_pos = int(dev.readSetting("RX_POSITION")) - 300
+    assert new_pos > pos and (new_pos - pos) % 256 == 0
+    assert r.timeNs == oracle.ticks_to_time_ns(new_pos, RATE)
+    assert_bit_exact(buf, ref[new_pos:new_pos + 300], "after the skip")
