@@ -439,6 +439,8 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         case 503204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 5>), grid, dim3(256), 0, st, a); break;
         case 303204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 3>), grid, dim3(256), 0, st, a); break;
         case 303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3>), grid, dim3(512), 0, st, a); break;
+        case 313204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, true, 3>), grid, dim3(256), 0, st, a); break;
+        case 313208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, true, 3>), grid, dim3(512), 0, st, a); break;
         case 1303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3, 4>), grid, dim3(512), 0, st, a); break;
         case 300802: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 2, false, 3>), grid, dim3(128), 0, st, a); break;
 #define SXFIR_X(DD, WW, HH, PP) \

@@ -69,7 +69,7 @@ struct DecimMulti {
     static constexpr int PADP = 8 * CPR;                  // lane stride in chunks; one pad chunk after every PADP
     static constexpr int SUBSL = CH + CH / PADP + 1;
     // sub-stream pitch: a whole number of DMA instructions (64 slots) with room for the bank skew
-    static constexpr int IPS = (SUBSL + (NCOL >= 4 ? 12 : 0) + 63) / 64;   // DMA instructions per sub-stream
+    static constexpr int IPS = (SUBSL + (NCOL * PS >= 8 ? 15 : 0) + 63) / 64;   // DMA instructions per sub-stream
     static constexpr int SUBSTRIDE = IPS * 64;
     static constexpr int NI = NCOL * IPS;                 // DMA instructions per tile (all waves together)
     static constexpr int LDS_SLOTS = NI * 64;
@@ -79,10 +79,20 @@ struct DecimMulti {
     static_assert(PS == 2 || PS == 4, "row split of 2 or 4");
     static_assert(GW >= 1, "a wave holds at least one output group");
     static_assert(SUBSL < 4000, "the multiply-shift divisions below are exact below 4000 only");
-    // bank skew per column group so that the 16 lanes of every ds_read_b128 group differ in slot
+    // Bank skew per column group.  A ds_read_b128 is served 16 lanes at a time (lanes 16k..16k+15) and is
+    // conflict free when those lanes hit 16 different 16-byte slots mod 16.  The output groups g (low lane
+    // bits) already differ: the lane stride is PADP + 1 slots, an odd number.  Column bit k sits at lane
+    // bit 5 - PB - k; those below lane bit 4 vary inside a 16-lane group and get a skew equal to their own
+    // lane bit, which makes the slot residue of a lane its low four lane bits (a permutation).
     static __device__ __forceinline__ int skew(int c)
     {
-        return NCOL == 8 ? 8 * (c & 1) + 4 * ((c >> 1) & 1) : (NCOL == 4 ? 8 * (c & 1) : 0);
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int bit = 5 - PB - k;
+            if ((NCOL >> k) > 1 && bit < 4) s |= ((c >> k) & 1) << bit;
+        }
+        return s;
     }
     // physical slot r of a sub-stream image -> logical chunk (a pad slot repeats its left neighbour)
     static __device__ __forceinline__ int logical(int r)

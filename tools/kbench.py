@@ -11,6 +11,7 @@ rounds = int(os.environ.get("KB_ROUNDS", "5"))
 iters = int(os.environ.get("KB_ITERS", "10"))
 nchan = int(os.environ.get("KB_NCHAN", "1"))
 D = int(os.environ.get("KB_D", "4"))
+FMT = os.environ.get("KB_FMT", "CF32")
 configs = []
 for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
     f = spec.split(":")
@@ -18,9 +19,10 @@ for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
     configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0, int(f[4]) if len(f) > 4 else 0))
 
 n = (1 << log2n) // nchan
-x = torch.empty((nchan, n), dtype=torch.complex64, device="cuda")
-sxxcvr_amd.synth_fill(x, 0x51255, 0, 0)
-y = torch.empty((nchan, n // D), dtype=torch.complex64, device="cuda")
+dt = torch.complex64 if FMT == "CF32" else torch.int32
+x = torch.empty((nchan, n), dtype=dt, device="cuda")
+sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=FMT)
+y = torch.empty((nchan, n // D), dtype=dt, device="cuda")
 taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched in configs:
@@ -35,7 +37,7 @@ for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_SCHED"] = str(sched)
     if occ: os.environ["SXFIR_OCC"] = str(occ)
     else: os.environ.pop("SXFIR_OCC", None)
-    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, D, nchan=nchan))
+    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, D, nchan=nchan, fmt=FMT))
 ref = None
 res = {c: [] for c in configs}
 st = torch.cuda.current_stream().cuda_stream
@@ -46,7 +48,7 @@ for r in range(rounds):
         res[c].append(ms)
         if r == 0:
             torch.cuda.synchronize()
-            chk = torch.view_as_real(y).view(torch.int32).sum(dtype=torch.int64).item()
+            chk = (torch.view_as_real(y) if FMT == "CF32" else y).view(torch.int32).sum(dtype=torch.int64).item()
             if ref is None: ref = chk
             print("config", c, "checksum", "same" if chk == ref else "DIFFERENT")
 import ctypes as C
@@ -68,6 +70,6 @@ for c, p in zip(configs, plans):
                       c, len(r), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), per.sum(1).mean()))
 for c in configs:
     a = np.array(res[c])
-    gbs = (8.0 + 8.0 / D) * (1 << log2n) / (a * 1e-3) / 1e9
+    gbs = (8.0 + 8.0 / D) * (1.0 if FMT == "CF32" else 0.5) * (1 << log2n) / (a * 1e-3) / 1e9
     print("%-12s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
         "%s:%d:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
