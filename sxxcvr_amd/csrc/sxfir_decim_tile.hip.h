@@ -146,11 +146,13 @@ __device__ __forceinline__ void store_tile(const DecimTileCtx<NT> &c, int tile, 
     // that each global store instruction writes 1 KiB of consecutive addresses (whole lines).
     const long long m0 = (long long)tile * C::TILE_OUT;
     if (m0 + C::TILE_OUT <= c.n_out) {
+        // one pad slot after every 16 keeps both the scattered writes (lane stride 4 chunks) and the
+        // linear read-back free of bank conflicts
         const int oc = 4 * c.g + 2 * c.p;
-        xbuf[oc] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
-        xbuf[oc + 1] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
+        xbuf[oc + (oc >> 4)] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
+        xbuf[oc + 1 + (oc >> 4)] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
         f32x4 *dst = reinterpret_cast<f32x4 *>(c.out + 2 * m0);
-        const f32x4 v0 = xbuf[c.lane], v1 = xbuf[64 + c.lane];
+        const f32x4 v0 = xbuf[c.lane + (c.lane >> 4)], v1 = xbuf[68 + c.lane + (c.lane >> 4)];
         __builtin_nontemporal_store(v0, dst + c.lane);
         __builtin_nontemporal_store(v1, dst + 64 + c.lane);
     } else {
