@@ -27,6 +27,8 @@
     X(4, 2, false, 4) X(8, 2, false, 4) X(8, 4, false, 4) X(16, 4, false, 4) X(16, 8, false, 4) X(32, 8, false, 4) \
     X(32, 16, false, 4) \
     X(4, 2, true, 4) X(8, 4, true, 4) X(16, 8, true, 4) X(32, 8, true, 4)
+// profiling modes of decim4_tile_kernel<128> (its ABL template argument)
+#define SXFIR_TILE_ABLATIONS(X) X(1) X(2) X(3) X(7) X(8) X(9) X(10) X(11) X(12) X(17) X(18) X(19)
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_sgpr.hip.h"
@@ -498,30 +500,15 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<8>), grid, dim3(64), 0, st, a);
         } else if (p->ntaps == 128 && p->sgpr_r == 4) {
             hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<4>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 1) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 1>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 2) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 2>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 7) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 7>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 11) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 11>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 12) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 12>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 9) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 9>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 10) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 10>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 8) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 8>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 3) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 3>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 17) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 17>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 18) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 18>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate == 19) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 19>), grid, dim3(64), 0, st, a);
+        } else if (p->ntaps == 128 && p->ablate != 0) {
+            // profiling builds of the same kernel (SXFIR_ABLATE, sxfir_decim_tile.hip.h): wrong results
+            switch (p->ablate) {
+#define SXFIR_X(N) \
+            case N: hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, N>), grid, dim3(64), 0, st, a); break;
+                SXFIR_TILE_ABLATIONS(SXFIR_X)
+#undef SXFIR_X
+            default: return fail(SXFIR_EINVAL, "SXFIR_ABLATE=%d is not a profiling mode of the tile kernel", p->ablate);
+            }
         } else if (p->ntaps == 128) {
             if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
             else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);
