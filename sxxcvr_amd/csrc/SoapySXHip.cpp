@@ -83,6 +83,8 @@ private:
 
     int gpu;
     int decim, interp, taps_per_phase;
+    bool decim_auto, interp_auto;   // ratio follows the sample rate like the chip's does: divider / 16
+    uint32_t first_channel;
     int nchan;                  // channels per direction (device argument `channels`; the reference has 1, :1591-1595)
     int capture_channel;        // which TX channel tx_capture reads back (setting TX_CAPTURE_CHANNEL)
     uint64_t seed;
@@ -94,6 +96,21 @@ private:
 
     int64_t timestamp_to_samples(long long timestamp) const { return SoapySDR::timeNsToTicks(timestamp, sampleRate); }
     long long samples_to_timestamp(int64_t samples) const { return SoapySDR::ticksToTimeNs(samples, sampleRate); }
+
+    // (Re)create the GPU chains for the current ratios.  Callers hold both stream mutexes (or are the
+    // constructor).
+    void rebuild_chains(bool rx, bool tx)
+    {
+        if (rx) {
+            rx_chain.reset();      // frees the old chain's HBM before the new one allocates
+            rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, first_channel, nchan, wire_s32));
+        }
+        if (tx) {
+            tx_chain.reset();
+            tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, nchan, wire_s32));
+            tx_chain->set_threshold2(tx_threshold2);
+        }
+    }
 
     void reset_streams()
     {
@@ -114,9 +131,12 @@ public:
           tx_threshold2(0.0f),
           linked(false),
           gpu(std::stoi(arg(args, "gpu", "0"))),
-          decim(std::stoi(arg(args, "decim", "4"))),
-          interp(std::stoi(arg(args, "interp", "4"))),
+          decim(arg(args, "decim", "4") == "auto" ? 16 : std::stoi(arg(args, "decim", "4"))),
+          interp(arg(args, "interp", "4") == "auto" ? 16 : std::stoi(arg(args, "interp", "4"))),
           taps_per_phase(std::stoi(arg(args, "taps_per_phase", "32"))),
+          decim_auto(arg(args, "decim", "4") == "auto"),
+          interp_auto(arg(args, "interp", "4") == "auto"),
+          first_channel((uint32_t)std::stoul(arg(args, "first_channel", "0"))),
           nchan(std::stoi(arg(args, "channels", "1"))),
           capture_channel(0),
           seed(std::stoull(arg(args, "seed", "0x51255"), nullptr, 0)),
@@ -132,9 +152,7 @@ public:
         int ndev = 0;
         if (sxfir_device_count(&ndev) != SXFIR_OK || ndev < 1)
             throw std::runtime_error(std::string("No MI355X visible: ") + sxfir_last_error());
-        const uint32_t first_channel = (uint32_t)std::stoul(arg(args, "first_channel", "0"));
-        rx_chain.reset(new sx::RxChain(gpu, decim, taps_per_phase, seed, first_channel, nchan, wire_s32));
-        tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, nchan, wire_s32));
+        rebuild_chains(true, true);
     }
 
     ~SoapySXHip(void) { SoapySDR_logf(SOAPY_SDR_INFO, "Uninitializing SoapySX"); }
@@ -435,7 +453,7 @@ public:
     void setSampleRate(const int direction, const size_t channel, const double rate)
     {
         (void)direction; (void)channel;
-        std::scoped_lock lock(reg_mutex);
+        std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex, reg_mutex);
         if (rate != rate || rate <= 0) throw std::runtime_error("Sample rate must be positive");
         const double divider = round(masterClock / rate);
         bool found = false;
@@ -445,6 +463,14 @@ public:
         if (!found) throw std::runtime_error("Unsupported sample rate");
         sampleRate = masterClock / divider;
         clock.set_rate(sampleRate);
+        // decim=auto / interp=auto: the converters run at master clock / 16 and the ratio follows the rate,
+        // as the SX1255's own decimator and interpolator do when the divider registers are programmed
+        // (:1192-1208): 600 kS/s -> 4, 300 kS/s -> 8, 150 -> 16, 75 -> 32, 50 -> 48, 25 -> 96 (at 38.4 MHz)
+        const int ratio = (int)divider / 16;
+        const bool new_rx = decim_auto && ratio != decim, new_tx = interp_auto && ratio != interp;
+        if (new_rx) decim = ratio;
+        if (new_tx) interp = ratio;
+        if (new_rx || new_tx) rebuild_chains(new_rx, new_tx);
     }
 
     double getSampleRate(const int direction, const size_t channel) const

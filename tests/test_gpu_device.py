@@ -512,3 +512,37 @@ def test_rx_read_ahead_is_invisible(oracle):
     assert new_pos > pos and (new_pos - pos) % 256 == 0
     assert r.timeNs == oracle.ticks_to_time_ns(new_pos, RATE)
     assert_bit_exact(buf, ref[new_pos:new_pos + 300], "after the skip")
+
+
+def test_ratio_follows_sample_rate(oracle):
+    """decim=auto / interp=auto: like the SX1255, whose decimator and interpolator follow the divider that
+    setSampleRate programs (SX.cpp:1192-1208), the ratio is divider / 16.  The reference's own test rates give
+    BASELINE's shapes: 300 kS/s -> 256-tap /8 (config 3), 75 kS/s -> 1024-tap /32 (config 5)."""
+    dev = SoapySDR.Device({"driver": "sx", "clock": "virtual", "decim": "auto", "interp": "auto"})
+    assert dev.readSetting("RX_DECIM") == "16"                      # default rate = master clock / 256
+    for rate, ratio in ((300000.0, 8), (75000.0, 32)):
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, rate)
+        assert dev.readSetting("RX_DECIM") == str(ratio) and dev.readSetting("TX_INTERP") == str(ratio)
+        assert dev.readSetting("RX_NTAPS") == str(32 * ratio)
+        rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+        tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"threshold": "0"})
+        dev.activateStream(rx)
+        dev.activateStream(tx)
+        ref = rx_reference(oracle, ratio, 3000)
+        buf = np.zeros(3000, dtype=np.complex64)
+        r = dev.readStream(rx, [buf], 3000)
+        assert r.ret == 3000 and r.timeNs == 0
+        assert_bit_exact(buf, ref, "rx at %g S/s" % rate)
+        block = oracle.synth_iq(5, 1, 0, 1024) * np.float32(0.25)
+        w = dev.writeStream(tx, [block], 1024)
+        assert w.ret == 1024
+        first = int(dev.readSetting("TX_POSITION")) - 1024
+        out = dev.txCapture(first * ratio, 1024 * ratio)
+        stream = np.concatenate([np.zeros(32, dtype=np.complex64), block])
+        assert_bit_exact(out, tx_reference(oracle, ratio, stream)[32 * ratio:], "tx at %g S/s" % rate)
+        dev.deactivateStream(rx)
+        dev.deactivateStream(tx)
+        dev.closeStream(rx)
+        dev.closeStream(tx)
+    with pytest.raises(RuntimeError, match="Unsupported sample rate"):
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 48000.0)
