@@ -261,13 +261,14 @@ private:
 class TxChain {
 public:
     static constexpr size_t kSlotFrames = 1u << 15;    // stream samples per channel and pinned slot
+    static constexpr size_t kFlushFrames = 4096;       // small writes are gathered up to this before a GPU pass
     static constexpr int kSlots = 4;
 
     // wire_s32: the DAC-rate sink holds S32_LE I2S words with the transmitter-keying bits
     // (convert_tx_buffer, SoapySX.cpp:116-137, fused into the interpolator's store).
     TxChain(int gpu, int interp, int taps_per_phase, size_t ring_frames, int nchan, bool wire_s32)
         : gpu_(gpu), interp_(interp), ntaps_(interp * taps_per_phase), nchan_(nchan), plan_(nullptr),
-          ring_len_(ring_frames * (size_t)interp), next_(0), written_(0), slot_(0)
+          ring_len_(ring_frames * (size_t)interp), next_(0), accepted_(0), written_(0), slot_(0), pend_(0)
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
         stream_.reset(new GpuStream());
@@ -298,9 +299,11 @@ public:
     void reset()
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
+        pend_ = 0;                  // what was not passed to the GPU yet is dropped with the rest of the sink
         drain();
         gpu_check(sxfir_reset(plan_, stream_->get()), "sxfir_reset");
         next_ = 0;
+        accepted_ = 0;
         written_ = 0;
     }
 
@@ -309,8 +312,8 @@ public:
     void consume(int64_t pos, size_t n, const float *const *srcs)
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
-        if (pos < next_) throw std::runtime_error("tx chain: position moved backwards");
-        feed(nullptr, (size_t)(pos - next_));
+        if (pos < accepted_) throw std::runtime_error("tx chain: position moved backwards");
+        feed(nullptr, (size_t)(pos - accepted_));
         feed(srcs, n);
         written_ += (int64_t)n;
     }
@@ -320,6 +323,7 @@ public:
     void capture(int64_t dac_pos, size_t n, float *host_dst, int channel = 0)
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
+        flush();
         const int64_t end = next_ * interp_;
         if (channel < 0 || channel >= nchan_) throw std::runtime_error("tx capture: no such channel");
         if (dac_pos < 0 || dac_pos + (int64_t)n > end || end - dac_pos > (int64_t)ring_len_)
@@ -343,31 +347,55 @@ private:
         for (int k = 0; k < kSlots; ++k) busy_[k] = false;
     }
 
-    // n stream samples per channel (srcs == nullptr: silence) -> n*interp ring samples at ring position
-    // next_*interp; returns without waiting for the GPU
+    // n stream samples per channel (srcs == nullptr: silence) are appended to the current pinned slot
+    // (channel c at c*kSlotFrames); the GPU pass over a slot is issued once kFlushFrames have gathered
+    // or the slot is full, and is never waited for here (write-behind: the sink is only observable
+    // through capture(), which flushes).
     void feed(const float *const *srcs, size_t n)
     {
         size_t done = 0;
         while (done < n) {
-            size_t m = std::min(kSlotFrames, n - done);
-            const size_t off = (size_t)((next_ * interp_) % (int64_t)ring_len_);
-            m = std::min(m, (ring_len_ - off) / (size_t)interp_);    // do not wrap inside one pass
-            if (busy_[slot_]) drain();                               // the slot's last H2D may still be reading it
+            if (pend_ == 0 && busy_[slot_]) drain();                 // the slot's last H2D may still be reading it
+            const size_t m = std::min(kSlotFrames - pend_, n - done);
             float *host = stage_.floats() + 2 * kSlotFrames * (size_t)nchan_ * (size_t)slot_;
             for (int c = 0; c < nchan_; ++c) {
-                if (srcs) std::memcpy(host + 2 * (size_t)c * m, srcs[c] + 2 * done, 8 * m);
-                else std::memset(host + 2 * (size_t)c * m, 0, 8 * m);
+                float *dst = host + 2 * ((size_t)c * kSlotFrames + pend_);
+                if (srcs) std::memcpy(dst, srcs[c] + 2 * done, 8 * m);
+                else std::memset(dst, 0, 8 * m);
             }
-            char *dev = in_.at(8 * kSlotFrames * (size_t)nchan_ * (size_t)slot_);
+            pend_ += m;
+            accepted_ += (int64_t)m;
+            done += m;
+            if (pend_ >= kFlushFrames) flush();
+        }
+    }
+
+    // pass the gathered samples of the current slot through the interpolator into the sink ring at ring
+    // position next_*interp (in two passes where the ring wraps), asynchronously
+    void flush()
+    {
+        if (pend_ == 0) return;
+        void *st = stream_->get();
+        const size_t slot_off = kSlotFrames * (size_t)nchan_ * (size_t)slot_;
+        const float *host = stage_.floats() + 2 * slot_off;
+        for (int c = 0; c < nchan_; ++c)
+            gpu_check(sxfir_memcpy_h2d(in_.at(8 * (slot_off + (size_t)c * kSlotFrames)), host + 2 * (size_t)c * kSlotFrames,
+                                       8 * pend_, st),
+                      "sxfir_memcpy_h2d");
+        size_t done = 0;
+        while (done < pend_) {
+            const size_t off = (size_t)((next_ * interp_) % (int64_t)ring_len_);
+            const size_t m = std::min(pend_ - done, (ring_len_ - off) / (size_t)interp_);
             size_t n_out = 0;
-            void *st = stream_->get();
-            gpu_check(sxfir_memcpy_h2d(dev, host, 8 * m * (size_t)nchan_, st), "sxfir_memcpy_h2d");
-            gpu_check(sxfir_interpolate(plan_, dev, m, m, ring_.at(8 * off), ring_len_, &n_out, st), "sxfir_interpolate");
-            busy_[slot_] = true;
-            slot_ = (slot_ + 1) % kSlots;
+            gpu_check(sxfir_interpolate(plan_, in_.at(8 * (slot_off + done)), m, kSlotFrames, ring_.at(8 * off), ring_len_,
+                                        &n_out, st),
+                      "sxfir_interpolate");
             next_ += (int64_t)m;
             done += m;
         }
+        busy_[slot_] = true;
+        slot_ = (slot_ + 1) % kSlots;
+        pend_ = 0;
     }
 
     int gpu_, interp_, ntaps_, nchan_;
@@ -377,9 +405,11 @@ private:
     DeviceBuffer in_, ring_;
     PinnedBuffer stage_;
     bool busy_[kSlots];
-    int64_t next_;        // stream samples consumed so far (written + silence)
+    int64_t next_;        // stream samples passed to the GPU so far (written + silence)
+    int64_t accepted_;    // next_ + what is gathered in the current slot
     int64_t written_;     // stream samples that carried application data
     int slot_;
+    size_t pend_;         // samples gathered in the current slot and not yet passed to the GPU
 };
 
 }  // namespace sx
