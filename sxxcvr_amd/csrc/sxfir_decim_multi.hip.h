@@ -73,6 +73,9 @@ struct DecimMulti {
     static constexpr int SUBSTRIDE = IPS * 64;
     static constexpr int NI = NCOL * IPS;                 // DMA instructions per tile (all waves together)
     static constexpr int LDS_SLOTS = NI * 64;
+    // waves per SIMD the register allocator must leave room for: what the LDS image allows, at most 4
+    static constexpr int LDS_WAVES = (160 * 1024 / (LDS_SLOTS * 16)) * W / 4;
+    static constexpr int MIN_WAVES = LDS_WAVES < 1 ? 1 : (LDS_WAVES > 4 ? 4 : LDS_WAVES);
     static constexpr int WROWS = JR + 7;                  // window rows per lane
     static constexpr int WCH = WROWS * CPR;               // window chunks per lane
     static_assert(D % 4 == 0 && (NCOL & (NCOL - 1)) == 0 && NCOL <= 8, "D must be 4, 8, 16 or 32");
@@ -122,7 +125,8 @@ __device__ __forceinline__ unsigned pack_half2(float i, float q)
 // ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
 // kernel with s_memtime stamps around its phases (a.stamps)
 template <int D, int W, bool HALF = false, int ABL = 0, int PS = 2>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(4, 8))) void decim_multi_kernel(const DecimMultiArgs a)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(DecimMulti<D, W, HALF, PS>::MIN_WAVES, 8))) void
+decim_multi_kernel(const DecimMultiArgs a)
 {
     using C = DecimMulti<D, W, HALF, PS>;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
