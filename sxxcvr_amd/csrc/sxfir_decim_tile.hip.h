@@ -165,27 +165,53 @@ __device__ __forceinline__ void store_tile(const DecimTileCtx<NT> &c, int tile, 
 }
 
 // Same arithmetic with the I and Q FMAs of one (tap, sample) pair issued as one
-// v_pk_fma_f32 (the tap is broadcast to both halves by op_sel): two independent
-// IEEE fused multiply-adds per instruction, so results are bit-identical.
-template <int NT>
+// v_pk_fma_f32 (two independent IEEE fused multiply-adds per instruction, so the
+// results are bit-identical).  The tap is broadcast to both halves by op_sel: taps
+// live in 64-bit register pairs {h[2k], h[2k+1]} and op_sel / op_sel_hi pick the
+// low or the high dword for both lanes of the packed operation.  Inline asm keeps
+// the register picture of the scalar loop (the compiler's own packing of this loop
+// needs 178 VGPRs).
+__device__ __forceinline__ void pk_fma_lo(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(hpair), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(hpair), "v"(x));
+}
+
+template <int NT, bool S32IN = false>
 __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,
                                                 const float (&h)[NT / 2], f32x4 *xbuf)
 {
     using C = DecimTile4<NT>;
+    f32x2 hp[C::TPL / 2];
+#pragma unroll
+    for (int k = 0; k < C::TPL / 2; ++k) hp[k] = (f32x2){h[2 * k], h[2 * k + 1]};
     f32x2 acc[C::R];
 #pragma unroll
     for (int i = 0; i < C::R; ++i) acc[i] = (f32x2){0.0f, 0.0f};
 #pragma unroll
     for (int t = 0; t < C::WCH; ++t) {
-        const f32x4 v = win[t + (t >> 4)];
+        f32x4 v = win[t + (t >> 4)];
+        if constexpr (S32IN) {
+            // S32_LE wire words (convert_rx_buffer, SoapySX.cpp:103-112): only the int->float conversion
+            // happens here; the exact 2^-31 scale is folded into the taps by the caller, which gives the
+            // same bits as scaling every sample (a power of two commutes with the fused multiply-add)
+            v = (f32x4){(float)__float_as_int(v.x), (float)__float_as_int(v.y), (float)__float_as_int(v.z),
+                        (float)__float_as_int(v.w)};
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int w = 2 * t + s;
-            const f32x2 x = s ? (f32x2){v.z, v.w} : (f32x2){v.x, v.y};
+            const f32x2 x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
 #pragma unroll
             for (int i = 0; i < C::R; ++i) {
                 const int kl = 4 * i + C::TPL - w;
-                if (kl >= 0 && kl < C::TPL) acc[i] = __builtin_elementwise_fma((f32x2){h[kl], h[kl]}, x, acc[i]);
+                if (kl >= 0 && kl < C::TPL) {
+                    if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
+                    else pk_fma_lo(acc[i], hp[kl >> 1], x);
+                }
             }
         }
     }
@@ -282,7 +308,7 @@ __device__ __forceinline__ void write_history(const DecimTileCtx<NT> &c, float *
 
 #define SXFIR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// ABL (profiling builds only; 3 = packed-FMA arithmetic): 0 = the real kernel, 1 = stage + store but no FIR arithmetic
+// ABL (profiling builds only; 3 = scalar v_fmac_f32 arithmetic instead of v_pk_fma_f32, same bits): 0 = the real kernel, 1 = stage + store but no FIR arithmetic
 // (memory side alone), 2 = FIR arithmetic on whatever LDS holds, no staging (compute side alone).
 // S32IN: the input (and the history) are S32_LE I2S wire words instead of CF32.
 template <int NT, bool DBUF, int ABL = 0, bool S32IN = false>
@@ -371,9 +397,9 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             } else if constexpr (ABL == 19) {
                 compute_tile<NT, false, 8, 2>(c, tile, win0, h, lds);   // no staging, 1/8 of the LDS reads, all FMAs
             } else if constexpr (ABL == 3) {
-                compute_tile_pk<NT>(c, tile, win0, h, lds);
+                compute_tile<NT, S32IN>(c, tile, win0, h, lds);         // one v_fmac_f32 per FMA (A/B against the packed form)
             } else if constexpr (ABL != 1) {
-                compute_tile<NT, S32IN>(c, tile, win0, h, lds);
+                compute_tile_pk<NT, S32IN>(c, tile, win0, h, lds);
             } else {
                 const f32x4 v0 = win0[0], v1 = win0[17];
                 const long long m = (long long)tile * C::TILE_OUT + 8 * c.g + 4 * c.p;
@@ -409,7 +435,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             } else {
                 SXFIR_WAIT_VMCNT(0);
             }
-            compute_tile<NT>(c, tile, win0, h, lds);
+            compute_tile_pk<NT>(c, tile, win0, h, lds);
             if ((tile += tile_step) >= tile_end) break;
             // odd phase: compute from buffer 1, prefetch into buffer 0
             if (tile + tile_step < tile_end) {
@@ -418,7 +444,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
             } else {
                 SXFIR_WAIT_VMCNT(0);
             }
-            compute_tile<NT>(c, tile, win1, h, lds + C::BUF_SLOTS);
+            compute_tile_pk<NT>(c, tile, win1, h, lds + C::BUF_SLOTS);
             if ((tile += tile_step) >= tile_end) break;
         }
     }

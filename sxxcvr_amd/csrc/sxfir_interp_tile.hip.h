@@ -75,10 +75,12 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
     const float *hist = a.hist + 2 * a.hist_stride * ch;
     float *out = a.out + 2 * a.out_stride * ch;
 
-    // lane taps: h[4*jj + rr] = taps[(16p + jj)*L + 4c + rr]
-    float h[64];
+    // lane taps: h[4*jj + rr] = taps[(16p + jj)*L + 4c + rr], held as pairs hp[k] = {h[2k], h[2k+1]}
+    f32x2 hp[32];          // 64-bit register pairs for the packed FMAs
 #pragma unroll
-    for (int k = 0; k < 64; ++k) h[k] = a.taps[(16 * p + (k >> 2)) * L + 4 * c + (k & 3)];
+    for (int k = 0; k < 32; ++k)
+        hp[k] = (f32x2){a.taps[(16 * p + (k >> 1)) * L + 4 * c + 2 * (k & 1)],
+                        a.taps[(16 * p + (k >> 1)) * L + 4 * c + 2 * (k & 1) + 1]};
 
     // window: samples q0 + 4g - 16p - 16 + w, w = 0..19  ->  LDS sample index (+32) 4g - 16p + 16 + w
     const f32x4 *win = lds + (2 * g - 8 * p + 8);
@@ -119,33 +121,38 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 #pragma unroll 1
         for (int kt = 0; kt < C::KT; ++kt) {
         const f32x4 *wk = win + kt * (C::QT / 2);
-        // ---- compute: window sample w meets input qi at row jj = qi + 16 - w ---
-        float ai[4][4], aq[4][4];
+        // ---- compute: window sample w meets input qi at row jj = qi + 16 - w.  The I and Q FMAs of a
+        // (tap, sample) pair are one v_pk_fma_f32 (sxfir_decim_tile.hip.h: same bits, less power).
+        f32x2 acc[4][4];
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) { ai[qi][rr] = 0.0f; aq[qi][rr] = 0.0f; }
+            for (int rr = 0; rr < 4; ++rr) acc[qi][rr] = (f32x2){0.0f, 0.0f};
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             const f32x4 v = wk[t];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int w = 2 * t + s;
-                const float xi = s ? v.z : v.x;
-                const float xq = s ? v.w : v.y;
+                const f32x2 x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
 #pragma unroll
                 for (int qi = 0; qi < 4; ++qi) {
                     const int jj = qi + 16 - w;
                     if (jj >= 0 && jj < 16) {
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
-                            ai[qi][rr] = __builtin_fmaf(h[4 * jj + rr], xi, ai[qi][rr]);
-                            aq[qi][rr] = __builtin_fmaf(h[4 * jj + rr], xq, aq[qi][rr]);
+                            if (rr & 1) pk_fma_hi(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
+                            else pk_fma_lo(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
                         }
                     }
                 }
             }
         }
+        float ai[4][4], aq[4][4];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { ai[qi][rr] = acc[qi][rr].x; aq[qi][rr] = acc[qi][rr].y; }
 
         // ---- reduce over p: low half-wave keeps inputs 0-1, high half-wave inputs 2-3
         float oi[2][4], oq[2][4];
