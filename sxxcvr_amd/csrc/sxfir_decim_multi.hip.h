@@ -251,58 +251,40 @@ decim_multi_kernel(const DecimMultiArgs a)
         SXFIR_PHASE(2)
 
         // ---- compute: window sample w meets output i at local tap kl = 4*i + TPL - 1 - w ---
-        // CF32: the I and Q FMAs of a (tap, sample) pair are one v_pk_fma_f32 (sxfir_decim_tile.hip.h:
-        // same bits, half the instructions, measurably less power).  CF16: scalar FMAs, which hipcc
-        // turns into v_fma_mix_f32 with the half->float conversion folded in.
-        float ai[8], aq[8];
-        if constexpr (!HALF) {
-            f32x2 acc[8];
+        // The I and Q FMAs of a (tap, sample) pair are one v_pk_fma_f32 (sxfir_decim_tile.hip.h: same
+        // bits, half the instructions, measurably less power).  CF16: each sample is converted once
+        // (two v_cvt_f32_f16, SDWA picks the half) into the pair the packed FMAs take.
+        constexpr int SPC = HALF ? 4 : 2;                  // samples per 16-byte chunk
+        f32x2 acc[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = (f32x2){0.0f, 0.0f};
-            if constexpr (ABL != 1 && ABL != 4)
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x2){0.0f, 0.0f};
+        if constexpr (ABL != 1 && ABL != 4)
 #pragma unroll
-            for (int t = 0; t < C::WCH; ++t) {
-                const f32x4 v = win[t + t / C::PADP];
+        for (int t = 0; t < C::WCH; ++t) {
+            const f32x4 v = win[t + t / C::PADP];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int w = 2 * t + s;
-                    const f32x2 x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int kl = 4 * i + C::TPL - 1 - w;
-                        if (kl >= 0 && kl < C::TPL) {
-                            if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
-                            else pk_fma_lo(acc[i], hp[kl >> 1], x);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { ai[i] = acc[i].x; aq[i] = acc[i].y; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { ai[i] = 0.0f; aq[i] = 0.0f; }
-            if constexpr (ABL != 1 && ABL != 4)
-#pragma unroll
-            for (int t = 0; t < C::WCH; ++t) {
-                const f32x4 v = win[t + t / C::PADP];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int w = 4 * t + s;
+            for (int s = 0; s < SPC; ++s) {
+                const int w = SPC * t + s;
+                f32x2 x;
+                if constexpr (HALF) {
                     const unsigned bits = __float_as_uint(s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)));
-                    const float xi = half_bits_to_float(bits & 0xFFFFu);
-                    const float xq = half_bits_to_float(bits >> 16);
+                    x = (f32x2){half_bits_to_float(bits & 0xFFFFu), half_bits_to_float(bits >> 16)};
+                } else {
+                    x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
+                }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int kl = 4 * i + C::TPL - 1 - w;
-                        if (kl >= 0 && kl < C::TPL) {
-                            ai[i] = __builtin_fmaf(h[kl], xi, ai[i]);
-                            aq[i] = __builtin_fmaf(h[kl], xq, aq[i]);
-                        }
+                for (int i = 0; i < 8; ++i) {
+                    const int kl = 4 * i + C::TPL - 1 - w;
+                    if (kl >= 0 && kl < C::TPL) {
+                        if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
+                        else pk_fma_lo(acc[i], hp[kl >> 1], x);
                     }
                 }
             }
         }
+        float ai[8], aq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ai[i] = acc[i].x; aq[i] = acc[i].y; }
 
         if constexpr (ABL == 3) asm volatile("" ::"v"(ai[0]), "v"(aq[7]));   // the arithmetic ends here
         SXFIR_PHASE(3)
