@@ -162,9 +162,16 @@ decim_multi_kernel(const DecimMultiArgs a)
     const int cc0 = C::PADP * (G - (C::JR / 8) * p + 4 - C::JR / 8);   // first window chunk (multiple of PADP)
     const f32x4 *win = lds + (c * C::SUBSTRIDE + C::skew(c) + cc0 + cc0 / C::PADP);
 
+    // Tile schedule: in pass i the n_groups workgroups cover the consecutive tiles [i*G, (i+1)*G), dealt so
+    // that the workgroups of one XCD (blockIdx % 8 shares an XCD and its L2; speed only) hold a contiguous
+    // block of them: a tile's 31 halo rows were then fetched by the same XCD moments ago and hit its L2
+    // instead of going to HBM a second time (TCC_MISS: 24 % more reads than algorithmic at /16 and /32
+    // before this, none after).
+    const int NG = a.n_groups;
+    const int first_tile = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     // fused history carry-over: the last wave of the workgroup that owns the last tile copies the
     // tail of (hist ++ in) into the plan's other history buffer
-    if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && ww == W - 1) {
+    if (first_tile == (a.n_tiles - 1) % NG && ww == W - 1) {
         char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)C::SBYTES * a.hist_stride * ch;
         for (int j = lane; j < C::NT; j += 64) {
             const long long s = a.n_in - C::NT + j;
@@ -202,7 +209,7 @@ decim_multi_kernel(const DecimMultiArgs a)
         ph[k] += t_now - tk; \
         tk = t_now; \
     }
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
+    for (int tile = first_tile; tile < a.n_tiles; tile += NG) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         // samples of the tile: [D*(M0-32)+1, D*(M0+TILE_OUT-1)]; interior = all inside `in`
         const bool interior = (M0 >= 32) && (D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1);
