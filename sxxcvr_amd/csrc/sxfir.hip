@@ -22,7 +22,7 @@
 #define SXFIR_MULTI_VARIANTS(X) \
     X(4, 1, false, 2) X(4, 4, false, 2) X(8, 1, false, 2) X(8, 2, false, 2) X(8, 4, false, 2) X(16, 2, false, 2) \
     X(16, 4, false, 2) X(32, 4, false, 2) X(32, 8, false, 2) \
-    X(4, 1, true, 2) X(8, 1, true, 2) X(8, 2, true, 2) X(16, 2, true, 2) X(16, 4, true, 2) X(32, 4, true, 2) \
+    X(4, 1, true, 2) X(8, 1, true, 2) X(8, 2, true, 2) X(8, 4, true, 2) X(16, 2, true, 2) X(16, 4, true, 2) X(32, 4, true, 2) \
     X(32, 8, true, 2) \
     X(4, 2, false, 4) X(8, 2, false, 4) X(8, 4, false, 4) X(16, 4, false, 4) X(16, 8, false, 4) X(32, 8, false, 4) \
     X(32, 16, false, 4) \
@@ -205,7 +205,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // waves per workgroup of the multi-column kernel, measured (tools/kbench.py, KB_D, specs "w1".."w8"):
     // the choice that brings the LDS image down to 10 KiB per wave (16 waves per CU) while the 31-row
     // halo stays a small part of the staging
-    p->multi_waves = ratio <= 4 ? 1 : (ratio == 8 ? 2 : 4);
+    p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
     if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
         if (strcmp(v, "mu") == 0 && mode == SXFIR_DECIMATE && fmt == SXFIR_CF32 && ratio == 4 && ntaps == 128) {
@@ -234,6 +234,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             return fail(SXFIR_EUNSUPPORTED, "no multi-column kernel for ratio %d with %d waves per workgroup", ratio, W);
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0) p->occ_multi = nb;
+        // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's
+        // prologue (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16
+        p->oversub = 8;
         if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
         if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
     }
