@@ -240,6 +240,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
         if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
     }
+    if (p->itile_capable) {
+        p->oversub = 4;              // measured flat between 2 and 16 (tools/ibench.py)
+        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
+    }
     if (p->tile_capable) {
         int nb = 0;
         const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>

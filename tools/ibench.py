@@ -11,8 +11,9 @@ y = torch.empty(n * L, dtype=torch.complex64, device="cuda")
 taps = sxxcvr_amd.design_lowpass(32 * L, L, 8.0, float(L))
 for name, k in (("tiled", KERNEL_TILED), ("generic", KERNEL_GENERIC)):
     p = sxxcvr_amd.Resampler(INTERPOLATE, taps, L); p.set_kernel(k)
-    for _ in range(3): p.process(x, out=y)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); iters = 20
+    fast = k == KERNEL_TILED
+    for _ in range(100 if fast else 3): p.process(x, out=y)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); iters = 100 if fast else 10
     for _ in range(iters): p.process(x, out=y)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
     print("%-8s L=%d  %.4f ms  in %.1f GS/s  out %.1f GS/s  %.0f GB/s algorithmic (%.3f of 8 TB/s)" % (
