@@ -1,0 +1,93 @@
+"""Host logic behind the Device on the CPU (no GPU): the sample-clock / PCM model that replaces ALSA and the
+SX1255 register shadow, driven by a small C++ probe (tests/host/host_logic_probe.cpp, built with g++ here)
+and compared with hand-evaluated ALSA semantics (SoapySX.cpp:434-517 sets exactly these modes) and with the
+oracle's restatement of the reference's gain / tuning arithmetic."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("host") / "host_logic_probe")
+    csrc = os.path.join(ROOT, "sxxcvr_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           "-I" + os.path.join(csrc, "compat"), os.path.join(ROOT, "tests", "host", "host_logic_probe.cpp"),
+           os.path.join(csrc, "compat", "SoapySDRCompat.cpp"), "-o", exe, "-pthread"]
+    subprocess.run(cmd, check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    rows = {}
+    for line in out.splitlines():
+        key, *vals = line.split()
+        rows.setdefault(key, []).append(vals)
+    return rows
+
+
+def one(rows, key):
+    assert len(rows[key]) == 1
+    return rows[key][0]
+
+
+def test_ring_geometry(probe):
+    """AlsaPcm::configure (SX.cpp:451-466): period defaults to 256, caps at 65536; the ring is the largest
+    multiple of the period within 65536 frames."""
+    want = {0: (256, 65536), 256: (256, 65536), 1000: (1000, 65000), 65536: (65536, 65536), 100000: (65536, 65536)}
+    for period, got_p, got_b in probe["geometry"]:
+        assert (int(got_p), int(got_b)) == want[int(period)]
+
+
+def test_capture_semantics(probe):
+    # running capture PCM: avail = delay = frames the clock produced and nobody read
+    assert one(probe, "capture_after_1000") == ["0", "1000", "1000"]
+    # a read of what is there returns at once and leaves the clock alone
+    assert one(probe, "capture_read") == ["256", "0", "1000"]
+    # a blocking read waits until the last frame exists: appl 256 + 2000 = clock 2256
+    assert one(probe, "capture_blocking_read") == ["2000", "256", "2256"]
+    # NORMAL mode has stop_threshold = boundary (SX.cpp:492-496): it keeps running through an overrun
+    assert one(probe, "capture_overrun_normal") == ["0", "70000", "1"]
+    # snd_pcm_forward moves the application pointer only
+    assert one(probe, "capture_forward") == ["5000", "7256"]
+
+
+def test_link_mode_semantics(probe):
+    """LINK mode (SX.cpp:36-43, :497-501): linked PCMs start on the first TX write and stop together on xrun."""
+    # prepared playback ring takes at most one ring; the write starts both PCMs
+    assert one(probe, "link_first_write") == ["65536", "0", "1", "1"]
+    # playback: delay = written - played, avail = ring - delay;  capture: avail = delay = produced
+    assert one(probe, "link_tx_after_1000") == ["1000", "64536"]
+    assert one(probe, "link_rx_after_1000") == ["1000", "1000"]
+    # the ring runs dry: -EPIPE (-32) on both, both stopped
+    assert one(probe, "link_underrun") == ["-32", "1", "1"]
+    assert one(probe, "link_rx_after_xrun") == ["-32"]
+    # drop + prepare + reset (SX.cpp:419-432)
+    assert one(probe, "link_after_reset") == ["1", "0", "0"]
+
+
+def test_register_shadow_against_oracle(probe, oracle):
+    """Tuning words and the LNA/PGA and DAC/MIXER splits are the reference's arithmetic (SX.cpp:1236-1272,
+    :1370-1394) as restated by the oracle."""
+    for clock, f, tuned, word in probe["tune"]:
+        want_f, want_w = oracle.quantize_frequency(float(clock), float(f))
+        assert int(word) == want_w and abs(float(tuned) - want_f) < 1e-3
+    for key, direction in (("rxgain", 1), ("txgain", 0)):          # SOAPY_SDR_RX = 1, SOAPY_SDR_TX = 0
+        for g, coarse, fine, _reg in probe[key]:
+            want = oracle.gain_split(direction, float(g))
+            assert (float(coarse), float(fine)) == want, (key, g)
+    # register image after power-up: RX, TX and PA driver enabled in reg 0, default tuning word 433.92 MHz
+    boot = [int(v) for v in one(probe, "boot")]
+    assert boot[0] == 0x0F and boot[0x11] == 3                      # status: both PLLs locked (SX.cpp:635-636)
+    f, w = oracle.quantize_frequency(38.4e6, 433.92e6)
+    assert (boot[1] << 16) | (boot[2] << 8) | boot[3] == w and (boot[4] << 16) | (boot[5] << 8) | boot[6] == w
+    ant = one(probe, "antenna")
+    assert ant[:2] == ["DLB", "NONE"] and int(ant[2]) & 0x0C == 0x0C and int(ant[3]) & 0x08 == 0
+    assert one(probe, "burst_over_end") == ["Invalid", "register", "address"]
+
+
+def test_tick_conversion_against_oracle(probe, oracle):
+    for rate, t, ns, back in probe["ticks"]:
+        assert int(ns) == oracle.ticks_to_time_ns(int(t), float(rate))
+        assert int(back) == int(t)                                  # round trip is exact at every table rate
