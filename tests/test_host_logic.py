@@ -91,3 +91,24 @@ def test_tick_conversion_against_oracle(probe, oracle):
     for rate, t, ns, back in probe["ticks"]:
         assert int(ns) == oracle.ticks_to_time_ns(int(t), float(rate))
         assert int(back) == int(t)                                  # round trip is exact at every table rate
+
+
+def test_gpu_chains_over_fake_backend(oracle, tmp_path):
+    """GpuChains.hpp (RX batching + read-ahead + jump handling + channel layout, TX write-behind + silence +
+    sink-ring wrap) on the CPU: linked against tests/host/fake_sxfir.cpp, a TEST-ONLY implementation of the C ABI
+    in which the oracle does the arithmetic.  Every sample must equal one direct oracle pass over the stream."""
+    exe = str(tmp_path / "chains_probe")
+    csrc = os.path.join(ROOT, "sxxcvr_amd", "csrc")
+    odir = os.path.join(ROOT, "oracle")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-I" + odir,
+           os.path.join(ROOT, "tests", "host", "chains_probe.cpp"), os.path.join(ROOT, "tests", "host", "fake_sxfir.cpp"),
+           "-o", exe, "-L" + odir, "-lsxoracle", "-Wl,-rpath," + odir, "-pthread"]
+    subprocess.run(cmd, check=True)
+    run = subprocess.run([exe], capture_output=True, text=True)
+    lines = run.stdout.splitlines()
+    assert run.returncode == 0 and lines[-1] == "bad 0", run.stdout[-2000:]
+    assert all(l.split()[1] == "0" for l in lines if " mismatches " in l)
+    assert "tx_backwards refused" in lines
+    # ten sequential reads (154k samples per channel) in a handful of batched passes, not one per read
+    launches = int([l for l in lines if l.startswith("rx_launches")][0].split()[1])
+    assert launches <= 12
