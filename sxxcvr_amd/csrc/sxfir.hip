@@ -171,8 +171,13 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         p->multi_capable = (ntaps == 32 * ratio) &&
                            ((fmt == SXFIR_CF32 && (ratio == 8 || ratio == 16 || ratio == 32)) ||
                             (fmt == SXFIR_CF16 && (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32)));
+        // Numeric contract: two row halves and column groups of 4 when the shape allows the
+        // adjacent-pair trees, i.e. whole, even rows and a power-of-two number (<= 32) of column groups;
+        // otherwise one chain over all taps.
         const int jt = (ntaps + ratio - 1) / ratio;
-        if (ntaps % ratio == 0 && ratio % 4 == 0 && jt % 2 == 0) {
+        const int ncol4 = ratio / 4;
+        const bool pow2_cols = ratio % 4 == 0 && (ncol4 & (ncol4 - 1)) == 0 && ncol4 <= 32;
+        if (ntaps % ratio == 0 && pow2_cols && jt % 2 == 0) {
             p->jsplit = 2;
             p->cw = 4;
         } else {
