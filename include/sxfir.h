@@ -168,8 +168,8 @@ int sxfir_time_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_
 int sxfir_debug_clock(sxfir_plan *plan, double *mhz);
 
 /* Diagnostic builds only (SXFIR_ABLATE=3 on the multi-column decimator): copies the raw per-wave stamp
- * records of the last launch (5 x uint64 each: tiles, cycles staging, waiting for data, arithmetic,
- * reduction + store + barrier) to `host`; returns the number of records through *n_records. */
+ * records of the last launch (5 x uint64 each: tiles, cycles in reduction + store, waiting for data,
+ * arithmetic, barrier + issuing the next tile's DMAs) to `host`; returns the number of records through *n_records. */
 int sxfir_debug_stamps(sxfir_plan *plan, unsigned long long *host, size_t capacity_records, size_t *n_records);
 
 #ifdef __cplusplus

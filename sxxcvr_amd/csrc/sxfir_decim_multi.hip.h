@@ -209,16 +209,13 @@ decim_multi_kernel(const DecimMultiArgs a)
         ph[k] += t_now - tk; \
         tk = t_now; \
     }
-    for (int tile = first_tile; tile < a.n_tiles; tile += NG) {
+    // HBM -> LDS for one tile: the W waves share the NI DMA instructions
+    auto stage = [&](int tile) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         // samples of the tile: [D*(M0-32)+1, D*(M0+TILE_OUT-1)]; interior = all inside `in`
         const bool interior = (M0 >= 32) && (D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1);
         const long long s_base = D * (M0 - 31) - PBIAS;
         const char *base = in + C::SBYTES * s_base;
-
-        __syncthreads();                                   // everyone is done reading the previous tile
-        SXFIR_PHASE(4)
-        // ---- stage: the W waves share the NI DMA instructions -------------------
 #pragma unroll
         for (int i0 = 0; i0 < NIW; ++i0) {
             const int o = i0 * W + ww;
@@ -252,6 +249,13 @@ decim_multi_kernel(const DecimMultiArgs a)
                 }
             }
         }
+    };
+
+    // Per tile: wait for its data | FIR arithmetic out of LDS | barrier | issue the NEXT tile's DMAs |
+    // reduce and store this tile's outputs (registers only) while those DMAs are in flight.
+    if (first_tile < a.n_tiles) stage(first_tile);
+    for (int tile = first_tile; tile < a.n_tiles; tile += NG) {
+        const long long M0 = (long long)tile * C::TILE_OUT;
         SXFIR_PHASE(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMAs landed ...
         __syncthreads();                                   // ... and everybody else's
@@ -295,6 +299,9 @@ decim_multi_kernel(const DecimMultiArgs a)
 
         if constexpr (ABL == 3) asm volatile("" ::"v"(ai[0]), "v"(aq[7]));   // the arithmetic ends here
         SXFIR_PHASE(3)
+        __syncthreads();                                   // everyone is done reading this tile's image
+        if (tile + NG < a.n_tiles) stage(tile + NG);
+        SXFIR_PHASE(4)
         // ---- reductions, in the order of the numeric contract: adjacent-pair tree over the row
         // ranges p, then over the column groups c.  A swap step halves the outputs a lane holds
         // (v_permlane{16,32}_swap: no LDS); the remaining column bits are butterflies.

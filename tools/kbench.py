@@ -65,8 +65,8 @@ for c, p in zip(configs, plans):
             r = np.frombuffer(buf, dtype=np.uint64, count=5 * nrec.value).reshape(-1, 5).astype(np.float64)
             r = r[r[:, 0] > 0]
             per = r[:, 1:] / r[:, :1]
-            print("config %s phases, mean shader cycles per tile per wave over %d waves: stage %.0f | wait data %.0f | "
-                  "arithmetic %.0f | reduce+store+barrier %.0f | sum %.0f" % (
+            print("config %s phases, mean shader cycles per tile per wave over %d waves: reduce+store %.0f | wait data %.0f | "
+                  "arithmetic %.0f | barrier + issue next tile's DMAs %.0f | sum %.0f" % (
                       c, len(r), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), per.sum(1).mean()))
 for c in configs:
     a = np.array(res[c])
