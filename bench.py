@@ -80,6 +80,45 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def measure_gather(world, y, total_channels, host_collectives, cdev, per_gpu, elapsed, steps):
+    """Exchange step of BASELINE config 4: RCCL gather of every rank's decimated output to rank 0 over xGMI,
+    timed after (and outside) the timed region."""
+    import torch
+    import torch.distributed as dist
+    import sxxcvr_amd.dist as sxdist
+    gather = None
+    if world > 1:
+        # exchange step of config 4: decimated output of every rank to rank 0 over xGMI
+        yg = y.cpu() if host_collectives else y
+        for _ in range(2):
+            sxdist.gather_channels(yg, total_channels, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            sxdist.gather_channels(yg, total_channels, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = (time.perf_counter() - g0) / reps
+        t = torch.tensor([g], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g = float(t.item())
+        peer_bytes = y.numel() * 8
+        gather = {
+            "ms": round(g * 1e3, 3),
+            "bytes_per_peer": peer_bytes,
+            "GB/s_into_root": round(peer_bytes * (world - 1) / g / 1e9, 2),
+            "GB/s_per_link": round(peer_bytes / g / 1e9, 2),
+            "value_with_gather": round(world * per_gpu * 1.0 / (elapsed / steps + g) / 1e6, 1),
+            "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part "
+                    "of value",
+        }
+
+    return gather
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,85 +204,78 @@ def main():
                                        y.stride(0) if nchan_local > 1 else n_in // DECIM, min(max(args.steps, 20), 200), stream)
     achieved = BYTES_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e9
 
+    def emit(gather):
+        """Rank 0 prints the one JSON line."""
+        if rank == 0:
+            ms_per_step = elapsed / args.steps * 1e3
+            value = world * per_gpu * args.steps / elapsed / 1e6
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp) and world == 1 and args.log2_samples == 28:     # measured for exactly this launch
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line = {
+                "metric": "complex MS/s, 128-tap decim-by-4 CF32 (input rate, whole job)",
+                "value": round(value, 1),
+                "unit": "MS/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {
+                    "workload": workload,
+                    "ntaps": NTAPS, "decim": DECIM, "format": "CF32",
+                    "channels_per_gpu": nchan_local, "input_samples_per_gpu": per_gpu,
+                    "output_MS/s": round(value / DECIM, 1),
+                    "per_gpu_MS/s": round(value / world, 1),
+                },
+                "roofline": {
+                    "bound": "hbm",
+                    "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic,
+                    "kernel": "sxfir::decim4_tile_kernel<128>",
+                    "kernel_ms": round(kernel_ms, 4),
+                    "algorithmic_bytes_per_launch": int(BYTES_PER_INPUT_SAMPLE * per_gpu),
+                    "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                    "fp32_TFLOPs": round(FLOP_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e12, 2),
+                },
+            }
+            if gather is not None:
+                line["gather"] = gather
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(line), flush=True)
+
+    # The exchange step (config 4's gather over xGMI) is reported beside `value`, never inside it, and must
+    # not be able to take the line down with it: errors are recorded, and a watchdog prints the line without
+    # the gather figures if the collective does not come back.
     gather = None
     if world > 1:
-        # exchange step of config 4: decimated output of every rank to rank 0 over xGMI
-        yg = y.cpu() if host_collectives else y
-        for _ in range(2):
-            sxdist.gather_channels(yg, total_channels, dst=0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            sxdist.gather_channels(yg, total_channels, dst=0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g = (time.perf_counter() - g0) / reps
-        t = torch.tensor([g], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        g = float(t.item())
-        peer_bytes = y.numel() * 8
-        gather = {
-            "ms": round(g * 1e3, 3),
-            "bytes_per_peer": peer_bytes,
-            "GB/s_into_root": round(peer_bytes * (world - 1) / g / 1e9, 2),
-            "GB/s_per_link": round(peer_bytes / g / 1e9, 2),
-            "value_with_gather": round(world * per_gpu * 1.0 / (elapsed / args.steps + g) / 1e6, 1),
-            "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part "
-                    "of value",
-        }
+        import threading
+        finished = threading.Event()
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * per_gpu * args.steps / elapsed / 1e6
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and args.log2_samples == 28:     # measured for exactly this launch
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "complex MS/s, 128-tap decim-by-4 CF32 (input rate, whole job)",
-            "value": round(value, 1),
-            "unit": "MS/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": workload,
-                "ntaps": NTAPS, "decim": DECIM, "format": "CF32",
-                "channels_per_gpu": nchan_local, "input_samples_per_gpu": per_gpu,
-                "output_MS/s": round(value / DECIM, 1),
-                "per_gpu_MS/s": round(value / world, 1),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "kernel": "sxfir::decim4_tile_kernel<128>",
-                "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": int(BYTES_PER_INPUT_SAMPLE * per_gpu),
-                "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                "fp32_TFLOPs": round(FLOP_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e12, 2),
-            },
-        }
-        if gather is not None:
-            line["gather"] = gather
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        def watchdog():
+            if not finished.wait(240.0):
+                emit({"error": "gather did not complete within 240 s"})
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            gather = measure_gather(world, y, total_channels, host_collectives, cdev, per_gpu, elapsed, args.steps)
+        except Exception as e:
+            gather = {"error": "%s: %s" % (type(e).__name__, e)}
+        finished.set()
+    emit(gather)
 
     if world > 1:
         dist.barrier()
