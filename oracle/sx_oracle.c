@@ -281,14 +281,14 @@ static void decim_f32_range(const float *h, int ntaps, int D, int jsplit, int cw
                 for (int b = 0; b < BLK; b++) { pi[p][b] = ai[b]; pq[p][b] = aq[b]; }
             }
             for (int b = 0; b < nb; b++) {
-                float ti[SXO_MAX_GROUPS], tq[SXO_MAX_GROUPS];
+                float ti[SXO_MAX_GROUPS] = {0.0f}, tq[SXO_MAX_GROUPS] = {0.0f};
                 for (int p = 0; p < jsplit; p++) { ti[p] = pi[p][b]; tq[p] = pq[p][b]; }
                 ci[c][b] = tree_sum(ti, jsplit);
                 cq[c][b] = tree_sum(tq, jsplit);
             }
         }
         for (int b = 0; b < nb; b++) {
-            float ti[SXO_MAX_GROUPS], tq[SXO_MAX_GROUPS];
+            float ti[SXO_MAX_GROUPS] = {0.0f}, tq[SXO_MAX_GROUPS] = {0.0f};
             for (int c = 0; c < ncol; c++) { ti[c] = ci[c][b]; tq[c] = cq[c][b]; }
             y[2 * (m + b - m0)] = tree_sum(ti, ncol);
             y[2 * (m + b - m0) + 1] = tree_sum(tq, ncol);
