@@ -169,7 +169,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                            (fmt == SXFIR_S32 && ratio == 4 && ntaps == 128));
         // multi-column kernel: 32 taps per phase; CF32 at ratio 8/16/32, CF16 at ratio 4/8/16/32
         p->multi_capable = (ntaps == 32 * ratio) &&
-                           ((fmt == SXFIR_CF32 && (ratio == 8 || ratio == 16 || ratio == 32)) ||
+                           (((fmt == SXFIR_CF32 || fmt == SXFIR_S32) && (ratio == 8 || ratio == 16 || ratio == 32)) ||
                             (fmt == SXFIR_CF16 && (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32)));
         // Numeric contract: two row halves and column groups of 4 when the shape allows the
         // adjacent-pair trees, i.e. whole, even rows and a power-of-two number (<= 32) of column groups;
@@ -225,6 +225,11 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
         p->jsplit = p->multi_ps;
         // resident workgroups per CU: LDS is the limiter (checked against the occupancy API below)
+        if (fmt == SXFIR_S32) {          // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
+            p->multi_waves = 4;
+            p->multi_ps = 2;
+            p->jsplit = 2;
+        }
         const int W = p->multi_waves;
         int nb = 0;
         const void *k = nullptr;
@@ -444,6 +449,16 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             a.stamps = (unsigned long long *)p->stamps_dev;
         }
         const int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps) + 100000 * p->ablate;
+        if (p->fmt == SXFIR_S32) {
+            switch (p->ratio) {
+            case 8: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL((sxfir::decim_multi_kernel<16, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
+            }
+            HIPCHECK(hipGetLastError());
+            *history_done = true;
+            return SXFIR_OK;
+        }
         switch (key) {
         case 100801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 1>), grid, dim3(64), 0, st, a); break;
         case 200801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 2>), grid, dim3(64), 0, st, a); break;

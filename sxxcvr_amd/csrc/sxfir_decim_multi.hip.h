@@ -124,7 +124,9 @@ __device__ __forceinline__ unsigned pack_half2(float i, float q)
 
 // ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
 // kernel with s_memtime stamps around its phases (a.stamps)
-template <int D, int W, bool HALF = false, int ABL = 0, int PS = 2>
+// S32IN: the input (and the history) are S32_LE I2S wire words instead of CF32 (convert_rx_buffer,
+// SoapySX.cpp:103-112, folded in: int->float on load, the exact 2^-31 scale in the taps).
+template <int D, int W, bool HALF = false, int ABL = 0, int PS = 2, bool S32IN = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(DecimMulti<D, W, HALF, PS>::MIN_WAVES, 8))) void
 decim_multi_kernel(const DecimMultiArgs a)
 {
@@ -152,7 +154,10 @@ decim_multi_kernel(const DecimMultiArgs a)
     // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(JR*p + jj) + 4c + rr
     float h[C::TPL];
 #pragma unroll
-    for (int kl = 0; kl < C::TPL; ++kl) h[kl] = a.taps[D * (C::JR * p + (kl >> 2)) + 4 * c + (kl & 3)];
+    for (int kl = 0; kl < C::TPL; ++kl) {
+        const float t = a.taps[D * (C::JR * p + (kl >> 2)) + 4 * c + (kl & 3)];
+        h[kl] = S32IN ? __fmul_rn(t, 4.656612873077393e-10f) : t;      // a power of two commutes with the FMA
+    }
     f32x2 hp[C::TPL / 2];      // the same taps as 64-bit register pairs for the packed FMAs (CF32)
 #pragma unroll
     for (int k = 0; k < C::TPL / 2; ++k) hp[k] = (f32x2){h[2 * k], h[2 * k + 1]};
@@ -282,6 +287,7 @@ decim_multi_kernel(const DecimMultiArgs a)
                     x = (f32x2){half_bits_to_float(bits & 0xFFFFu), half_bits_to_float(bits >> 16)};
                 } else {
                     x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
+                    if constexpr (S32IN) x = (f32x2){(float)__float_as_int(x.x), (float)__float_as_int(x.y)};
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {

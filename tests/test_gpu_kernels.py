@@ -211,3 +211,26 @@ def test_s32_wire_front_and_back_end(oracle):
         assert np.array_equal(got, want), "S32 interpolator kernel %d" % kern
     keyed = (want[0::2] & 3) == 3
     assert keyed.any() and (~keyed).any()
+
+
+@pytest.mark.parametrize("D,n_in", [(8, (1 << 16) + 8 * 5), (16, 50000), (32, 4096 * 5 + 32 * 3)])
+def test_s32_wire_words_through_the_multi_column_kernel(oracle, D, n_in):
+    """f-3 at the config 3 / config 5 shapes: the /8, /16, /32 LDS-tiled decimator reads S32_LE I2S wire words
+    (convert_rx_buffer, SX.cpp:103-112, inside the kernel).  Bit-exact against oracle conversion + oracle FIR,
+    across a call boundary, and equal to the generic kernel."""
+    from sxxcvr_amd.resampler import KERNEL_GENERIC, KERNEL_TILED
+    n_in -= n_in % D
+    rng = np.random.default_rng(D)
+    words = rng.integers(-2 ** 31, 2 ** 31, size=2 * (n_in + 2048), dtype=np.int64).astype(np.int32)
+    words[:6] = [2 ** 31 - 1, -2 ** 31, 1, -1, 0, 0x7FFFFF80]
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    ref = None
+    for kern in (KERNEL_TILED, KERNEL_GENERIC):
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="S32")
+        plan.set_kernel(kern)
+        if ref is None:
+            ref = oracle.decim_f32(h, D, oracle.convert_rx(words), *plan.contract)
+        wg = to_gpu(words.reshape(-1, 2))
+        y1 = to_cpu(plan.process(wg[:n_in].clone()))
+        y2 = to_cpu(plan.process(wg[n_in:].clone()))
+        assert_bit_exact(np.concatenate([y1, y2]), ref, "S32 /%d kernel %d" % (D, kern))
