@@ -28,7 +28,7 @@
     X(32, 16, false, 4) \
     X(4, 2, true, 4) X(8, 4, true, 4) X(16, 8, true, 4) X(32, 8, true, 4)
 // profiling modes of decim4_tile_kernel<128> (its ABL template argument)
-#define SXFIR_TILE_ABLATIONS(X) X(1) X(2) X(3) X(7) X(8) X(9) X(10) X(11) X(12) X(17) X(18) X(19)
+#define SXFIR_TILE_ABLATIONS(X) X(1) X(2) X(3) X(7) X(8) X(9) X(10) X(11) X(12) X(17) X(18) X(19) X(20) X(21) X(22)
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_sgpr.hip.h"

@@ -68,10 +68,12 @@ struct DecimTile4 {
     static_assert(NT % 64 == 0, "tile kernel needs NT % 64 == 0");
 };
 
+// AUX = cache policy bits of the load (0 = default, 2 = nt: streaming, 1 = sc0, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void *gsrc, void *ldst)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, AUX);
 }
 
 // v_permlane32_swap_b32 vdst, src (gfx950): lanes 32-63 of vdst <-> lanes 0-31
@@ -99,7 +101,7 @@ struct DecimTileCtx {
 // HBM -> LDS for one tile, no VGPR round trip.  Slot q = 64*i + lane of the
 // buffer holds logical chunk q - (q+1)/17 (a pad slot re-loads its left
 // neighbour and is never read).
-template <int NT>
+template <int NT, int AUX = 0>
 __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, f32x4 *buf)
 {
     using C = DecimTile4<NT>;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, 
             // works per basic block), which is what selects the SGPR-base + 32-bit VGPR offset form
             unsigned b = c.boff[i];
             asm volatile("" : "+v"(b));
-            glds16(src + b, buf + 64 * i);
+            glds16<AUX>(src + b, buf + 64 * i);
         }
     } else {
 #pragma unroll
@@ -379,7 +381,10 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     }
     if constexpr (!DBUF) {
         for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
-            if constexpr (ABL != 2 && ABL != 12 && (ABL < 17 || ABL > 19)) stage_tile<NT>(c, tile, lds);
+            if constexpr (ABL == 20) stage_tile<NT, 2>(c, tile, lds);          // nt loads
+            else if constexpr (ABL == 21) stage_tile<NT, 16>(c, tile, lds);    // sc1 loads
+            else if constexpr (ABL == 22) stage_tile<NT, 1>(c, tile, lds);     // sc0 loads
+            else if constexpr (ABL != 2 && ABL != 12 && (ABL < 17 || ABL > 19)) stage_tile<NT>(c, tile, lds);
             // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
             SXFIR_WAIT_VMCNT(0);
             if constexpr (ABL == 7) {
