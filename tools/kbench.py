@@ -22,7 +22,9 @@ n = (1 << log2n) // nchan
 dt = torch.complex64 if FMT == "CF32" else torch.int32
 x = torch.empty((nchan, n), dtype=dt, device="cuda")
 sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=FMT)
-y = torch.empty((nchan, n // D), dtype=dt, device="cuda")
+yoff = int(os.environ.get("KB_YOFF", "0"))          # output buffer displaced by this many bytes (HBM channel phase probe)
+ybase = torch.empty(nchan * (n // D) * (8 if FMT == "CF32" else 4) + yoff + 64, dtype=torch.uint8, device="cuda")
+y = ybase[yoff:yoff + nchan * (n // D) * (8 if FMT == "CF32" else 4)].view(dt).view(nchan, n // D)
 taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched in configs:
