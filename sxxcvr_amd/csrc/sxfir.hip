@@ -28,7 +28,7 @@
     X(32, 16, false, 4) \
     X(4, 2, true, 4) X(8, 4, true, 4) X(16, 8, true, 4) X(32, 8, true, 4)
 // profiling modes of decim4_tile_kernel<128> (its ABL template argument)
-#define SXFIR_TILE_ABLATIONS(X) X(1) X(2) X(3) X(7) X(8) X(9) X(10) X(11) X(12) X(17) X(18) X(19) X(20) X(21) X(22)
+#define SXFIR_TILE_ABLATIONS(X) X(1) X(2) X(3) X(7) X(8) X(9) X(10) X(11) X(12) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_sgpr.hip.h"
@@ -513,6 +513,18 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.n_waves = (int)per_chan;
         a.sched = p->sched;
+        {
+            const int W = (int)per_chan, last = (int)n_tiles - 1;
+            a.w8 = (W % 8 == 0) ? W / 8 : 0;
+            a.run_base = (int)(n_tiles / W);
+            a.run_extra = (int)(n_tiles % W);
+            if (p->sched == 1) {
+                a.hist_wave = a.run_base >= 1 ? W - 1 : last;           // owner of the last contiguous run
+            } else {
+                const int t = last % W;                                  // first tile of the owner's sequence
+                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+            }
+        }
         a.stamps = nullptr;
         if (p->ablate == 11 || p->ablate == 12) {
             // diagnostic build: one {cycles, ticks} pair per wave, printed by sxfir_debug_clock()

@@ -46,7 +46,11 @@ struct DecimTileArgs {
     long long hist_stride;
     int n_tiles;            // tiles per channel
     int n_waves;            // waves (workgroups) per channel
-    int sched;              // 0 = strided passes (XCD-blocked), 1 = one contiguous run per wave
+    int sched;              // 0 = strided passes (XCD-blocked), 1 = one contiguous run per wave, 2 = plain strided passes
+    // schedule constants worked out on the host (no integer divisions in the wave's prologue)
+    int w8;                 // n_waves / 8 when n_waves is a multiple of 8, else 0 (sched 0)
+    int run_base, run_extra;    // n_tiles / n_waves, n_tiles % n_waves (sched 1)
+    int hist_wave;          // the wave whose tiles include the last one: it carries the history over
     unsigned long long *stamps;   // diagnostic builds only (ABL 11/12): per-wave {shader cycles, 100 MHz ticks}
 };
 
@@ -337,11 +341,35 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
         c.boff[i] = 16u * off;
     }
 
-    // taps of this lane's half, h[kl] = taps[TPL*p + kl]
+    // taps of this lane's half, h[kl] = taps[TPL*p + kl].  All lanes of a half hold the same 64 values:
+    // loading them per lane costs 16 global_load_dwordx4 that each return 1 KiB (16 KiB per wave, more
+    // than a tile).  Instead NT/4 lanes DMA the NT taps into the still empty tile image once and every lane
+    // reads its half back with TPL/4 broadcast ds_read_b128 (2.8 % of the kernel time at 4 tiles per wave).
     float h[C::TPL];
+    auto load_taps = [&]() __attribute__((always_inline)) {
+        if constexpr (ABL == 23) {
 #pragma unroll
-    for (int k = 0; k < C::TPL; ++k)
-        h[k] = S32IN ? __fmul_rn(a.taps[C::TPL * c.p + k], 4.656612873077393e-10f) : a.taps[C::TPL * c.p + k];
+            for (int k = 0; k < C::TPL; ++k) h[k] = __int_as_float(0x3a000000 + 64 * k + c.p);   // no tap traffic (wrong results)
+        } else if constexpr (ABL == 24) {
+#pragma unroll
+            for (int k = 0; k < C::TPL; ++k) h[k] = a.taps[C::TPL * c.p + k];     // per-lane global loads (A/B)
+        } else {
+            if (c.lane < NT / 4) glds16(reinterpret_cast<const char *>(a.taps) + 16 * c.lane, lds);
+            SXFIR_WAIT_VMCNT(0);
+            const f32x4 *tp = lds + (C::TPL / 4) * c.p;
+#pragma unroll
+            for (int k = 0; k < C::TPL / 4; ++k) {
+                const f32x4 t = tp[k];
+                h[4 * k] = t.x; h[4 * k + 1] = t.y; h[4 * k + 2] = t.z; h[4 * k + 3] = t.w;
+            }
+            // the reads must have returned before the first tile's DMA overwrites these slots
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (S32IN) {
+#pragma unroll
+                for (int k = 0; k < C::TPL; ++k) h[k] = __fmul_rn(h[k], 4.656612873077393e-10f);
+            }
+        }
+    };
 
     // this lane's window chunk 0 inside a buffer
     const int u0c = 16 * c.g - (NT / 4) * c.p + NT / 4;   // logical chunk, multiple of 16
@@ -357,22 +385,24 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     const int W = a.n_waves;
     int tile_begin, tile_end, tile_step;
     if (a.sched == 0) {
-        tile_begin = (W % 8 == 0) ? (wave % 8) * (W / 8) + wave / 8 : wave;
+        tile_begin = a.w8 ? (wave & 7) * a.w8 + (wave >> 3) : wave;
+        tile_end = a.n_tiles;
+        tile_step = W;
+    } else if (a.sched == 2) {
+        // SCHED_PLAIN: pass i covers tiles [i*W, (i+1)*W) in workgroup order
+        tile_begin = wave;
         tile_end = a.n_tiles;
         tile_step = W;
     } else {
-        const int base = a.n_tiles / W, extra = a.n_tiles % W;
-        tile_begin = wave * base + (wave < extra ? wave : extra);
-        tile_end = tile_begin + base + (wave < extra ? 1 : 0);
+        tile_begin = wave * a.run_base + (wave < a.run_extra ? wave : a.run_extra);
+        tile_end = tile_begin + a.run_base + (wave < a.run_extra ? 1 : 0);
         tile_step = 1;
     }
     if (tile_begin >= tile_end) return;
 
     // the wave that owns the last tile also carries the history over (before it issues any DMA, so
     // the counted vmcnt waits of the double-buffered loop are not disturbed)
-    const int last = a.n_tiles - 1;
-    if (last >= tile_begin && last < tile_end && (last - tile_begin) % tile_step == 0)
-        write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
+    if (wave == a.hist_wave) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
 
     unsigned long long st_c0 = 0, st_r0 = 0;
     if constexpr (ABL == 11 || ABL == 12) {
@@ -380,11 +410,15 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
         st_r0 = __builtin_amdgcn_s_memrealtime();
     }
     if constexpr (!DBUF) {
-        for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
+        auto stage = [&](int tile) __attribute__((always_inline)) {
             if constexpr (ABL == 20) stage_tile<NT, 2>(c, tile, lds);          // nt loads
             else if constexpr (ABL == 21) stage_tile<NT, 16>(c, tile, lds);    // sc1 loads
             else if constexpr (ABL == 22) stage_tile<NT, 1>(c, tile, lds);     // sc0 loads
             else if constexpr (ABL != 2 && ABL != 12 && (ABL < 17 || ABL > 19)) stage_tile<NT>(c, tile, lds);
+        };
+        load_taps();
+        for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
+            stage(tile);
             // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
             SXFIR_WAIT_VMCNT(0);
             if constexpr (ABL == 7) {
@@ -430,6 +464,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
         // DMAs of `tile` have landed once at most NLOAD operations remain outstanding.
         static_assert(C::NLOAD == 10 || C::NLOAD == 6, "vmcnt immediates below assume NLOAD");
         const f32x4 *win1 = win0 + C::BUF_SLOTS;
+        load_taps();
         stage_tile<NT>(c, tile_begin, lds);
         int tile = tile_begin;
         while (true) {
