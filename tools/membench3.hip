@@ -99,6 +99,33 @@ __global__ __launch_bounds__(64) void dma_r4w1_queue(const f4* __restrict__ in, 
     t = __builtin_amdgcn_readfirstlane((unsigned)tn);
   }
 }
+// persistent waves, NQ atomic queues: a wave of class c = blockIdx % NQ takes tiles NQ*k + c in request order
+template <int NQ>
+__global__ __launch_bounds__(64) void dma_r4w1_queues(const f4* __restrict__ in, f4* __restrict__ out, size_t ntiles,
+                                                      unsigned long long* counters, unsigned long long base) {
+  __shared__ f4 lds[512];
+  const int lane = threadIdx.x;
+  const unsigned cls = blockIdx.x % NQ;
+  unsigned long long* ctr = counters + 16 * cls;               // one 128-byte line per counter
+  unsigned long long k = 0;
+  if (lane == 0) k = atomicAdd(ctr, 1ull) - base;
+  unsigned long long t = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)k) * NQ + cls;
+  while (t < ntiles) {
+    const f4* src = in + t * 512 + lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i),
+                                       (__attribute__((address_space(3))) void*)(lds + 64 * i), 16, 0, 0);
+    unsigned long long kn = 0;
+    if (lane == 0) kn = atomicAdd(ctr, 1ull) - base;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const f4 a = lds[lane] + lds[lane + 64] + lds[lane + 128] + lds[lane + 192];
+    const f4 b = lds[lane + 256] + lds[lane + 320] + lds[lane + 384] + lds[lane + 448];
+    __builtin_nontemporal_store(a, out + t * 128 + lane);
+    __builtin_nontemporal_store(b, out + t * 128 + 64 + lane);
+    t = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)kn) * NQ + cls;
+  }
+}
 int main() {
   const size_t n = (size_t)1 << 27;        // float4 count = 2 GiB
   f4 *in, *out;
@@ -125,11 +152,21 @@ int main() {
   timeit("4:1 LDS-DMA, 16 tiles per 64-thread block", 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1<16>, dim3(ntiles / 16), dim3(64), 0, 0, in, out); });
   timeit("4:1 LDS-DMA persistent 4096 waves, plain strided", 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1_persist, dim3(4096), dim3(64), 0, 0, in, out, ntiles); });
   timeit("4:1 LDS-DMA persistent 65536 waves, plain strided", 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1_persist, dim3(65536), dim3(64), 0, 0, in, out, ntiles); });
-  unsigned long long* counter; CK(hipMalloc(&counter, 8)); CK(hipMemset(counter, 0, 8));
-  unsigned long long base = 0;
-  for (int waves : {4096, 8192, 16384}) {
-    char nm[64]; snprintf(nm, 64, "4:1 LDS-DMA persistent %d waves, atomic queue", waves);
-    timeit(nm, 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1_queue, dim3(waves), dim3(64), 0, 0, in, out, ntiles, counter, base); base += ntiles + waves; });
+  unsigned long long* counters; CK(hipMalloc(&counters, 128 * 256)); CK(hipMemset(counters, 0, 128 * 256));
+  // every class of NQ queues is used by waves/NQ waves and ends with one out-of-range grab per wave
+  {
+    unsigned long long base = 0;
+    timeit("4:1 LDS-DMA persistent 4096 waves, 32 atomic queues", 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1_queues<32>, dim3(4096), dim3(64), 0, 0, in, out, ntiles, counters, base); base += ntiles / 32 + 4096 / 32; });
+  }
+  CK(hipMemset(counters, 0, 128 * 256));
+  {
+    unsigned long long base = 0;
+    timeit("4:1 LDS-DMA persistent 4096 waves, 64 atomic queues", 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1_queues<64>, dim3(4096), dim3(64), 0, 0, in, out, ntiles, counters, base); base += ntiles / 64 + 4096 / 64; });
+  }
+  CK(hipMemset(counters, 0, 128 * 256));
+  {
+    unsigned long long base = 0;
+    timeit("4:1 LDS-DMA persistent 4096 waves, 16 atomic queues", 20.0 * n, [&] { hipLaunchKernelGGL(dma_r4w1_queues<16>, dim3(4096), dim3(64), 0, 0, in, out, ntiles, counters, base); base += ntiles / 16 + 4096 / 16; });
   }
   return 0;
 }
