@@ -99,6 +99,8 @@ int sx_device_get_antenna(sx_device *dev, int direction, size_t channel, char *o
 /* named gain elements ("LNA", "PGA", "DAC", "MIXER") and raw SX1255 register shadow, SX.cpp:1279-1368, :1501-1561 */
 int sx_device_set_gain_element(sx_device *dev, int direction, size_t channel, const char *name, double db);
 double sx_device_get_gain_element(sx_device *dev, int direction, size_t channel, const char *name);
+/* getGainRange (SX.cpp:1291-1306): name == NULL or "" -> the overall range; out = {minimum, maximum, step} */
+int sx_device_get_gain_range(sx_device *dev, int direction, size_t channel, const char *name, double out[3]);
 int sx_device_list(sx_device *dev, const char *what, int direction, char *out, size_t cap); /* "gains", "antennas" */
 int sx_device_write_registers(sx_device *dev, const char *name, unsigned addr, const unsigned *values, size_t n);
 int sx_device_read_registers(sx_device *dev, const char *name, unsigned addr, unsigned *values, size_t n);

@@ -521,6 +521,18 @@ public:
         return e ? SoapySDR::Range(e->lo, e->hi, e->step) : SoapySDR::Range(0, 0, 0);
     }
 
+    // SoapySDR's default for the overall range: element ranges added up (RX 0..78 dB, TX 0..39 dB)
+    SoapySDR::Range getGainRange(const int direction, const size_t channel) const
+    {
+        double lo = 0.0, hi = 0.0;
+        for (const auto &name : listGains(direction, channel)) {
+            const SoapySDR::Range r = getGainRange(direction, channel, name);
+            lo += r.minimum();
+            hi += r.maximum();
+        }
+        return SoapySDR::Range(lo, hi);
+    }
+
     void setGain(const int direction, const size_t, const std::string &name, const double value)
     {
         std::scoped_lock lock(reg_mutex);

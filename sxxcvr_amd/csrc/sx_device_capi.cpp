@@ -238,6 +238,18 @@ int sx_device_set_gain_element(sx_device *dev, int direction, size_t channel, co
     })
 }
 
+int sx_device_get_gain_range(sx_device *dev, int direction, size_t channel, const char *name, double out[3])
+{
+    SX_TRY(SX_DEVICE_EXCEPTION, {
+        const SoapySDR::Range r = (name && name[0]) ? D(dev)->getGainRange(direction, channel, name)
+                                                    : D(dev)->getGainRange(direction, channel);
+        out[0] = r.minimum();
+        out[1] = r.maximum();
+        out[2] = r.step();
+        return 0;
+    })
+}
+
 double sx_device_get_gain_element(sx_device *dev, int direction, size_t channel, const char *name)
 {
     SX_TRY(-1.0, { return D(dev)->getGain(direction, channel, std::string(name ? name : "")); })

@@ -23,6 +23,26 @@ SOAPY_SDR_END_BURST, SOAPY_SDR_HAS_TIME = 2, 4
 SOAPY_SDR_TIMEOUT, SOAPY_SDR_STREAM_ERROR, SOAPY_SDR_CORRUPTION = -1, -2, -3
 SOAPY_SDR_OVERFLOW, SOAPY_SDR_NOT_SUPPORTED, SOAPY_SDR_TIME_ERROR, SOAPY_SDR_UNDERFLOW = -4, -5, -6, -7
 SOAPY_SDR_CF32 = "CF32"
+
+
+class Range:
+    """SoapySDR::Range as the Python bindings present it."""
+
+    def __init__(self, minimum, maximum, step=0.0):
+        self._min, self._max, self._step = float(minimum), float(maximum), float(step)
+
+    def minimum(self):
+        return self._min
+
+    def maximum(self):
+        return self._max
+
+    def step(self):
+        return self._step
+
+    def __repr__(self):
+        return "%g, %g, %g" % (self._min, self._max, self._step)
+
 SOAPY_SDR_FATAL, SOAPY_SDR_CRITICAL, SOAPY_SDR_ERROR, SOAPY_SDR_WARNING = 1, 2, 3, 4
 SOAPY_SDR_NOTICE, SOAPY_SDR_INFO, SOAPY_SDR_DEBUG, SOAPY_SDR_TRACE = 5, 6, 7, 8
 
@@ -59,6 +79,7 @@ def _load():
         "sx_device_set_sample_rate": (ci, [vp, ci, sz, dbl]),
         "sx_device_get_sample_rate": (dbl, [vp, ci, sz]),
         "sx_device_get_num_channels": (ci, [vp, ci]),
+        "sx_device_get_gain_range": (ci, [vp, ci, sz, C.c_char_p, P(C.c_double)]),
         "sx_device_get_info": (ci, [vp, cs, ci, cs, sz]),
         "sx_device_set_frequency": (ci, [vp, ci, sz, dbl]),
         "sx_device_get_frequency": (dbl, [vp, ci, sz]),
@@ -224,6 +245,12 @@ class Device:
         if name is None:
             return self._lib.sx_device_get_gain(self._dev, direction, channel)
         return self._lib.sx_device_get_gain_element(self._dev, direction, channel, name.encode())
+
+    def getGainRange(self, direction, channel, name=None):
+        """Overall range, or one element's; the returned object has minimum() / maximum() / step()."""
+        out = (C.c_double * 3)()
+        self._chk(self._lib.sx_device_get_gain_range(self._dev, direction, channel, (name or "").encode(), out))
+        return Range(out[0], out[1], out[2])
 
     def listGains(self, direction, channel):
         return self._str(self._lib.sx_device_list, b"gains", direction).split(",")

@@ -349,6 +349,15 @@ def test_control_surface_register_shadow(oracle):
         dev.setFrequency(RX, 0, f)
         assert dev.getFrequency(RX, 0) == oracle.quantize_frequency(38.4e6, f)[0]
     assert dev.getFrequency(TX, 0) == f0                                   # TX word untouched
+    # ranges test_gains.py prints: overall = element ranges added up (SoapySDR's default), elements :1291-1306
+    r = dev.getGainRange(RX, 0)
+    assert (r.minimum(), r.maximum()) == (0.0, 78.0)
+    r = dev.getGainRange(TX, 0)
+    assert (r.minimum(), r.maximum()) == (0.0, 39.0)
+    r = dev.getGainRange(RX, 0, "LNA")
+    assert (r.minimum(), r.maximum(), r.step()) == (0.0, 48.0, 6.0)
+    r = dev.getGainRange(TX, 0, "MIXER")
+    assert (r.minimum(), r.maximum(), r.step()) == (0.0, 30.0, 2.0)
     # gain sweep of test_gains.py
     assert dev.listGains(RX, 0) == ["LNA", "PGA"] and dev.listGains(TX, 0) == ["DAC", "MIXER"]
     for g in range(-10, 90):
