@@ -10,15 +10,15 @@
 // samples x[D*q-4c-3 .. D*q-4c] of output row q).  The LDS image holds the NCOL
 // sub-streams de-interleaved, each as a dense padded row sequence, so a lane's
 // window is contiguous and the inner loop is the decimate-by-4 one: 46
-// ds_read_b128 feeding 1024 v_fmac per lane.  The de-interleave costs nothing:
+// ds_read_b128 feeding 512 v_pk_fma_f32 per lane.  The de-interleave costs nothing:
 // LDS-DMA (global_load_lds_dwordx4) takes a per-lane SOURCE address, so each
 // 16-byte piece (half a row) is fetched from wherever it lives; pieces start
 // on odd sample indices (8-byte aligned sources, verified on MI355X).
 //
 // Workgroup = W waves sharing one tile of W*OW outputs (+ 31 halo rows); every wave owns OW of them:
 // lanes = (p, c, g): tap-row range p (top lane bits), column group c (next lane bits), output group g
-// (8 outputs each).  PS = 2 (shipped): two row halves, 64 taps and 1024 v_fmac per lane and tile.
-// PS = 4 (SXFIR_MULTI_PS=4, measured slower: DESIGN.md): four row quarters, 32 taps and 512 v_fmac, so
+// (8 outputs each).  PS = 2 (shipped): two row halves, 64 taps and 512 packed FMAs per lane and tile.
+// PS = 4 (SXFIR_MULTI_PS=4, measured slower: DESIGN.md): four row quarters, 32 taps and 256 packed FMAs, so
 // that twice as many, lighter waves share a tile.
 // Reduction: v_permlane32_swap / v_permlane16_swap over p and c bit 0, lane xor 8 / 4 / 2 for the
 // remaining column bits: the adjacent-pair trees of the numeric contract, first over the
@@ -52,7 +52,7 @@ struct DecimMulti {
     // HALF: IQ stored as IEEE half pairs (CF16, 4 bytes per sample; BASELINE config 5), fp32
     // arithmetic.  A 16-byte piece is then a whole row (4 samples) instead of half a row.
     // PS: the 32 tap rows are split over PS lanes (2 or 4); PS = 4 makes a wave half as heavy (32 taps,
-    // 512 v_fmac per lane and tile), so twice as many waves share a tile and hide each other's waits.
+    // 256 packed FMAs per lane and tile), so twice as many waves share a tile and hide each other's waits.
     static constexpr int NT = 32 * D;
     static constexpr int NCOL = D / 4;
     static constexpr int JR = 32 / PS;                    // tap rows per lane

@@ -6,18 +6,23 @@
 // feeding the stream that SoapySX::readStream (SoapySX.cpp:868-967) hands out.
 //
 // Work decomposition (wave64, one wave = one workgroup, no barriers):
-//   * a wave owns a contiguous run of tiles of one channel; a tile is 256
-//     outputs = 1024 input samples (8 KiB) plus a 128-sample halo;
+//   * a wave owns a few tiles of one channel (strided passes over the stream,
+//     see the schedule in the kernel); a tile is 256 outputs = 1024 input
+//     samples (8 KiB) plus a 128-sample halo;
 //   * the tile is staged in LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-//     wave-instruction, coalesced 16 B per lane), taps live in VGPRs; with
-//     DBUF the next tile's DMA is issued before the current tile is computed
-//     and retired by a counted s_waitcnt vmcnt (two LDS buffers per wave);
+//     wave-instruction, coalesced 16 B per lane), taps live in VGPRs (fetched
+//     once per wave through an LDS broadcast); with DBUF the next tile's DMA is
+//     issued before the current tile is computed and retired by a counted
+//     s_waitcnt vmcnt (two LDS buffers per wave; measured slower, not shipped);
 //   * lanes l and l+32 form a pair: both compute the same R = 8 consecutive
 //     outputs, lane half p = l >> 5 over the tap range [NT/2*p, NT/2*(p+1));
-//     each 16-byte ds_read_b128 (two complex samples) feeds up to 64 v_fma;
+//     each 16-byte ds_read_b128 (two complex samples) feeds up to 32
+//     v_pk_fma_f32 (the I and Q fused multiply-adds of one tap in one packed
+//     instruction, compute_tile_pk);
 //   * the two partial dot products are combined with v_permlane32_swap
 //     (gfx950) + one add, which also leaves outputs 0-3 on the low lane and
-//     4-7 on the high lane, so every lane stores 32 contiguous bytes.
+//     4-7 on the high lane; the 32 bytes a lane ends with go through LDS so
+//     that every store instruction writes whole lines.
 // LDS image: 16-byte chunks, one pad chunk after every 16, so the 16 lanes of
 // a ds_read_b128 group (lane stride 256 B) hit 16 different 16-byte slots.
 //

@@ -10,7 +10,7 @@
 // [16p, 16p+16)), phase group c (phases 4c..4c+3; lane bits below p), input
 // group g (4 consecutive inputs).  A lane holds its 64 taps in VGPRs and 32
 // accumulators (4 inputs x 4 phases x I/Q); its window is 10 ds_read_b128
-// (the tile is tiny: <= 1.3 KiB of LDS, staged by LDS-DMA) for 512 v_fmac.
+// (the tile is tiny: <= 2.3 KiB of LDS, staged by LDS-DMA) for 256 v_pk_fma_f32.
 // The two row-half partials are exchanged with v_permlane32_swap and added
 // once: the low lane keeps inputs 0-1, the high lane inputs 2-3, so each lane
 // stores 2 x 4 consecutive outputs.
