@@ -567,3 +567,16 @@ def test_ratio_follows_sample_rate(oracle):
     dev.closeStream(rx)
     with pytest.raises(RuntimeError, match="Unsupported sample rate"):
         dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 48000.0)
+
+
+def test_repeater_example_runs():
+    """examples/repeater_loopback.py: the reference's linear-repeater call pattern for a fixed number of blocks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--rate", "300000", "--blocks", "60"]):
+        run = subprocess.run([sys.executable, os.path.join(root, "examples", "repeater_loopback.py")] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+        assert "TX placed at sample" in run.stdout
