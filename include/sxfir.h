@@ -157,6 +157,11 @@ int sxfir_host_alloc(void **host, size_t bytes);
 int sxfir_host_free(void *host);
 int sxfir_stream_create(void **stream);
 int sxfir_stream_destroy(void *stream);
+/* Events: completion of the work queued on a stream so far, without draining what is queued later. */
+int sxfir_event_create(void **event);
+int sxfir_event_destroy(void *event);
+int sxfir_event_record(void *event, void *stream);
+int sxfir_event_sync(void *event);
 
 /* Timed launches for bench.py: runs `iters` back-to-back decimate passes of
  * the same buffers on `stream` bracketed by hipEvents ON THAT STREAM and

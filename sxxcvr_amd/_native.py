@@ -73,6 +73,10 @@ def load_sxfir():
         "sxfir_host_free": (ci, [vp]),
         "sxfir_stream_create": (ci, [P(vp)]),
         "sxfir_stream_destroy": (ci, [vp]),
+        "sxfir_event_create": (ci, [P(vp)]),
+        "sxfir_event_destroy": (ci, [vp]),
+        "sxfir_event_record": (ci, [vp, vp]),
+        "sxfir_event_sync": (ci, [vp]),
         "sxfir_memcpy_h2d": (ci, [vp, vp, sz, vp]),
         "sxfir_memcpy_d2h": (ci, [vp, vp, sz, vp]),
         "sxfir_stream_sync": (ci, [vp]),

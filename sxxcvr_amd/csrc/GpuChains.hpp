@@ -281,11 +281,16 @@ public:
         ring_.reserve(8 * ring_len_ * (size_t)nchan_);
         in_.reserve(8 * kSlotFrames * (size_t)nchan_ * kSlots);
         stage_.reserve(8 * kSlotFrames * (size_t)nchan_ * kSlots);
-        for (int k = 0; k < kSlots; ++k) busy_[k] = false;
+        for (int k = 0; k < kSlots; ++k) {
+            busy_[k] = false;
+            done_[k] = nullptr;
+            gpu_check(sxfir_event_create(&done_[k]), "sxfir_event_create");
+        }
     }
     ~TxChain()
     {
         sxfir_stream_sync(stream_->get());
+        for (int k = 0; k < kSlots; ++k) sxfir_event_destroy(done_[k]);
         sxfir_destroy(plan_);
     }
     TxChain(const TxChain &) = delete;
@@ -355,7 +360,11 @@ private:
     {
         size_t done = 0;
         while (done < n) {
-            if (pend_ == 0 && busy_[slot_]) drain();                 // the slot's last H2D may still be reading it
+            if (pend_ == 0 && busy_[slot_]) {
+                // the slot's last H2D may still be reading it: wait for THAT pass only, not for the newer ones
+                gpu_check(sxfir_event_sync(done_[slot_]), "sxfir_event_sync");
+                busy_[slot_] = false;
+            }
             const size_t m = std::min(kSlotFrames - pend_, n - done);
             float *host = stage_.floats() + 2 * kSlotFrames * (size_t)nchan_ * (size_t)slot_;
             for (int c = 0; c < nchan_; ++c) {
@@ -393,6 +402,7 @@ private:
             next_ += (int64_t)m;
             done += m;
         }
+        gpu_check(sxfir_event_record(done_[slot_], st), "sxfir_event_record");
         busy_[slot_] = true;
         slot_ = (slot_ + 1) % kSlots;
         pend_ = 0;
@@ -405,6 +415,7 @@ private:
     DeviceBuffer in_, ring_;
     PinnedBuffer stage_;
     bool busy_[kSlots];
+    void *done_[kSlots];  // recorded behind each slot's GPU pass
     int64_t next_;        // stream samples passed to the GPU so far (written + silence)
     int64_t accepted_;    // next_ + what is gathered in the current slot
     int64_t written_;     // stream samples that carried application data

@@ -942,4 +942,33 @@ int sxfir_stream_destroy(void *stream)
     return SXFIR_OK;
 }
 
+int sxfir_event_create(void **event)
+{
+    if (!event) return fail(SXFIR_EINVAL, "NULL argument");
+    hipEvent_t e = nullptr;
+    HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *)e;
+    return SXFIR_OK;
+}
+
+int sxfir_event_destroy(void *event)
+{
+    if (event) HIPCHECK(hipEventDestroy((hipEvent_t)event));
+    return SXFIR_OK;
+}
+
+int sxfir_event_record(void *event, void *stream)
+{
+    if (!event) return fail(SXFIR_EINVAL, "NULL event");
+    HIPCHECK(hipEventRecord((hipEvent_t)event, S(stream)));
+    return SXFIR_OK;
+}
+
+int sxfir_event_sync(void *event)
+{
+    if (!event) return fail(SXFIR_EINVAL, "NULL event");
+    HIPCHECK(hipEventSynchronize((hipEvent_t)event));
+    return SXFIR_OK;
+}
+
 }  // extern "C"
