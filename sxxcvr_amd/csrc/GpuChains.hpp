@@ -4,9 +4,12 @@
 // interpolates what snd_pcm_writei hands it (SoapySX.cpp:1093).
 //
 //   RxChain: synthetic wideband IQ source (counter based, resident in HBM)
-//            -> polyphase FIR decimator (HIP) -> pinned staging -> caller
-//   TxChain: caller -> pinned staging -> polyphase FIR interpolator (HIP)
-//            -> DAC-rate ring in HBM (the synthetic sink)
+//            -> polyphase FIR decimator (HIP), which stores straight into
+//            pinned host staging (zero copy) -> caller
+//   TxChain: caller -> pinned host staging, read in place by the polyphase
+//            FIR interpolator (HIP) -> DAC-rate ring in HBM (the synthetic sink)
+// The narrow side of either resampler is 1/ratio of the traffic, so it crosses
+// PCIe inside the kernel and the wide side never leaves HBM.
 //
 // Both are batched and asynchronous, which is what a GPU behind a 256-sample
 // API needs: the RX side produces the stream in batches of thousands of
@@ -126,10 +129,7 @@ public:
         gpu_check(sxfir_design_lowpass(ntaps_, decim_, 8.0, 1.0, taps.data()), "sxfir_design_lowpass");
         gpu_check(sxfir_create(&plan_, SXFIR_DECIMATE, taps.data(), ntaps_, decim_, nchan_, fmt_, gpu_), "sxfir_create(rx)");
         in_.reserve(8 * kMaxBatch * (size_t)decim_ * (size_t)nchan_);
-        for (int k = 0; k < 2; ++k) {
-            out_[k].reserve(8 * kMaxBatch * (size_t)nchan_);
-            stage_[k].reserve(8 * kMaxBatch * (size_t)nchan_);
-        }
+        for (int k = 0; k < 2; ++k) stage_[k].reserve(8 * kMaxBatch * (size_t)nchan_);
     }
     ~RxChain()
     {
@@ -210,10 +210,11 @@ private:
         gpu_check(sxfir_synth_fill(in_.get(), m * (size_t)decim_, m * (size_t)decim_, nchan_, seed_, first_channel_,
                                    pos * decim_, fmt_, st),
                   "sxfir_synth_fill");
-        gpu_check(sxfir_decimate(plan_, in_.get(), m * (size_t)decim_, m * (size_t)decim_, out_[k].get(), m, &n_out, st),
+        // the decimator stores straight into the pinned staging buffer (device-visible host memory): the
+        // outputs are 1/decim of the traffic and cross PCIe as they are produced, no separate D2H copy
+        gpu_check(sxfir_decimate(plan_, in_.get(), m * (size_t)decim_, m * (size_t)decim_, stage_[k].floats(), m, &n_out, st),
                   "sxfir_decimate");
         if (n_out != m) throw std::runtime_error("rx chain: decimator produced an unexpected block size");
-        gpu_check(sxfir_memcpy_d2h(stage_[k].floats(), out_[k].get(), 8 * m * (size_t)nchan_, st), "sxfir_memcpy_d2h");
         slot_[k].pos = pos;
         slot_[k].n = m;
         slot_[k].ready = false;
@@ -234,12 +235,13 @@ private:
         void *st = stream_->get();
         gpu_check(sxfir_reset(plan_, st), "sxfir_reset");
         const int64_t warm = (ntaps_ + decim_ - 1) / decim_;     // outputs whose inputs cover ntaps samples
+        scratch_.reserve(8 * (size_t)warm * (size_t)nchan_);
         const int64_t from = pos - warm;                          // may be negative: source index < 0 is zero
         size_t n_out = 0;
         gpu_check(sxfir_synth_fill(in_.get(), (size_t)(warm * decim_), (size_t)(warm * decim_), nchan_, seed_,
                                    first_channel_, from * decim_, fmt_, st),
                   "sxfir_synth_fill");
-        gpu_check(sxfir_decimate(plan_, in_.get(), (size_t)(warm * decim_), (size_t)(warm * decim_), out_[0].get(),
+        gpu_check(sxfir_decimate(plan_, in_.get(), (size_t)(warm * decim_), (size_t)(warm * decim_), scratch_.get(),
                                  (size_t)warm, &n_out, st),
                   "sxfir_decimate(prime)");
     }
@@ -250,7 +252,7 @@ private:
     int fmt_;
     sxfir_plan *plan_;
     std::unique_ptr<GpuStream> stream_;
-    DeviceBuffer in_, out_[2];
+    DeviceBuffer in_, scratch_;      // wideband source block; outputs of the priming pass (discarded)
     PinnedBuffer stage_[2];
     Slot slot_[2];
     int64_t next_;
@@ -279,7 +281,6 @@ public:
                                wire_s32 ? SXFIR_S32 : SXFIR_CF32, gpu_),
                   "sxfir_create(tx)");
         ring_.reserve(8 * ring_len_ * (size_t)nchan_);
-        in_.reserve(8 * kSlotFrames * (size_t)nchan_ * kSlots);
         stage_.reserve(8 * kSlotFrames * (size_t)nchan_ * kSlots);
         for (int k = 0; k < kSlots; ++k) {
             busy_[k] = false;
@@ -386,18 +387,15 @@ private:
         if (pend_ == 0) return;
         void *st = stream_->get();
         const size_t slot_off = kSlotFrames * (size_t)nchan_ * (size_t)slot_;
-        const float *host = stage_.floats() + 2 * slot_off;
-        for (int c = 0; c < nchan_; ++c)
-            gpu_check(sxfir_memcpy_h2d(in_.at(8 * (slot_off + (size_t)c * kSlotFrames)), host + 2 * (size_t)c * kSlotFrames,
-                                       8 * pend_, st),
-                      "sxfir_memcpy_h2d");
+        // the interpolator reads its input straight from the pinned slot (device-visible host memory): the
+        // input is 1/interp of the traffic and crosses PCIe as the kernel fetches it, no separate H2D copy
+        const char *host = reinterpret_cast<const char *>(stage_.floats() + 2 * slot_off);
         size_t done = 0;
         while (done < pend_) {
             const size_t off = (size_t)((next_ * interp_) % (int64_t)ring_len_);
             const size_t m = std::min(pend_ - done, (ring_len_ - off) / (size_t)interp_);
             size_t n_out = 0;
-            gpu_check(sxfir_interpolate(plan_, in_.at(8 * (slot_off + done)), m, kSlotFrames, ring_.at(8 * off), ring_len_,
-                                        &n_out, st),
+            gpu_check(sxfir_interpolate(plan_, host + 8 * done, m, kSlotFrames, ring_.at(8 * off), ring_len_, &n_out, st),
                       "sxfir_interpolate");
             next_ += (int64_t)m;
             done += m;
@@ -412,7 +410,7 @@ private:
     sxfir_plan *plan_;
     size_t ring_len_;
     std::unique_ptr<GpuStream> stream_;
-    DeviceBuffer in_, ring_;
+    DeviceBuffer ring_;
     PinnedBuffer stage_;
     bool busy_[kSlots];
     void *done_[kSlots];  // recorded behind each slot's GPU pass
