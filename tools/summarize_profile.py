@@ -45,13 +45,18 @@ if trace:
         out["lds_bytes"] = r.get("LDS_Block_Size")
         out["grid"] = [r.get("Grid_Size_X"), r.get("Grid_Size_Y")]
         out["workgroup"] = r.get("Workgroup_Size_X")
-        # the profiled command is bench.py --steps 50 --warmup 50: launches 0-49 are warm-up (they contain
-        # the clock transient of the first ~20 launches), 50-99 the timed region, 100-149 the event-timed
-        # launches bench.py reports as roofline.kernel_ms
+        # the profiled command is bench.py --steps 50 --warmup 50: its last 150 launches are warm-up steps,
+        # timed steps and the event-timed launches bench.py reports as roofline.kernel_ms; whatever comes
+        # before is the untimed settle phase (--settle), which contains the clock transient of the first
+        # ~20 launches
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
         if len(d) >= 150:
-            out["avg_ns_by_phase"] = {"warmup_0_49": sum(d[:50]) / 50.0, "timed_50_99": sum(d[50:100]) / 50.0,
-                                      "event_timed_100_149": sum(d[100:150]) / 50.0}
+            n = len(d)
+            out["avg_ns_by_phase"] = {"warmup": sum(d[n - 150:n - 100]) / 50.0, "timed": sum(d[n - 100:n - 50]) / 50.0,
+                                      "event_timed": sum(d[n - 50:]) / 50.0}
+            if n > 150:
+                out["avg_ns_by_phase"]["settle"] = sum(d[:n - 150]) / float(n - 150)
+                out["avg_ns_by_phase"]["settle_first_20"] = sum(d[:20]) / 20.0
 
 
 def counters(sub):
