@@ -146,3 +146,35 @@ def test_full_size_eight_channels(oracle):
         # and the channel is the one the source says it is: first outputs against the oracle
         ref = oracle.decim_f32(h, 4, oracle.synth_iq(SEED, 16 + c, 0, 4 * 300), 2, 4)
         assert_bit_exact(to_cpu(y[c, :300]), ref, "channel %d" % c)
+
+
+@pytest.mark.parametrize("mode,ratio", [("decim", 4), ("decim", 32), ("interp", 8)])
+def test_offsets_beyond_4_gib(oracle, mode, ratio):
+    """One call over a buffer four times the benchmark's (2^30 wide-rate samples = 8 GiB): byte offsets no
+    longer fit 32 bits anywhere in the stream.  The last outputs must still be the oracle's."""
+    import torch
+    nt = 32 * ratio
+    wide = 1 << 30
+    if mode == "decim":
+        h = sxxcvr_amd.design_lowpass(nt, ratio)
+        n_in = wide
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio)
+    else:
+        h = sxxcvr_amd.design_lowpass(nt, ratio, 8.0, float(ratio))
+        n_in = wide // ratio
+        plan = sxxcvr_amd.Resampler(INTERPOLATE, h, ratio)
+    plan.set_kernel(KERNEL_TILED)
+    x = torch.empty(n_in, dtype=torch.complex64, device="cuda")
+    sxxcvr_amd.synth_fill(x, SEED, 0, 0)
+    y = plan.process(x)
+    _sync()
+    if mode == "decim":
+        total = n_in // ratio
+        for m0 in (total // 2 + 5, total - 150):                      # input byte offsets around 4 GiB and 8 GiB
+            w = oracle.synth_iq(SEED, 0, ratio * m0 - nt, nt + ratio * 150)
+            ref = oracle.decim_f32(h, ratio, w, *plan.contract)[32:32 + 150]
+            assert_bit_exact(to_cpu(y[m0:m0 + 150]), ref, "/%d at output %d" % (ratio, m0))
+    else:
+        for q0 in (n_in // 2 + 3, n_in - 60):                         # output byte offsets around 4 GiB and 8 GiB
+            ref = oracle.interp_f32(h, ratio, oracle.synth_iq(SEED, 0, q0 - 32, 32 + 60), 2)[32 * ratio:]
+            assert_bit_exact(to_cpu(y[q0 * ratio:(q0 + 60) * ratio]), ref, "x%d at input %d" % (ratio, q0))
