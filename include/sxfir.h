@@ -12,7 +12,7 @@
  * What each entry point replaces in the reference (tejeez/sxxcvr,
  * SoapySX/SoapySX.cpp = "SX.cpp"):
  *
- *   sxfir_create / sxfir_set_ratio ... the SX1255 decimator/interpolator
+ *   sxfir_create ..................... the SX1255 decimator/interpolator
  *       configuration written by setSampleRate (SX.cpp:1166-1209, register
  *       table SX.cpp:180-208): the reference only programs the chip's
  *       divider; here the filter itself is built.
@@ -84,7 +84,8 @@ int sxfir_device_info(int device, char *name, char *arch, int *compute_units, si
  *   mode   SXFIR_DECIMATE: y[m] = sum_k taps[k] x[m*ratio - k]
  *          SXFIR_INTERPOLATE: y[n] = sum_j taps[j*ratio + n%ratio] x[n/ratio - j]
  *   taps   host pointer, ntaps floats (copied)
- *   fmt    SXFIR_CF32 or SXFIR_CF16, used for both input and output
+ *   fmt    SXFIR_CF32 or SXFIR_CF16 (input and output alike), or SXFIR_S32 (wire words on the
+ *          hardware side, CF32 on the caller's side; see the format enum above)
  * Samples before the start of the stream are zero; the last ntaps-1 input
  * samples persist across calls (per channel) until sxfir_reset. */
 int sxfir_create(sxfir_plan **plan, int mode, const float *taps, int ntaps, int ratio,
@@ -168,14 +169,6 @@ int sxfir_event_sync(void *event);
  * returns the mean milliseconds per pass of the resampling kernel. */
 int sxfir_time_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
                         void *out_dev, size_t out_stride, int iters, void *stream, float *ms_per_pass);
-
-/* Diagnostic builds only (SXFIR_ABLATE=11/12): median in-kernel shader clock of the last launch. */
-int sxfir_debug_clock(sxfir_plan *plan, double *mhz);
-
-/* Diagnostic builds only (SXFIR_ABLATE=3 on the multi-column decimator): copies the raw per-wave stamp
- * records of the last launch (5 x uint64 each: tiles, cycles in reduction + store, waiting for data,
- * arithmetic, barrier + issuing the next tile's DMAs) to `host`; returns the number of records through *n_records. */
-int sxfir_debug_stamps(sxfir_plan *plan, unsigned long long *host, size_t capacity_records, size_t *n_records);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDIR = os.path.join(_HERE, "lib")
 
 _sxfir = None
+_sxfir_prof = None
 
 
 class NativeError(RuntimeError):
@@ -26,18 +27,25 @@ def _share_hip_runtime_with_torch():
         pass
 
 
-def load_sxfir():
-    """Load sxxcvr_amd/lib/libsxfir.so and declare its prototypes."""
-    global _sxfir
-    if _sxfir is not None:
+def load_sxfir(profiling=False):
+    """Load sxxcvr_amd/lib/libsxfir.so and declare its prototypes.
+
+    profiling=True loads libsxfir_prof.so instead: the same C ABI plus include/sxfir_prof.h, with the kernel
+    A/B variants and environment knobs (tools/ and tests/test_gpu_variants.py; an explicit argument, never
+    an environment switch: the product's arithmetic does not depend on the environment)."""
+    global _sxfir, _sxfir_prof
+    if profiling:
+        if _sxfir_prof is not None:
+            return _sxfir_prof
+    elif _sxfir is not None:
         return _sxfir
-    path = os.path.join(LIBDIR, "libsxfir.so")
+    path = os.path.join(LIBDIR, "libsxfir_prof.so" if profiling else "libsxfir.so")
     if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build the HIP extension first (python -m sxxcvr_amd.build). "
             "There is no CPU fallback." % path)
     _share_hip_runtime_with_torch()
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL if profiling else C.RTLD_GLOBAL)
     vp, sz, i64, u64, ll, dbl, ci = C.c_void_p, C.c_size_t, C.c_int64, C.c_uint64, C.c_longlong, C.c_double, C.c_int
     P = C.POINTER
     sig = {
@@ -50,8 +58,6 @@ def load_sxfir():
         "sxfir_reset": (ci, [vp, vp]),
         "sxfir_set_kernel": (ci, [vp, ci]),
         "sxfir_set_tx_threshold": (ci, [vp, C.c_float]),
-        "sxfir_debug_clock": (ci, [vp, P(dbl)]),
-        "sxfir_debug_stamps": (ci, [vp, P(C.c_ulonglong), sz, P(sz)]),
         "sxfir_contract": (ci, [vp, P(ci), P(ci)]),
         "sxfir_position": (ci, [vp, P(i64), P(i64)]),
         "sxfir_outputs_for": (ci, [vp, sz, P(sz)]),
@@ -81,15 +87,21 @@ def load_sxfir():
         "sxfir_memcpy_d2h": (ci, [vp, vp, sz, vp]),
         "sxfir_stream_sync": (ci, [vp]),
     }
+    if profiling:
+        sig["sxfir_debug_clock"] = (ci, [vp, P(dbl)])
+        sig["sxfir_debug_stamps"] = (ci, [vp, P(C.c_ulonglong), sz, P(sz)])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     lib._sx_signatures = sig
-    _sxfir = lib
+    if profiling:
+        _sxfir_prof = lib
+    else:
+        _sxfir = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise NativeError(rc, load_sxfir().sxfir_last_error().decode("utf-8", "replace"))
+        raise NativeError(rc, (lib or load_sxfir()).sxfir_last_error().decode("utf-8", "replace"))

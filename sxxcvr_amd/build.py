@@ -6,6 +6,9 @@
 Outputs (git-ignored, shipped to the GPU box by gpurun):
     sxxcvr_amd/lib/libsxfir.so       C ABI of the HIP resampling path (include/sxfir.h)
     sxxcvr_amd/lib/libSXSupport.so   SoapySDR-style Device plugin + its C ABI (include/sx_device.h)
+    sxxcvr_amd/lib/libsxfir_prof.so  the same C ABI built with -DSXFIR_PROFILING: kernel A/B variants, ablation
+                                     modes and environment knobs (include/sxfir_prof.h); tools/ and
+                                     tests/test_gpu_variants.py only, never loaded by the product
 """
 import os
 import shutil
@@ -50,6 +53,11 @@ TARGETS = {
         "compiler": "hipcc",
         "sources": ["sxfir.hip"],
         "flags": ["--offload-arch=" + ARCH, "-O3"],
+    },
+    "libsxfir_prof.so": {
+        "compiler": "hipcc",
+        "sources": ["sxfir.hip"],
+        "flags": ["--offload-arch=" + ARCH, "-O3", "-DSXFIR_PROFILING"],
     },
     "libSXSupport.so": {
         "compiler": "g++",

@@ -17,21 +17,37 @@
 #include "sxfir_decim_tile.hip.h"
 #include "sxfir_decim_multi.hip.h"
 
-// Instantiated (ratio, waves per workgroup, CF16) variants of the multi-column decimator: one list for
-// the occupancy query in sxfir_create and the launch in launch_decim.
+// Instantiated (ratio, waves per workgroup, CF16, row split) variants of the multi-column decimator: one list
+// for the occupancy query in sxfir_create and the launch in launch_decim.  The production library carries
+// what it launches; the profiling build (-DSXFIR_PROFILING, libsxfir_prof.so: tools/ and
+// tests/test_gpu_variants.py) adds the A/B variants, the ablation modes and the environment knobs.
+#define SXFIR_MULTI_SHIPPED(X) \
+    X(8, 4, false, 2) X(16, 4, false, 2) X(32, 4, false, 2) \
+    X(4, 1, true, 2) X(8, 4, true, 2) X(16, 4, true, 2) X(32, 4, true, 2)
+#ifdef SXFIR_PROFILING
 #define SXFIR_MULTI_VARIANTS(X) \
-    X(4, 1, false, 2) X(4, 4, false, 2) X(8, 1, false, 2) X(8, 2, false, 2) X(8, 4, false, 2) X(16, 2, false, 2) \
-    X(16, 4, false, 2) X(32, 4, false, 2) X(32, 8, false, 2) \
-    X(4, 1, true, 2) X(8, 1, true, 2) X(8, 2, true, 2) X(8, 4, true, 2) X(16, 2, true, 2) X(16, 4, true, 2) X(32, 4, true, 2) \
-    X(32, 8, true, 2) \
+    SXFIR_MULTI_SHIPPED(X) \
+    X(4, 1, false, 2) X(4, 4, false, 2) X(8, 1, false, 2) X(8, 2, false, 2) X(16, 2, false, 2) X(32, 8, false, 2) \
+    X(8, 1, true, 2) X(8, 2, true, 2) X(16, 2, true, 2) X(32, 8, true, 2) \
     X(4, 2, false, 4) X(8, 2, false, 4) X(8, 4, false, 4) X(16, 4, false, 4) X(16, 8, false, 4) X(32, 8, false, 4) \
     X(32, 16, false, 4) \
     X(4, 2, true, 4) X(8, 4, true, 4) X(16, 8, true, 4) X(32, 8, true, 4)
 // profiling modes of decim4_tile_kernel<128> (its ABL template argument)
 #define SXFIR_TILE_ABLATIONS(X) X(1) X(2) X(3) X(7) X(8) X(9) X(10) X(11) X(12) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+// (waves per workgroup, option bits) variants of decim4_tile2_kernel<128>
+#define SXFIR_TILE2_VARIANTS(X) \
+    X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 9) X(1, 11) \
+    X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3)
+#else
+#define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
+#endif
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
+#ifdef SXFIR_PROFILING
 #include "sxfir_decim_sgpr.hip.h"
+#include "sxfir_decim_tile2.hip.h"
+#include "../../include/sxfir_prof.h"
+#endif
 #include "sxfir_kernels.hip.h"
 
 namespace {
@@ -81,6 +97,7 @@ struct sxfir_plan {
     int sgpr_r;            // experiment: SGPR-tap variant with R outputs per lane (0 = off)
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
+    int t2_wpg, t2_opt;    // profiling only: decim4_tile2_kernel variant (waves per workgroup, T2_* bits); wpg 0 = off
     int compute_units;
     float *taps_dev;
     void *hist_dev;        // current history: nchan * hist_len samples
@@ -212,57 +229,67 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // halo stays a small part of the staging
     p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
+    p->t2_wpg = p->t2_opt = 0;
+    p->occ_multi = 2;
+    // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's prologue
+    // (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16; the
+    // interpolator is flat between 2 and 16 (tools/ibench.py)
+    if (p->multi_capable) p->oversub = 8;
+    if (p->itile_capable) p->oversub = 4;
+#ifdef SXFIR_PROFILING
+    // A/B knobs of the profiling build.  The production library never looks at the environment.
     if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
         if (strcmp(v, "mu") == 0 && mode == SXFIR_DECIMATE && fmt == SXFIR_CF32 && ratio == 4 && ntaps == 128) {
-            p->multi_capable = true;        // A/B: the multi-column kernel at D = 4 instead of decim4_tile_kernel
+            p->multi_capable = true;        // the multi-column kernel at D = 4 instead of decim4_tile_kernel
             p->tile_capable = false;
+            p->oversub = 8;
         }
     }
-    p->occ_multi = 2;
-    if (p->multi_capable) {
+    if (p->multi_capable && fmt != SXFIR_S32) {
         if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
         if (p->multi_ps == 4) p->multi_waves = ratio <= 4 ? 2 : (ratio == 8 ? 4 : 8);
         if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
         p->jsplit = p->multi_ps;
+    }
+    if (p->multi_capable || p->itile_capable || p->tile_capable) {
+        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
+    }
+    if (p->multi_capable || p->tile_capable) {
+        if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
+    }
+#endif
+    if (p->multi_capable) {
         // resident workgroups per CU: LDS is the limiter (checked against the occupancy API below)
-        if (fmt == SXFIR_S32) {          // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
-            p->multi_waves = 4;
-            p->multi_ps = 2;
-            p->jsplit = 2;
-        }
         const int W = p->multi_waves;
         int nb = 0;
         const void *k = nullptr;
-        switch (SXFIR_MULTI_KEY(ratio, W, fmt == SXFIR_CF16, p->multi_ps)) {
+        if (fmt == SXFIR_S32) {          // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
+            k = ratio == 8    ? (const void *)sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>
+                : ratio == 16 ? (const void *)sxfir::decim_multi_kernel<16, 4, false, 0, 2, true>
+                              : (const void *)sxfir::decim_multi_kernel<32, 4, false, 0, 2, true>;
+        } else {
+            switch (SXFIR_MULTI_KEY(ratio, W, fmt == SXFIR_CF16, p->multi_ps)) {
 #define SXFIR_X(DD, WW, HH, PP) \
-        case SXFIR_MULTI_KEY(DD, WW, HH, PP): k = (const void *)sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>; break;
-            SXFIR_MULTI_VARIANTS(SXFIR_X)
+            case SXFIR_MULTI_KEY(DD, WW, HH, PP): k = (const void *)sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>; break;
+                SXFIR_MULTI_VARIANTS(SXFIR_X)
 #undef SXFIR_X
+            }
         }
         if (!k) {
             delete p;
             return fail(SXFIR_EUNSUPPORTED, "no multi-column kernel for ratio %d with %d waves per workgroup", ratio, W);
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0) p->occ_multi = nb;
-        // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's
-        // prologue (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16
-        p->oversub = 8;
-        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
-        if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
-    }
-    if (p->itile_capable) {
-        p->oversub = 4;              // measured flat between 2 and 16 (tools/ibench.py)
-        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
     }
     if (p->tile_capable) {
         int nb = 0;
         const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
                                        : (const void *)sxfir::decim4_tile_kernel<64, false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
+#ifdef SXFIR_PROFILING
         const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
                                        : (const void *)sxfir::decim4_tile_kernel<64, true>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kdb, 64, 0) == hipSuccess && nb > 0) p->occ_db = nb;
-        // experiment knobs (profiling only; defaults are what ships)
         if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
             p->tile_dbuf = (strcmp(v, "db") == 0);
             p->sgpr_r = strcmp(v, "sg") == 0 ? 8 : (strcmp(v, "sg4") == 0 ? 4 : 0);
@@ -272,13 +299,33 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0)
                     p->occ_sb = nb;
             }
+            // "t2:<waves per workgroup>:<option bits>": decim4_tile2_kernel (sxfir_decim_tile2.hip.h)
+            if (strncmp(v, "t2:", 3) == 0 && ntaps == 128 && fmt == SXFIR_CF32) {
+                int wpg = 0, opt = 0;
+                if (sscanf(v + 3, "%d:%d", &wpg, &opt) == 2) {
+                    const void *k = nullptr;
+                    switch (wpg * 100 + opt) {
+#define SXFIR_X(WW, OO) case WW * 100 + OO: k = (const void *)sxfir::decim4_tile2_kernel<128, WW, OO>; break;
+                        SXFIR_TILE2_VARIANTS(SXFIR_X)
+#undef SXFIR_X
+                    }
+                    if (!k) {
+                        delete p;
+                        return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d", wpg, opt);
+                    }
+                    p->t2_wpg = wpg;
+                    p->t2_opt = opt;
+                    // occ_sb = resident WAVES per CU of this variant
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * wpg, 0) == hipSuccess && nb > 0)
+                        p->occ_sb = nb * wpg;
+                }
+            }
         }
-        if (const char *v = getenv("SXFIR_ABLATE")) p->ablate = atoi(v);
         if (const char *v = getenv("SXFIR_SCHED")) p->sched = atoi(v);
-        if (const char *v = getenv("SXFIR_OVERSUB")) p->oversub = atoi(v) > 0 ? atoi(v) : 1;
         if (const char *v = getenv("SXFIR_OCC")) {
             if (atoi(v) > 0) p->occ_sb = p->occ_db = atoi(v);
         }
+#endif
     }
 
     hipError_t e = hipMalloc((void **)&p->taps_dev, sizeof(float) * (size_t)ntaps);
@@ -334,6 +381,7 @@ int sxfir_set_tx_threshold(sxfir_plan *p, float tx_threshold2)
     return SXFIR_OK;
 }
 
+#ifdef SXFIR_PROFILING
 // Diagnostic (SXFIR_ABLATE=11/12 builds): median in-kernel shader clock in MHz of the last launch.
 int sxfir_debug_clock(sxfir_plan *p, double *mhz)
 {
@@ -357,6 +405,8 @@ int sxfir_debug_stamps(sxfir_plan *p, unsigned long long *host, size_t capacity_
     *n_records = n;
     return SXFIR_OK;
 }
+
+#endif  // SXFIR_PROFILING
 
 int sxfir_contract(const sxfir_plan *p, int *jsplit, int *cw)
 {
@@ -390,15 +440,17 @@ int sxfir_outputs_for(const sxfir_plan *p, size_t n_in, size_t *n_out)
     return SXFIR_OK;
 }
 
+// Generic path: the next call's history goes to the plan's other buffer (the caller swaps the two).
 static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, hipStream_t st)
 {
+    const dim3 grid((unsigned)((p->hist_len + 255) / 256), (unsigned)p->nchan);
     if (p->fmt != SXFIR_CF16)
-        hipLaunchKernelGGL(sxfir::history_kernel<float2>, dim3(p->nchan), dim3(256), 0, st,
-                           (float2 *)p->hist_dev, (const float2 *)in_dev, (long long)n_in, (long long)in_stride,
+        hipLaunchKernelGGL(sxfir::history_kernel<float2>, grid, dim3(256), 0, st, (float2 *)p->hist_alt,
+                           (const float2 *)p->hist_dev, (const float2 *)in_dev, (long long)n_in, (long long)in_stride,
                            (long long)p->hist_len, p->hist_len);
     else
-        hipLaunchKernelGGL(sxfir::history_kernel<uint32_t>, dim3(p->nchan), dim3(256), 0, st,
-                           (uint32_t *)p->hist_dev, (const uint32_t *)in_dev, (long long)n_in,
+        hipLaunchKernelGGL(sxfir::history_kernel<uint32_t>, grid, dim3(256), 0, st, (uint32_t *)p->hist_alt,
+                           (const uint32_t *)p->hist_dev, (const uint32_t *)in_dev, (long long)n_in,
                            (long long)in_stride, (long long)p->hist_len, p->hist_len);
     HIPCHECK(hipGetLastError());
     return SXFIR_OK;
@@ -441,14 +493,6 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         a.stamps = nullptr;
-        if (p->ablate == 3) {
-            const size_t need = (size_t)groups * p->nchan * W;
-            if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
-            if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 40 * need));
-            p->stamps_n = need;
-            a.stamps = (unsigned long long *)p->stamps_dev;
-        }
-        const int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps) + 100000 * p->ablate;
         if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 8: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
@@ -459,9 +503,24 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             *history_done = true;
             return SXFIR_OK;
         }
+        int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps);
+#ifdef SXFIR_PROFILING
+        if (p->ablate == 3) {
+            const size_t need = (size_t)groups * p->nchan * W;
+            if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
+            if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 40 * need));
+            p->stamps_n = need;
+            a.stamps = (unsigned long long *)p->stamps_dev;
+        }
+        key += 100000 * p->ablate;
+#endif
         switch (key) {
+#ifdef SXFIR_PROFILING
         case 100801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 1>), grid, dim3(64), 0, st, a); break;
         case 200801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 2>), grid, dim3(64), 0, st, a); break;
+        case 100804: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 1>), grid, dim3(256), 0, st, a); break;
+        case 200804: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 2>), grid, dim3(256), 0, st, a); break;
+        case 300804: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 3>), grid, dim3(256), 0, st, a); break;
         case 103204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 1>), grid, dim3(256), 0, st, a); break;
         case 203204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 2>), grid, dim3(256), 0, st, a); break;
         case 403204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 4>), grid, dim3(256), 0, st, a); break;
@@ -472,13 +531,14 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         case 313208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, true, 3>), grid, dim3(512), 0, st, a); break;
         case 1303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3, 4>), grid, dim3(512), 0, st, a); break;
         case 300802: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 2, false, 3>), grid, dim3(128), 0, st, a); break;
+#endif
 #define SXFIR_X(DD, WW, HH, PP) \
         case SXFIR_MULTI_KEY(DD, WW, HH, PP): \
             hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>), grid, dim3(64 * WW), 0, st, a); \
             break;
             SXFIR_MULTI_VARIANTS(SXFIR_X)
 #undef SXFIR_X
-        default: return fail(SXFIR_EUNSUPPORTED, "no multi kernel for ratio %d with %d waves", p->ratio, W);
+        default: return fail(SXFIR_EUNSUPPORTED, "no multi kernel for ratio %d with %d waves (mode %d)", p->ratio, W, key);
         }
         HIPCHECK(hipGetLastError());
         *history_done = true;
@@ -501,18 +561,53 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.in_stride = (long long)in_stride;
         a.out_stride = (long long)out_stride;
         a.hist_stride = p->hist_len;
-        const int tile_out = (p->sgpr_r && p->ntaps == 128) ? 64 * p->sgpr_r : 256;
+        int tile_out = 256;
+#ifdef SXFIR_PROFILING
+        if (p->sgpr_r && p->ntaps == 128) tile_out = 64 * p->sgpr_r;
+#endif
         const long long n_tiles = (n_out + tile_out - 1) / tile_out;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
-        // One resident generation of waves: every wave owns a contiguous run of tiles, so there is
-        // no tail of partly filled dispatch rounds and halo re-reads stay in the wave's own L1/L2.
+        a.n_tiles = (int)n_tiles;
+        a.sched = p->sched;
+        a.stamps = nullptr;
+#ifdef SXFIR_PROFILING
+        if (p->t2_wpg) {
+            // decim4_tile2_kernel: G workgroups of t2_wpg waves per channel, wave ww of workgroup b takes tiles
+            // (S(b) + i*G)*wpg + ww
+            const int wpg = p->t2_wpg;
+            const long long n_super = (n_tiles + wpg - 1) / wpg;
+            long long G = ((long long)p->compute_units * p->occ_sb * p->oversub / wpg) / p->nchan;
+            if (G < 1) G = 1;
+            if (G > n_super) G = n_super;
+            a.n_waves = (int)G;
+            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
+            a.run_base = a.run_extra = 0;
+            {
+                const long long last = n_tiles - 1, sup = last / wpg;
+                const int t = (int)(sup % G);
+                const int bb = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+                a.hist_wave = bb * wpg + (int)(last % wpg);
+            }
+            dim3 grid((unsigned)G, (unsigned)p->nchan);
+            switch ((wpg * 100 + p->t2_opt) * 10 + (p->ablate == 1 || p->ablate == 2 ? p->ablate : 0)) {
+#define SXFIR_X(WW, OO) \
+            case (WW * 100 + OO) * 10: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO>), grid, dim3(64 * WW), 0, st, a); break; \
+            case (WW * 100 + OO) * 10 + 1: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 1>), grid, dim3(64 * WW), 0, st, a); break;
+                SXFIR_TILE2_VARIANTS(SXFIR_X)
+#undef SXFIR_X
+            default: return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d ablate %d", wpg, p->t2_opt, p->ablate);
+            }
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
+        }
+#endif
+        // Short-lived waves in generations: W = CUs * resident waves * oversub waves per launch, each covering
+        // n_tiles / W tiles in strided, XCD-blocked passes (sxfir_decim_tile.hip.h).
         const bool dbuf = p->tile_dbuf;
         long long per_chan = ((long long)p->compute_units * (dbuf ? p->occ_db : p->occ_sb) * p->oversub) / p->nchan;
         if (per_chan < 1) per_chan = 1;
         if (per_chan > n_tiles) per_chan = n_tiles;
-        a.n_tiles = (int)n_tiles;
         a.n_waves = (int)per_chan;
-        a.sched = p->sched;
         {
             const int W = (int)per_chan, last = (int)n_tiles - 1;
             a.w8 = (W % 8 == 0) ? W / 8 : 0;
@@ -525,36 +620,46 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
             }
         }
-        a.stamps = nullptr;
+        dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
+#ifdef SXFIR_PROFILING
         if (p->ablate == 11 || p->ablate == 12) {
             // diagnostic build: one {cycles, ticks} pair per wave, printed by sxfir_debug_clock()
             if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 16 * (size_t)per_chan * p->nchan));
             p->stamps_n = (size_t)per_chan * p->nchan;
             a.stamps = (unsigned long long *)p->stamps_dev;
         }
-        dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
-        if (p->fmt == SXFIR_S32) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->sgpr_r == 8) {
-            hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<8>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->sgpr_r == 4) {
-            hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<4>), grid, dim3(64), 0, st, a);
-        } else if (p->ntaps == 128 && p->ablate != 0) {
-            // profiling builds of the same kernel (SXFIR_ABLATE, sxfir_decim_tile.hip.h): wrong results
-            switch (p->ablate) {
+        if (p->fmt == SXFIR_CF32 && p->ntaps == 128 && (p->sgpr_r || p->ablate != 0 || dbuf)) {
+            if (p->sgpr_r == 8) {
+                hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<8>), grid, dim3(64), 0, st, a);
+            } else if (p->sgpr_r == 4) {
+                hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<4>), grid, dim3(64), 0, st, a);
+            } else if (p->ablate != 0) {
+                // profiling builds of the same kernel (SXFIR_ABLATE, sxfir_decim_tile.hip.h): wrong results
+                switch (p->ablate) {
 #define SXFIR_X(N) \
-            case N: hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, N>), grid, dim3(64), 0, st, a); break;
-                SXFIR_TILE_ABLATIONS(SXFIR_X)
+                case N: hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, N>), grid, dim3(64), 0, st, a); break;
+                    SXFIR_TILE_ABLATIONS(SXFIR_X)
 #undef SXFIR_X
-            default: return fail(SXFIR_EINVAL, "SXFIR_ABLATE=%d is not a profiling mode of the tile kernel", p->ablate);
+                default: return fail(SXFIR_EINVAL, "SXFIR_ABLATE=%d is not a profiling mode of the tile kernel", p->ablate);
+                }
+            } else {
+                hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
             }
-        } else if (p->ntaps == 128) {
-            if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);
-        } else {
-            if (dbuf) hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, true>), grid, dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, false>), grid, dim3(64), 0, st, a);
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
         }
+        if (p->fmt == SXFIR_CF32 && p->ntaps == 64 && dbuf) {
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, true>), grid, dim3(64), 0, st, a);
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
+        }
+#endif
+        if (p->fmt == SXFIR_S32)
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
+        else if (p->ntaps == 128)
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, false>), grid, dim3(64), 0, st, a);
     } else {
         sxfir::GenericArgs a;
         a.in = in_dev;
@@ -613,12 +718,11 @@ int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_str
         rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
         if (rc) return rc;
     }
-    if (history_done) {
-        std::swap(p->hist_dev, p->hist_alt);
-    } else {
+    if (!history_done) {
         rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
         if (rc) return rc;
     }
+    std::swap(p->hist_dev, p->hist_alt);
     p->consumed += (long long)n_in;
     p->produced += n_out;
     if (n_out_p) *n_out_p = (size_t)n_out;
@@ -709,6 +813,7 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     HIPCHECK(hipGetLastError());
     rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
     if (rc) return rc;
+    std::swap(p->hist_dev, p->hist_alt);
     p->consumed += (long long)n_in;
     p->produced += n_out;
     if (n_out_p) *n_out_p = (size_t)n_out;

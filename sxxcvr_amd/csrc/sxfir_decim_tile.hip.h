@@ -101,11 +101,26 @@ struct DecimTileCtx {
     const float *in, *hist;
     float *out;
     long long n_out, last_chunk;
+    int n_odd;              // n_in is odd: the last chunk holds one valid sample (never fetched as 16 bytes)
     int lane, g, p;
     // byte offset (from the tile's first staged chunk) of the chunk each DMA instruction fetches for
     // this lane: tile-invariant, 32 bits, so that the DMA uses the SGPR-base + VGPR-offset form
     unsigned boff[DecimTile4<NT>::NLOAD];
 };
+
+// One 16-byte chunk of an edge tile.  With an odd n_in the last chunk holds one valid sample: its second
+// half lies beyond the caller's buffer (possibly beyond the allocation) and is never touched; that lane
+// fetches 8 bytes through a register instead of taking part in the DMA.
+template <int NT>
+__device__ __forceinline__ void stage_edge_chunk(const DecimTileCtx<NT> &c, long long ch, const f32x4 *src, f32x4 *slot0)
+{
+    if (c.n_odd && ch == c.last_chunk) {
+        const float2 v = *reinterpret_cast<const float2 *>(src);
+        slot0[c.lane] = (f32x4){v.x, v.y, 0.0f, 0.0f};
+    } else {
+        glds16(src, slot0);
+    }
+}
 
 // HBM -> LDS for one tile, no VGPR round trip.  Slot q = 64*i + lane of the
 // buffer holds logical chunk q - (q+1)/17 (a pad slot re-loads its left
@@ -115,7 +130,7 @@ __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, 
 {
     using C = DecimTile4<NT>;
     const long long c0 = ((long long)tile * C::TILE_IN - C::HALO) >> 1;   // first chunk staged (may be < 0)
-    const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk);
+    const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk - c.n_odd);
     if (interior) {
         const char *src = reinterpret_cast<const char *>(reinterpret_cast<const f32x4 *>(c.in) + c0);
 #pragma unroll
@@ -139,7 +154,7 @@ __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, 
                 if (ch > c.last_chunk) ch = c.last_chunk;
                 src = reinterpret_cast<const f32x4 *>(c.in) + ch;
             }
-            glds16(src, buf + 64 * i);
+            stage_edge_chunk(c, ch, src, buf + 64 * i);
         }
     }
 }
@@ -338,6 +353,7 @@ __global__ __launch_bounds__(64) void decim4_tile_kernel(const DecimTileArgs a)
     c.out = a.out + 2 * a.out_stride * ch;
     c.n_out = a.n_out;
     c.last_chunk = (a.n_in - 1) >> 1;                 // last input chunk holding a valid sample
+    c.n_odd = (int)(a.n_in & 1);
 #pragma unroll
     for (int i = 0; i < C::NLOAD; ++i) {
         const unsigned q = 64u * i + c.lane;

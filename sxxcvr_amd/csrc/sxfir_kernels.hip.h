@@ -185,24 +185,18 @@ __global__ __launch_bounds__(256) void interp_generic_kernel(const GenericArgs a
     FO::store(out, n, make_float2(pi[0], pq[0]), a.thr2);
 }
 
-// History carry-over: hist <- last hist_len samples of (hist ++ in[0, n_in)).
-// One workgroup per channel; reads complete before any write (same buffer).
+// History carry-over for the generic path: hist_out <- last hist_len samples of (hist ++ in[0, n_in)).
+// Out of place (the plan keeps two history buffers and swaps them, as the tiled kernels do), so it is
+// one element per thread over a grid of any size: no limit on hist_len.
 template <typename S>
-__global__ __launch_bounds__(256) void history_kernel(S *hist, const S *in, long long n_in, long long in_stride,
-                                                      long long hist_stride, int hist_len)
+__global__ __launch_bounds__(256) void history_kernel(S *hist_out, const S *hist, const S *in, long long n_in,
+                                                      long long in_stride, long long hist_stride, int hist_len)
 {
-    const int ch = blockIdx.x;
-    S *h = hist + hist_stride * ch;
-    const S *x = in + in_stride * ch;
-    S keep[8];
-    int cnt = 0;
-    for (int j = threadIdx.x; j < hist_len; j += blockDim.x, ++cnt) {
-        const long long s = n_in - hist_len + j;
-        keep[cnt] = s >= 0 ? x[s] : h[s + hist_len];
-    }
-    __syncthreads();
-    cnt = 0;
-    for (int j = threadIdx.x; j < hist_len; j += blockDim.x, ++cnt) h[j] = keep[cnt];
+    const int ch = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= hist_len) return;
+    const long long s = n_in - hist_len + j;
+    hist_out[hist_stride * ch + j] = s >= 0 ? in[in_stride * ch + s] : hist[hist_stride * ch + s + hist_len];
 }
 
 // ---- synthetic IQ source: splitmix64 stream keyed by (seed, channel) --------

@@ -8,12 +8,16 @@ import ctypes as C
 
 import numpy as np
 
-from ._native import check, load_sxfir
+from ._native import check as _check, load_sxfir
 
 DECIMATE, INTERPOLATE = 0, 1
 CF32, CF16, S32 = 0, 1, 2
 KERNEL_AUTO, KERNEL_TILED, KERNEL_GENERIC = 0, 1, 2
 _FMT = {"CF32": CF32, "CF16": CF16, "S32": S32, CF32: CF32, CF16: CF16, S32: S32}
+
+
+def check(rc, lib=None):
+    _check(rc, lib)
 
 
 def design_lowpass(ntaps, ratio, beta=8.0, gain=1.0):
@@ -42,13 +46,16 @@ def synth_fill(out, seed, first_channel=0, start=0, fmt="CF32"):
 class Resampler:
     """One sxfir plan: `nchan` independent channels of one GPU."""
 
-    def __init__(self, mode, taps, ratio, nchan=1, fmt="CF32", device=-1):
-        self._lib = load_sxfir()
+    def __init__(self, mode, taps, ratio, nchan=1, fmt="CF32", device=-1, profiling=False):
+        self._lib = load_sxfir(profiling)
         self._plan = C.c_void_p()
         taps = np.ascontiguousarray(taps, dtype=np.float32)
         self.mode, self.ratio, self.nchan, self.fmt, self.ntaps = mode, int(ratio), int(nchan), _FMT[fmt], taps.size
-        check(self._lib.sxfir_create(C.byref(self._plan), mode, taps.ctypes.data_as(C.c_void_p), taps.size,
+        self._ck(self._lib.sxfir_create(C.byref(self._plan), mode, taps.ctypes.data_as(C.c_void_p), taps.size,
                                      int(ratio), int(nchan), self.fmt, int(device)))
+
+    def _ck(self, rc):
+        _check(rc, self._lib)      # error text from the library this plan lives in
 
     def close(self):
         if self._plan:
@@ -65,40 +72,40 @@ class Resampler:
     @property
     def contract(self):
         a, b = C.c_int(), C.c_int()
-        check(self._lib.sxfir_contract(self._plan, C.byref(a), C.byref(b)))
+        self._ck(self._lib.sxfir_contract(self._plan, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     @property
     def position(self):
         a, b = C.c_int64(), C.c_int64()
-        check(self._lib.sxfir_position(self._plan, C.byref(a), C.byref(b)))
+        self._ck(self._lib.sxfir_position(self._plan, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def outputs_for(self, n_in):
         n = C.c_size_t()
-        check(self._lib.sxfir_outputs_for(self._plan, n_in, C.byref(n)))
+        self._ck(self._lib.sxfir_outputs_for(self._plan, n_in, C.byref(n)))
         return n.value
 
     def set_kernel(self, kernel):
-        check(self._lib.sxfir_set_kernel(self._plan, kernel))
+        self._ck(self._lib.sxfir_set_kernel(self._plan, kernel))
 
     def set_tx_threshold(self, threshold2):
-        check(self._lib.sxfir_set_tx_threshold(self._plan, float(threshold2)))
+        self._ck(self._lib.sxfir_set_tx_threshold(self._plan, float(threshold2)))
 
     def reset(self, stream=None):
-        check(self._lib.sxfir_reset(self._plan, C.c_void_p(stream or 0)))
+        self._ck(self._lib.sxfir_reset(self._plan, C.c_void_p(stream or 0)))
 
     # -- raw pointers ---------------------------------------------------------
     def process_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, stream=0):
         n_out = C.c_size_t()
         fn = self._lib.sxfir_decimate if self.mode == DECIMATE else self._lib.sxfir_interpolate
-        check(fn(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr), out_stride, C.byref(n_out),
+        self._ck(fn(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr), out_stride, C.byref(n_out),
                  C.c_void_p(stream)))
         return n_out.value
 
     def time_decimate_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream=0):
         ms = C.c_float()
-        check(self._lib.sxfir_time_decimate(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+        self._ck(self._lib.sxfir_time_decimate(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
                                             out_stride, iters, C.c_void_p(stream), C.byref(ms)))
         return ms.value
 
@@ -128,6 +135,11 @@ class Resampler:
         if out is None:
             out = torch.empty((self.nchan, n_out), dtype=out_dtype, device=x2.device)
         o2 = out.unsqueeze(0) if out.dim() == 1 else out
+        # the kernel writes through a raw pointer: a caller-supplied `out` must really hold the result
+        if (o2.dim() != 2 or o2.shape[0] != self.nchan or o2.shape[1] < n_out or (o2.shape[1] > 1 and o2.stride(1) != 1)
+                or o2.dtype != out_dtype or o2.device != x2.device):
+            raise ValueError("out must be a [nchan=%d, >=%d] %s tensor with unit sample stride on %s" % (
+                self.nchan, n_out, out_dtype, x2.device))
         got = self.process_ptr(x2.data_ptr(), n_in, x2.stride(0) if self.nchan > 1 else n_in, o2.data_ptr(),
                                o2.stride(0) if self.nchan > 1 else max(n_out, 1),
                                torch.cuda.current_stream(x2.device).cuda_stream)

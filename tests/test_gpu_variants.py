@@ -1,6 +1,9 @@
 """Every selectable variant of the decimate-by-4 tile kernel (tools/kbench.py's A/B knobs) must
 produce the bits of the default kernel: double-buffered LDS-DMA, contiguous-run schedule, packed
-FMA arithmetic, SGPR-resident taps, different wave counts."""
+FMA arithmetic, SGPR-resident taps, different wave counts, and the second-generation tile kernel
+(deferred stores, separate tap fetch, multi-wave workgroups).  These variants live in the PROFILING
+build of the library (libsxfir_prof.so, Resampler(profiling=True)); the production library has no
+knobs, which test_production_library_ignores_the_environment checks."""
 import os
 
 import numpy as np
@@ -23,7 +26,12 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_ABLATE": "3"},
     {"SXFIR_TILE_VARIANT": "sg"},
     {"SXFIR_TILE_VARIANT": "sg4"},
-])
+] + [{"SXFIR_TILE_VARIANT": "t2:%d:%d" % (w, o), "SXFIR_OVERSUB": ov, "SXFIR_SCHED": sc}
+     for (w, o, ov, sc) in [(1, 0, "16", "0"), (1, 1, "16", "0"), (1, 2, "64", "2"), (1, 3, "3", "0"), (1, 4, "2", "0"),
+                            (1, 5, "16", "0"), (1, 6, "1", "2"), (1, 7, "16", "0"), (1, 9, "16", "0"), (1, 11, "7", "0"),
+                            (2, 0, "16", "0"), (2, 1, "5", "2"), (2, 2, "64", "2"), (2, 3, "16", "0"), (2, 6, "16", "0"),
+                            (2, 7, "3", "0"), (4, 2, "64", "2"), (4, 3, "16", "0"), (4, 7, "16", "0"), (8, 2, "64", "2"),
+                            (8, 3, "16", "0")]])
 def test_variant_matches_oracle(oracle, monkeypatch, env):
     for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
@@ -32,7 +40,7 @@ def test_variant_matches_oracle(oracle, monkeypatch, env):
     h = sxxcvr_amd.design_lowpass(128, 4)
     n = (1 << 20) + 4 * 77
     x = oracle.synth_iq(0x51255, 4, 0, n + 4096)
-    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4)             # knobs are read at plan creation
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, profiling=True)     # knobs are read at plan creation
     plan.set_kernel(KERNEL_TILED)
     y1 = to_cpu(plan.process(to_gpu(x[:n])))
     y2 = to_cpu(plan.process(to_gpu(x[n:])))                # exercises the fused history carry-over
@@ -54,7 +62,7 @@ def test_quarter_row_split_variant(oracle, monkeypatch, D, n_in):
     n_in -= n_in % D
     h = sxxcvr_amd.design_lowpass(32 * D, D)
     x = oracle.synth_iq(0x51255, 21, 0, n_in + 2048)
-    plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D, profiling=True)
     plan.set_kernel(KERNEL_TILED)
     assert plan.contract == (4, 4)
     y = np.concatenate([to_cpu(plan.process(to_gpu(x[:n_in]))), to_cpu(plan.process(to_gpu(x[n_in:])))])
@@ -62,9 +70,27 @@ def test_quarter_row_split_variant(oracle, monkeypatch, D, n_in):
     if D != 4:
         x16 = oracle.f32_to_f16(x.view(np.float32))
         xq = oracle.f16_to_f32(x16).view(np.complex64)
-        p16 = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
+        p16 = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16", profiling=True)
         p16.set_kernel(KERNEL_TILED)
         assert p16.contract == (4, 4)
         got = to_cpu(p16.process(to_gpu(x16.view(np.uint32).view(np.int32)))).view(np.uint16)
         want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, 4, 4).view(np.float32))
         assert np.array_equal(got, want), "quarter split CF16 D=%d" % D
+
+
+def test_production_library_ignores_the_environment(oracle, monkeypatch):
+    """A drop-in driver must not change its arithmetic because an environment variable is set: with the
+    profiling knobs in the environment (one of them an ablation mode that gives wrong results in the
+    profiling build) the production library still produces the oracle's bits with its default contract."""
+    monkeypatch.setenv("SXFIR_ABLATE", "1")
+    monkeypatch.setenv("SXFIR_TILE_VARIANT", "sg")
+    monkeypatch.setenv("SXFIR_OVERSUB", "3")
+    monkeypatch.setenv("SXFIR_MULTI_PS", "4")
+    for D in (4, 8):
+        h = sxxcvr_amd.design_lowpass(32 * D, D)
+        n = 1 << 18
+        x = oracle.synth_iq(0x51255, 9, 0, n)
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
+        plan.set_kernel(KERNEL_TILED)
+        assert plan.contract == (2, 4)
+        assert_bit_exact(to_cpu(plan.process(to_gpu(x))), oracle.decim_f32(h, D, x, 2, 4), "production D=%d" % D)

@@ -1,4 +1,5 @@
-"""Kernel-variant A/B on one GPU, interleaved rounds in one process (profiling aid)."""
+"""Kernel-variant A/B on one GPU, interleaved rounds in one process (profiling aid; uses the profiling
+build of the library, libsxfir_prof.so, whose knobs are environment variables read at plan creation)."""
 import os, sys, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +29,7 @@ y = ybase[yoff:yoff + nchan * (n // D) * (8 if FMT == "CF32" else 4)].view(dt).v
 taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched in configs:
-    os.environ["SXFIR_TILE_VARIANT"] = v
+    os.environ["SXFIR_TILE_VARIANT"] = v.replace(".", ":")      # "t2.2.3" -> "t2:2:3" (tile2 kernel: waves per workgroup, option bits)
     os.environ.pop("SXFIR_MULTI_W", None); os.environ.pop("SXFIR_MULTI_PS", None)
     if v[0] == "w":                                  # "w4": multi kernel, 4 waves per workgroup; "w8p4": 4-way row split
         w, _, ps = v[1:].partition("p")
@@ -39,7 +40,7 @@ for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_SCHED"] = str(sched)
     if occ: os.environ["SXFIR_OCC"] = str(occ)
     else: os.environ.pop("SXFIR_OCC", None)
-    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, D, nchan=nchan, fmt=FMT))
+    plans.append(sxxcvr_amd.Resampler(DECIMATE, taps, D, nchan=nchan, fmt=FMT, profiling=True))
 ref = None
 res = {c: [] for c in configs}
 st = torch.cuda.current_stream().cuda_stream

@@ -2,7 +2,7 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cmd = ["hipcc", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--offload-arch=gfx950", "-O3", "--cuda-device-only",
-       "-c", os.path.join(ROOT, "sxxcvr_amd/csrc/sxfir.hip"), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+       "-DSXFIR_PROFILING", "-c", os.path.join(ROOT, "sxxcvr_amd/csrc/sxfir.hip"), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in err.splitlines():
