@@ -25,6 +25,8 @@ int sxfir_debug_clock(sxfir_plan *plan, double *mhz);
 /* SXFIR_ABLATE=3 on the multi-column decimator: copies the raw per-wave stamp records of the last launch
  * (5 x uint64 each: tiles, cycles in reduction + store, waiting for data, arithmetic, barrier + issuing the
  * next tile's DMAs) to `host`; returns the number of records through *n_records. */
+/* SXFIR_ABLATE=5 on the tile2 /4 kernel: records of 8 x uint64 {tiles, cycles issuing DMAs, waiting for data,
+ * FIR arithmetic, output transposition + stores, whole-wave cycles, whole-wave 100 MHz ticks, 0}. */
 int sxfir_debug_stamps(sxfir_plan *plan, unsigned long long *host, size_t capacity_records, size_t *n_records);
 
 #ifdef __cplusplus

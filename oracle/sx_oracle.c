@@ -55,6 +55,23 @@ void sxo_convert_rx(const int32_t *src, float *dst, size_t n)
         dst[i] = scaling * (float)src[i];
 }
 
+/* convert_rx over `threads` threads (bench.py's conversion-only CPU figure: this loop is all the arithmetic
+ * the reference's readStream does per sample, SoapySX.cpp:953). */
+void sxo_convert_rx_mt(const int32_t *src, float *dst, size_t n, int threads)
+{
+    const int64_t chunk = 1 << 16;
+    const int64_t nchunks = ((int64_t)n + chunk - 1) / chunk;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+    for (int64_t c = 0; c < nchunks; c++) {
+        const int64_t b = c * chunk;
+        const int64_t len = b + chunk <= (int64_t)n ? chunk : (int64_t)n - b;
+        sxo_convert_rx(src + 2 * b, dst + 2 * b, (size_t)len);
+    }
+}
+
 /* float -> int32 as the reference's real platform (ARM, saturating vcvt) does
  * it.  The reference's C++ (SoapySX.cpp:124-125) converts 2^31 * 1.0f, which
  * overflows int32 (undefined behaviour in C++; x86 yields INT32_MIN, the
@@ -124,6 +141,22 @@ void sxo_synth_iq(uint64_t seed, uint32_t channel, int64_t start, size_t n, floa
         const int32_t b = (int32_t)((u >> 16) & 0xFFFFFF) - 8388608;
         out[2 * i] = (float)a * (1.0f / 8388608.0f);
         out[2 * i + 1] = (float)b * (1.0f / 8388608.0f);
+    }
+}
+
+/* The same stream produced by `threads` threads (the source is a pure function of the index). */
+void sxo_synth_iq_mt(uint64_t seed, uint32_t channel, int64_t start, size_t n, float *out, int threads)
+{
+    const int64_t chunk = 1 << 16;
+    const int64_t nchunks = ((int64_t)n + chunk - 1) / chunk;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+    for (int64_t c = 0; c < nchunks; c++) {
+        const int64_t b = c * chunk;
+        const int64_t len = b + chunk <= (int64_t)n ? chunk : (int64_t)n - b;
+        sxo_synth_iq(seed, channel, start + b, (size_t)len, out + 2 * b);
     }
 }
 
@@ -347,14 +380,10 @@ int sxo_decim_f32_mt(const float *h, int ntaps, int D, int jsplit, int cw, const
     return 0;
 }
 
-int sxo_interp_f32(const float *h, int ntaps, int L, int groups, const float *x,
-                   size_t n_x, int64_t n0, size_t n_out, float *y)
+static int interp_f32_range(const float *h, int L, int groups, int gl, const float *x, size_t n_x, int64_t n0,
+                            size_t o_begin, size_t o_end, float *y)
 {
-    const int jt = ntaps / L;
-    if (ntaps < 1 || L < 1 || ntaps % L || n0 < 0) return -2;
-    if (!pow2(groups) || groups > SXO_MAX_GROUPS || jt % groups) return -2;
-    const int gl = jt / groups;
-    for (size_t o = 0; o < n_out; o++) {
+    for (size_t o = o_begin; o < o_end; o++) {
         const int64_t n = n0 + (int64_t)o;
         const int64_t q = n / L;
         const int r = (int)(n % L);
@@ -375,6 +404,38 @@ int sxo_interp_f32(const float *h, int ntaps, int L, int groups, const float *x,
         }
         y[2 * o] = tree_sum(ti, groups);
         y[2 * o + 1] = tree_sum(tq, groups);
+    }
+    return 0;
+}
+
+int sxo_interp_f32(const float *h, int ntaps, int L, int groups, const float *x,
+                   size_t n_x, int64_t n0, size_t n_out, float *y)
+{
+    const int jt = ntaps / L;
+    if (ntaps < 1 || L < 1 || ntaps % L || n0 < 0) return -2;
+    if (!pow2(groups) || groups > SXO_MAX_GROUPS || jt % groups) return -2;
+    return interp_f32_range(h, L, groups, jt / groups, x, n_x, n0, 0, n_out, y);
+}
+
+/* The same outputs, computed by `threads` threads over blocks of outputs (whole-stream parity checks). */
+int sxo_interp_f32_mt(const float *h, int ntaps, int L, int groups, const float *x,
+                      size_t n_x, int64_t n0, size_t n_out, float *y, int threads)
+{
+    const int jt = ntaps / L;
+    if (ntaps < 1 || L < 1 || ntaps % L || n0 < 0) return -2;
+    if (!pow2(groups) || groups > SXO_MAX_GROUPS || jt % groups) return -2;
+    if (n_out && (n0 + (int64_t)n_out - 1) / L >= (int64_t)n_x) return -1;
+    const int64_t chunk = 16384;
+    const int64_t nchunks = ((int64_t)n_out + chunk - 1) / chunk;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+    for (int64_t c = 0; c < nchunks; c++) {
+        const size_t b = (size_t)(c * chunk);
+        size_t e = b + (size_t)chunk;
+        if (e > n_out) e = n_out;
+        (void)interp_f32_range(h, L, groups, jt / groups, x, n_x, n0, b, e, y);
     }
     return 0;
 }

@@ -43,11 +43,13 @@ long long sxo_time_ns_to_ticks(long long time_ns, double rate);
 /* ---- a-3 / a-4: sample conversion (SoapySX.cpp:103-112, :116-137) ---- */
 /* n = number of complex samples; buffers hold 2*n scalars, I/Q interleaved. */
 void sxo_convert_rx(const int32_t *src, float *dst, size_t n);
+void sxo_convert_rx_mt(const int32_t *src, float *dst, size_t n, int threads);
 void sxo_convert_tx(const float *src, int32_t *dst, size_t n, float tx_threshold2);
 
 /* ---- synthetic CF32 IQ source (replaces the ALSA/I2S feed) ---- */
 /* out[2*i], out[2*i+1] = I, Q of absolute sample index start+i; index < 0 -> 0. */
 void sxo_synth_iq(uint64_t seed, uint32_t channel, int64_t start, size_t n, float *out);
+void sxo_synth_iq_mt(uint64_t seed, uint32_t channel, int64_t start, size_t n, float *out, int threads);
 
 /* ---- low-pass prototype: Kaiser-windowed sinc, cutoff 0.5/ratio, sum = gain ---- */
 void sxo_design_lowpass(int ntaps, int ratio, double beta, double gain, float *taps);

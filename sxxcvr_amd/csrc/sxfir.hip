@@ -37,7 +37,10 @@
 // (waves per workgroup, option bits) variants of decim4_tile2_kernel<128>
 #define SXFIR_TILE2_VARIANTS(X) \
     X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 9) X(1, 11) \
-    X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3)
+    X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
+    X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51)
+// variants that also exist with phase stamps (ABL 5)
+#define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5)
 #else
 #define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
 #endif
@@ -46,6 +49,7 @@
 #ifdef SXFIR_PROFILING
 #include "sxfir_decim_sgpr.hip.h"
 #include "sxfir_decim_tile2.hip.h"
+#include "sxfir_decim_s2.hip.h"
 #include "../../include/sxfir_prof.h"
 #endif
 #include "sxfir_kernels.hip.h"
@@ -98,6 +102,7 @@ struct sxfir_plan {
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int t2_wpg, t2_opt;    // profiling only: decim4_tile2_kernel variant (waves per workgroup, T2_* bits); wpg 0 = off
+    int s2_opt;            // profiling only: decim4_s2_kernel (scalar taps) with these T2_* bits; -1 = off
     int compute_units;
     float *taps_dev;
     void *hist_dev;        // current history: nchan * hist_len samples
@@ -230,6 +235,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
     p->t2_wpg = p->t2_opt = 0;
+    p->s2_opt = -1;
     p->occ_multi = 2;
     // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's prologue
     // (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16; the
@@ -298,6 +304,18 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                                : (const void *)sxfir::decim4_sgpr_kernel<4>;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0)
                     p->occ_sb = nb;
+            }
+            // "s2:<option bits>": decim4_s2_kernel (taps as scalar operands, sxfir_decim_s2.hip.h)
+            if (strncmp(v, "s2:", 3) == 0 && ntaps == 128 && fmt == SXFIR_CF32) {
+                const int opt = atoi(v + 3);
+                const void *k = opt == 0 ? (const void *)sxfir::decim4_s2_kernel<0>
+                                : opt == 1 ? (const void *)sxfir::decim4_s2_kernel<1> : nullptr;
+                if (!k) {
+                    delete p;
+                    return fail(SXFIR_EUNSUPPORTED, "no s2 variant %d", opt);
+                }
+                p->s2_opt = opt;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
             }
             // "t2:<waves per workgroup>:<option bits>": decim4_tile2_kernel (sxfir_decim_tile2.hip.h)
             if (strncmp(v, "t2:", 3) == 0 && ntaps == 128 && fmt == SXFIR_CF32) {
@@ -399,9 +417,10 @@ int sxfir_debug_clock(sxfir_plan *p, double *mhz)
 
 int sxfir_debug_stamps(sxfir_plan *p, unsigned long long *host, size_t capacity_records, size_t *n_records)
 {
-    if (!p || !host || !n_records || !p->stamps_dev || p->ablate != 3) return fail(SXFIR_EINVAL, "no stamps recorded");
+    if (!p || !host || !n_records || !p->stamps_dev || (p->ablate != 3 && p->ablate != 5)) return fail(SXFIR_EINVAL, "no stamps recorded");
     const size_t n = p->stamps_n < capacity_records ? p->stamps_n : capacity_records;
-    HIPCHECK(hipMemcpy(host, p->stamps_dev, 40 * n, hipMemcpyDeviceToHost));
+    // records: 5 x uint64 (multi-column kernel, ablate 3) or 8 x uint64 (tile2 kernel, ablate 5)
+    HIPCHECK(hipMemcpy(host, p->stamps_dev, (p->ablate == 5 ? 64 : 40) * n, hipMemcpyDeviceToHost));
     *n_records = n;
     return SXFIR_OK;
 }
@@ -571,6 +590,37 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.sched = p->sched;
         a.stamps = nullptr;
 #ifdef SXFIR_PROFILING
+        if (p->s2_opt >= 0) {
+            long long G = ((long long)p->compute_units * p->occ_sb * p->oversub) / p->nchan;
+            if (G < 1) G = 1;
+            if (G > n_tiles) G = n_tiles;
+            a.n_waves = (int)G;
+            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
+            a.run_base = a.run_extra = 0;
+            {
+                const int t = (int)((n_tiles - 1) % G);
+                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+            }
+            dim3 grid((unsigned)G, (unsigned)p->nchan);
+            if (p->ablate == 5) {
+                const size_t need = (size_t)G * p->nchan;
+                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
+                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
+                p->stamps_n = need;
+                a.stamps = (unsigned long long *)p->stamps_dev;
+            }
+            switch (p->s2_opt * 10 + (p->ablate == 1 || p->ablate == 5 ? p->ablate : 0)) {
+            case 0: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<0>), grid, dim3(64), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<0, 1>), grid, dim3(64), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<0, 5>), grid, dim3(64), 0, st, a); break;
+            case 10: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<1>), grid, dim3(64), 0, st, a); break;
+            case 11: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<1, 1>), grid, dim3(64), 0, st, a); break;
+            case 15: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<1, 5>), grid, dim3(64), 0, st, a); break;
+            default: return fail(SXFIR_EUNSUPPORTED, "no s2 variant %d ablate %d", p->s2_opt, p->ablate);
+            }
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
+        }
         if (p->t2_wpg) {
             // decim4_tile2_kernel: G workgroups of t2_wpg waves per channel, wave ww of workgroup b takes tiles
             // (S(b) + i*G)*wpg + ww
@@ -579,21 +629,38 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             long long G = ((long long)p->compute_units * p->occ_sb * p->oversub / wpg) / p->nchan;
             if (G < 1) G = 1;
             if (G > n_super) G = n_super;
-            a.n_waves = (int)G;
             a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
             a.run_base = a.run_extra = 0;
-            {
+            if (p->t2_opt & sxfir::T2_HCARRY) {
+                // contiguous runs of K tiles per wave, waves numbered in dispatch order
+                const long long K = (n_tiles + G * wpg - 1) / (G * wpg);
+                G = ((n_tiles + K - 1) / K + wpg - 1) / wpg;          // workgroups that have a tile
+                a.run_base = (int)K;
+                a.hist_wave = (int)((n_tiles - 1) / K);
+            } else {
                 const long long last = n_tiles - 1, sup = last / wpg;
                 const int t = (int)(sup % G);
                 const int bb = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
                 a.hist_wave = bb * wpg + (int)(last % wpg);
             }
+            a.n_waves = (int)G;
             dim3 grid((unsigned)G, (unsigned)p->nchan);
-            switch ((wpg * 100 + p->t2_opt) * 10 + (p->ablate == 1 || p->ablate == 2 ? p->ablate : 0)) {
+            if (p->ablate == 5) {
+                const size_t need = (size_t)G * p->nchan * wpg;
+                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
+                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
+                p->stamps_n = need;
+                a.stamps = (unsigned long long *)p->stamps_dev;
+            }
+            switch ((wpg * 100 + p->t2_opt) * 10 + (p->ablate == 1 || p->ablate == 2 || p->ablate == 5 ? p->ablate : 0)) {
 #define SXFIR_X(WW, OO) \
             case (WW * 100 + OO) * 10: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO>), grid, dim3(64 * WW), 0, st, a); break; \
             case (WW * 100 + OO) * 10 + 1: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 1>), grid, dim3(64 * WW), 0, st, a); break;
                 SXFIR_TILE2_VARIANTS(SXFIR_X)
+#undef SXFIR_X
+#define SXFIR_X(WW, OO) \
+            case (WW * 100 + OO) * 10 + 5: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 5>), grid, dim3(64 * WW), 0, st, a); break;
+                SXFIR_TILE2_STAMPED(SXFIR_X)
 #undef SXFIR_X
             default: return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d ablate %d", wpg, p->t2_opt, p->ablate);
             }

@@ -16,6 +16,10 @@
 //           current tile is computed and retired by a counted vmcnt.
 //   WPG     waves per workgroup, each with a private tile image (no barriers): the
 //           taps' LDS copy and the dispatch cost are shared.
+//   HCARRY  a wave takes a CONTIGUOUS run of tiles and keeps the 128-sample halo in
+//           LDS (one ds_read_b128 + ds_write_b128 per lane and tile) instead of
+//           fetching it again: 11 % fewer bytes through the L2 -> LDS path.
+//   PRIO    the wave raises its priority for the arithmetic of a tile.
 //
 // New code: the reference decimates inside the SX1255 (SoapySX.cpp:180-208 only
 // programs the divider); this kernel plays that role for SoapySX::readStream
@@ -26,29 +30,38 @@
 
 namespace sxfir {
 
-enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8 };
+enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32 };
 
-// HBM -> LDS for one tile into an image of exactly C::SLOTS slots (the last DMA
-// instruction is issued for the lanes that still fall inside it).
-template <int NT>
-__device__ __forceinline__ void stage_tile2(const DecimTileCtx<NT> &c, int tile, f32x4 *buf)
+// byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
+__device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
+{
+    unsigned off = q - (((q + 1u) * 3856u) >> 16);                        // (q+1)/17, exact for q < 4096
+    off = off < chunks ? off : chunks - 1u;
+    return 16u * off;
+}
+
+// HBM -> LDS for the slots [Q0, Q0 + 64*(NI-1) + LASTL) of one tile's image: DMA instruction j fills the slots
+// Q0 + 64j + lane from the per-lane byte offsets off[j] (tile-invariant, see slot_source_offset).  The last
+// instruction is issued for LASTL lanes.
+template <int NT, int Q0, int NI, int LASTL>
+__device__ __forceinline__ void stage_range(const DecimTileCtx<NT> &c, int tile, f32x4 *buf, const unsigned (&off)[NI])
 {
     using C = DecimTile4<NT>;
-    constexpr int LAST = C::SLOTS - 64 * (C::NLOAD - 1);      // lanes of the last instruction
     const long long c0 = ((long long)tile * C::TILE_IN - C::HALO) >> 1;
-    const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk - c.n_odd);
+    constexpr int FIRSTCH = Q0 - (Q0 + 1) / 17;           // first chunk of the range
+    const bool interior = (c0 + FIRSTCH >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk - c.n_odd);
     if (interior) {
         const char *src = reinterpret_cast<const char *>(reinterpret_cast<const f32x4 *>(c.in) + c0);
 #pragma unroll
-        for (int i = 0; i < C::NLOAD; ++i) {
-            unsigned b = c.boff[i];
+        for (int j = 0; j < NI; ++j) {
+            unsigned b = off[j];
             asm volatile("" : "+v"(b));                  // 32-bit offset next to its use (see stage_tile)
-            if (i < C::NLOAD - 1 || LAST >= 64 || c.lane < LAST) glds16(src + b, buf + 64 * i);
+            if (j < NI - 1 || LASTL >= 64 || c.lane < LASTL) glds16(src + b, buf + Q0 + 64 * j);
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < C::NLOAD; ++i) {
-            unsigned b = c.boff[i];
+        for (int j = 0; j < NI; ++j) {
+            unsigned b = off[j];
             asm volatile("" : "+v"(b));
             long long ch = c0 + (b >> 4);
             const f32x4 *src;
@@ -58,7 +71,7 @@ __device__ __forceinline__ void stage_tile2(const DecimTileCtx<NT> &c, int tile,
                 if (ch > c.last_chunk) ch = c.last_chunk;
                 src = reinterpret_cast<const f32x4 *>(c.in) + ch;
             }
-            if (i < C::NLOAD - 1 || LAST >= 64 || c.lane < LAST) stage_edge_chunk(c, ch, src, buf + 64 * i);
+            if (j < NI - 1 || LASTL >= 64 || c.lane < LASTL) stage_edge_chunk(c, ch, src, buf + Q0 + 64 * j);
         }
     }
 }
@@ -112,16 +125,26 @@ __device__ __forceinline__ void st16(const f32x4 &v, f32x4 *dst)
     else __builtin_nontemporal_store(v, dst);
 }
 
+// ABL (profiling): 0 = the real kernel, 1 = staging + stores without the FIR (memory side alone), 2 = FIR on
+// whatever LDS holds (no staging), 5 = the real kernel with s_memtime stamps around its phases (a.stamps:
+// per wave 8 x uint64 {tiles, cycles issuing DMAs, waiting for data, FIR arithmetic, output transposition +
+// stores, cycles from the wave's first to its last instruction, the same span in 100 MHz ticks, 0}).
 template <int NT, int WPG, int OPT, int ABL = 0, bool S32IN = false>
 __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileArgs a)
 {
     using C = DecimTile4<NT>;
     constexpr bool DEFER = (OPT & T2_DEFER) != 0, TAPSEP = (OPT & T2_TAPSEP) != 0, DBUF = (OPT & T2_DBUF) != 0;
-    constexpr bool PLAINST = (OPT & T2_PLAINST) != 0;
+    constexpr bool PLAINST = (OPT & T2_PLAINST) != 0, HCARRY = (OPT & T2_HCARRY) != 0, PRIO = (OPT & T2_PRIO) != 0;
+    static_assert(!(HCARRY && DBUF), "halo carry-over is for the single-buffered loop");
     constexpr int IMG = C::SLOTS;                       // slots per tile image
     constexpr int NB = DBUF ? 2 : 1;
     __shared__ __attribute__((aligned(16))) f32x4 lds[WPG * NB * IMG + (TAPSEP ? NT / 4 : 0)];
 
+    unsigned long long wave_c0 = 0, wave_r0 = 0;
+    if constexpr (ABL == 5) {
+        wave_c0 = __builtin_amdgcn_s_memtime();
+        wave_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int ww = WPG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     f32x4 *img = lds + ww * (NB * IMG);
     f32x4 *tapbuf = TAPSEP ? lds + WPG * NB * IMG : img;
@@ -137,24 +160,52 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
     c.n_out = a.n_out;
     c.last_chunk = (a.n_in - 1) >> 1;
     c.n_odd = (int)(a.n_in & 1);
-#pragma unroll
-    for (int i = 0; i < C::NLOAD; ++i) {
-        const unsigned q = 64u * i + c.lane;
-        unsigned off = q - (((q + 1u) * 3856u) >> 16);                    // (q+1)/17, exact for q < 4096
-        off = off < (unsigned)C::CHUNKS ? off : (unsigned)C::CHUNKS - 1u;
-        c.boff[i] = 16u * off;
-    }
 
-    // Tile schedule: in pass i the G workgroups of a channel cover the G*WPG consecutive tiles
-    // [i*G*WPG, (i+1)*G*WPG); wave ww of workgroup b takes tile (S(b) + i*G)*WPG + ww, where S deals the
-    // workgroups of one XCD (blockIdx % 8 shares an XCD; speed only) a contiguous block of the pass,
-    // so that halo re-reads stay in that XCD's L2.  a.sched == 2: S(b) = b (plain dispatch order).
+    // Image split for staging: the halo (slots [0, HS): the HALO/2 chunks before the tile) and the body.
+    // Without HCARRY both are staged for every tile as one range.
+    constexpr int HS = C::HALO / 2 + C::HALO / 32;       // halo slots (64 chunks + 4 pads at NT = 128)
+    constexpr int BODY = IMG - HS;
+    constexpr int NIB = (BODY + 63) / 64, LASTB = BODY - 64 * (NIB - 1);
+    constexpr int NIA = (HS + 63) / 64, LASTA = HS - 64 * (NIA - 1);
+    constexpr int NIF = C::NLOAD, LASTF = IMG - 64 * (C::NLOAD - 1);
+    unsigned boff[HCARRY ? NIB : NIF];
+#pragma unroll
+    for (int j = 0; j < (HCARRY ? NIB : NIF); ++j)
+        boff[j] = slot_source_offset((HCARRY ? HS : 0) + 64u * j + c.lane, C::CHUNKS);
+
+    auto stage_full = [&](int t, f32x4 *buf) __attribute__((always_inline)) {
+        if constexpr (ABL == 2) return;
+        if constexpr (HCARRY) {
+            unsigned aoff[NIA];
+#pragma unroll
+            for (int j = 0; j < NIA; ++j) aoff[j] = slot_source_offset(64u * j + c.lane, C::CHUNKS);
+            stage_range<NT, 0, NIA, LASTA>(c, t, buf, aoff);
+            stage_range<NT, HS, NIB, LASTB>(c, t, buf, boff);
+        } else {
+            stage_range<NT, 0, NIF, LASTF>(c, t, buf, boff);
+        }
+    };
+
+    // Tile schedule.  Strided (default): in pass i the G workgroups of a channel cover the G*WPG consecutive
+    // tiles [i*G*WPG, (i+1)*G*WPG); wave ww of workgroup b takes tile (S(b) + i*G)*WPG + ww, where S deals the
+    // workgroups of one XCD (blockIdx % 8 shares an XCD; speed only) a contiguous block of the pass, so that
+    // halo re-reads stay in that XCD's L2; a.sched == 2: S(b) = b (plain dispatch order).
+    // HCARRY: wave number b*WPG + ww takes the contiguous run of a.run_base tiles starting at its number
+    // times a.run_base.
     const int G = a.n_waves;                            // workgroups per channel
     const int b = blockIdx.x;
-    const int S = (a.sched == 0 && a.w8) ? (b & 7) * a.w8 + (b >> 3) : b;
-    int tile = S * WPG + ww;
-    const int tile_step = G * WPG;
-    if (tile >= a.n_tiles) return;
+    int tile, tile_end, tile_step;
+    if constexpr (HCARRY) {
+        tile = (b * WPG + ww) * a.run_base;
+        tile_end = tile + a.run_base < a.n_tiles ? tile + a.run_base : a.n_tiles;
+        tile_step = 1;
+    } else {
+        const int S = (a.sched == 0 && a.w8) ? (b & 7) * a.w8 + (b >> 3) : b;
+        tile = S * WPG + ww;
+        tile_end = a.n_tiles;
+        tile_step = G * WPG;
+    }
+    if (tile >= tile_end) return;
 
     if (b * WPG + ww == a.hist_wave) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
 
@@ -180,6 +231,17 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
 
     const int u0c = 16 * c.g - (NT / 4) * c.p + NT / 4;   // this lane's first window chunk (multiple of 16)
     const int woff = u0c + (u0c >> 4);
+    // output transposition buffer inside the (dead) image; with HCARRY it must leave the carried halo alone
+    constexpr int XB = HCARRY ? HS + 12 : 0;
+
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tk = 0;
+    if constexpr (ABL == 5) tk = __builtin_amdgcn_s_memtime();
+#define SXFIR_T2_PHASE(k) \
+    if constexpr (ABL == 5) { \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+        ph[k] += t_now - tk; \
+        tk = t_now; \
+    }
 
     // outputs of the previous tile, transposed for whole-line stores, waiting to be stored (DEFER)
     f32x4 pend0 = {0, 0, 0, 0}, pend1 = {0, 0, 0, 0};
@@ -204,15 +266,20 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
 #pragma unroll
             for (int i = 0; i < 4; ++i) { oi[i] = v0[i] + hp[0].x; oq[i] = v1[i] + hp[31 % (C::TPL / 2)].y; }
         } else {
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
             fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
+        if constexpr (ABL == 5) asm volatile("" ::"v"(oi[0]), "v"(oq[3]));   // the arithmetic ends here
+        SXFIR_T2_PHASE(3)
         if (m0 + C::TILE_OUT <= c.n_out) {
             // through the now dead image: chunk 4g + 2p + {0,1} of the tile's 128 output chunks, read back
             // linearly, so that each global store instruction writes 1 KiB of consecutive addresses
             const int oc = 4 * c.g + 2 * c.p;
-            buf[oc + (oc >> 4)] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
-            buf[oc + 1 + (oc >> 4)] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
-            const f32x4 v0 = buf[c.lane + (c.lane >> 4)], v1 = buf[68 + c.lane + (c.lane >> 4)];
+            f32x4 *xb = buf + XB;
+            xb[oc + (oc >> 4)] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
+            xb[oc + 1 + (oc >> 4)] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
+            const f32x4 v0 = xb[c.lane + (c.lane >> 4)], v1 = xb[68 + c.lane + (c.lane >> 4)];
             f32x4 *dst = reinterpret_cast<f32x4 *>(c.out + 2 * m0);
             if constexpr (DEFER) {
                 pend0 = v0;
@@ -235,18 +302,37 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
+    int ntile = 0;
     if constexpr (!DBUF) {
-        if constexpr (ABL != 2) stage_tile2<NT>(c, tile, img);
+        stage_full(tile, img);
+        SXFIR_T2_PHASE(1)
         SXFIR_WAIT_VMCNT(0);
         if constexpr (TAPSEP) read_taps();
+        SXFIR_T2_PHASE(2)
         while (true) {
             if constexpr (DEFER) flush();
             process(tile, img);
+            ++ntile;
+            SXFIR_T2_PHASE(4)
             tile += tile_step;
-            if (tile >= a.n_tiles) break;
-            if constexpr (ABL != 2) stage_tile2<NT>(c, tile, img);
+            if (tile >= tile_end) break;
+            if constexpr (HCARRY) {
+                // the last HALO samples of this tile are the next tile's halo: chunk CHUNKS - HALO/2 + l -> chunk l
+                constexpr int SRC0 = C::CHUNKS - C::HALO / 2;
+                if (HS <= 64 || c.lane < C::HALO / 2) {
+                    const int sc = SRC0 + c.lane;
+                    const f32x4 v = img[sc + (sc >> 4)];
+                    img[c.lane + (c.lane >> 4)] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (ABL != 2) stage_range<NT, HS, NIB, LASTB>(c, tile, img, boff);
+            } else {
+                stage_full(tile, img);
+            }
+            SXFIR_T2_PHASE(1)
             // LDS-DMA completion is ordered for this wave's ds_reads only by its own vmcnt
             SXFIR_WAIT_VMCNT(0);
+            SXFIR_T2_PHASE(2)
         }
         if constexpr (DEFER) flush();
     } else {
@@ -255,13 +341,14 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         //           have had the whole arithmetic phase of tile k-1 to complete
         //   else:   DMA(k) | stores(k-1) | DMA(k+1)      -> vmcnt(NLOAD) also waits for fresh stores
         static_assert(C::NLOAD == 10, "vmcnt immediate below assumes NLOAD == 10");
-        if constexpr (ABL != 2) stage_tile2<NT>(c, tile, img);
+        stage_full(tile, img);
         int cur = 0;
         bool first = true;
         while (true) {
             const int next = tile + tile_step;
-            if (next < a.n_tiles) {
-                if constexpr (ABL != 2) stage_tile2<NT>(c, next, img + (cur ^ 1) * IMG);
+            if (next < tile_end) {
+                stage_full(next, img + (cur ^ 1) * IMG);
+                SXFIR_T2_PHASE(1)
                 SXFIR_WAIT_VMCNT(10);
             } else {
                 SXFIR_WAIT_VMCNT(0);
@@ -269,14 +356,31 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             if constexpr (TAPSEP) {
                 if (first) { read_taps(); first = false; }
             }
+            SXFIR_T2_PHASE(2)
             if constexpr (DEFER) flush();
             process(tile, img + cur * IMG);
-            if (next >= a.n_tiles) break;
+            ++ntile;
+            SXFIR_T2_PHASE(4)
+            if (next >= tile_end) break;
             tile = next;
             cur ^= 1;
         }
         if constexpr (DEFER) flush();
     }
+    if constexpr (ABL == 5) {
+        SXFIR_T2_PHASE(4)
+        ph[0] = (unsigned long long)ntile;
+        const unsigned long long wave_c1 = __builtin_amdgcn_s_memtime(), wave_r1 = __builtin_amdgcn_s_memrealtime();
+        if (c.lane == 0 && a.stamps) {
+            unsigned long long *rec = a.stamps + 8 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPG + ww);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rec[k] = ph[k];
+            rec[5] = wave_c1 - wave_c0;
+            rec[6] = wave_r1 - wave_r0;
+            rec[7] = 0;
+        }
+    }
+#undef SXFIR_T2_PHASE
 }
 
 }  // namespace sxfir

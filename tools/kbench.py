@@ -71,6 +71,21 @@ for c, p in zip(configs, plans):
             print("config %s phases, mean shader cycles per tile per wave over %d waves: reduce+store %.0f | wait data %.0f | "
                   "arithmetic %.0f | barrier + issue next tile's DMAs %.0f | sum %.0f" % (
                       c, len(r), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), per.sum(1).mean()))
+for c, p in zip(configs, plans):
+    if c[3] == 5:                                    # tile2 kernel with phase stamps
+        cap = 1 << 20
+        buf = (C.c_ulonglong * (8 * cap))(); nrec = C.c_size_t()
+        if p._lib.sxfir_debug_stamps(p._plan, buf, cap, C.byref(nrec)) == 0:
+            r = np.frombuffer(buf, dtype=np.uint64, count=8 * nrec.value).reshape(-1, 8).astype(np.float64)
+            r = r[(r[:, 0] > 0) & (r[:, 6] > 0)]
+            per = r[:, 1:5] / r[:, :1]
+            mhz = 100.0 * r[:, 5] / r[:, 6]
+            print("config %s phases, mean shader cycles per tile per wave over %d waves: issue DMAs %.0f | wait data %.0f | "
+                  "FIR %.0f | transpose + stores %.0f | sum %.0f; whole wave %.0f cycles per tile (prologue etc. %.0f per wave); "
+                  "tiles per wave %.1f; in-kernel clock p10/p50/p90 %.0f/%.0f/%.0f MHz; wave lifetime %.2f us" % (
+                      c, len(r), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), per.sum(1).mean(),
+                      (r[:, 5] / r[:, 0]).mean(), (r[:, 5] - r[:, 1:5].sum(1)).mean(), r[:, 0].mean(),
+                      *np.percentile(mhz, [10, 50, 90]), (r[:, 6] / 100.0).mean()))
 for c in configs:
     a = np.array(res[c])
     gbs = (8.0 + 8.0 / D) * (1.0 if FMT == "CF32" else 0.5) * (1 << log2n) / (a * 1e-3) / 1e9

@@ -1,0 +1,135 @@
+// What does the chip sustain on the FIR's arithmetic alone, and does the operand source matter?
+// 4 waves per SIMD on every CU run loops of 512 packed FMAs per "tile" on random data, as the /4 tile kernel
+// does, in four forms: taps in VGPR pairs (3 VGPR operands per v_pk_fma_f32, the shipped form), taps in
+// SGPR pairs (2 VGPR operands), scalar v_fmac_f32 with an SGPR tap, and the VGPR form with the kernel's 47
+// ds_read_b128 per tile interleaved.  Reports wall time per tile and SIMD, and the in-kernel shader clock
+// (s_memtime / s_memrealtime), after a warm-up long enough for the power management to settle.
+// Profiling aid: hipcc --offload-arch=gfx950 -O3 tools/valu_power_probe.hip -o /tmp/valu_power_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__device__ __forceinline__ void pkv_lo(f2& acc, const f2& h, const f2& x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(h), "v"(x));
+}
+__device__ __forceinline__ void pkv_hi(f2& acc, const f2& h, const f2& x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(h), "v"(x));
+}
+__device__ __forceinline__ void pks_lo(f2& acc, const f2& h, const f2& x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(h), "v"(x));
+}
+__device__ __forceinline__ void pks_hi(f2& acc, const f2& h, const f2& x) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(h), "v"(x));
+}
+
+// MODE 0: VGPR taps, 1: SGPR taps, 2: scalar fmac with SGPR taps, 3: VGPR taps + 47 LDS reads per tile
+template <int MODE>
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, float* __restrict__ out, int tiles,
+                                             unsigned long long* stamps) {
+  __shared__ f4 lds[640 * 4];
+  const int lane = threadIdx.x & 63;
+  f4* img = lds + 640 * (threadIdx.x >> 6);
+  for (int i = lane; i < 640; i += 64) img[i] = (f4){0.001f * i, 0.002f * lane, -0.0015f * i, 0.0007f * lane};
+  __syncthreads();
+  f2 hv[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) hv[k] = (f2){taps[2 * k + (lane >> 5) * 64], taps[2 * k + 1 + (lane >> 5) * 64]};
+  f2 hs[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int a = __builtin_amdgcn_readfirstlane(__float_as_int(taps[2 * k]));
+    const int b = __builtin_amdgcn_readfirstlane(__float_as_int(taps[2 * k + 1]));
+    hs[k] = (f2){__int_as_float(a), __int_as_float(b)};
+  }
+  f2 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (f2){0.01f * lane + i, -0.02f * lane - i};
+  f2 x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = (f2){0.37f + 0.011f * lane + i, -0.59f + 0.013f * lane - i};
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  const f4* win = img + (lane & 31) * 17;
+  for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {          // 8 x 64 = 512 packed FMAs
+      if (MODE == 3) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {        // ~47 reads per tile
+          if (r * 6 + q < 47) {
+            const f4 v = win[(r * 6 + q) % 60];
+            x[q & 3] = x[q & 3] + (f2){v.x, v.w} * 1e-6f;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        if (MODE == 0 || MODE == 3) {
+          pkv_lo(acc[(2 * k) & 7], hv[k], x[k & 3]);
+          pkv_hi(acc[(2 * k + 1) & 7], hv[k], x[(k + 1) & 3]);
+        } else if (MODE == 1) {
+          pks_lo(acc[(2 * k) & 7], hs[k], x[k & 3]);
+          pks_hi(acc[(2 * k + 1) & 7], hs[k], x[(k + 1) & 3]);
+        } else {
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[(2 * k) & 7].x) : "s"(hs[k].x), "v"(x[k & 3].x));
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[(2 * k) & 7].y) : "s"(hs[k].x), "v"(x[k & 3].y));
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[(2 * k + 1) & 7].x) : "s"(hs[k].y), "v"(x[(k + 1) & 3].x));
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[(2 * k + 1) & 7].y) : "s"(hs[k].y), "v"(x[(k + 1) & 3].y));
+        }
+      }
+    }
+    // keep magnitudes bounded without changing the instruction mix much
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = acc[i] * 0.5f;
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s + hv[0].x;
+  if (lane == 0) {
+    stamps[2 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6))] = c1 - c0;
+    stamps[2 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = r1 - r0;
+  }
+}
+
+int main() {
+  const int blocks = 1024;                 // 4 workgroups of 4 waves per CU = 4 waves per SIMD
+  float* taps; float* out; unsigned long long* stamps;
+  CK(hipMalloc(&taps, 512)); CK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CK(hipMalloc(&stamps, (size_t)blocks * 4 * 16));
+  float h[128];
+  for (int i = 0; i < 128; ++i) h[i] = 0.003f * (float)((i * 37) % 29 - 14) + 1e-4f * i;
+  CK(hipMemcpy(taps, h, 512, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int tiles = 256;                   // per wave and launch: one launch = the FIR work of one bench step
+  const char* names[4] = {"v_pk_fma_f32, taps in VGPR pairs (shipped)", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
+                          "v_pk_fma_f32 VGPR taps + 47 ds_read_b128 per tile"};
+  for (int rep = 0; rep < 2; ++rep)
+    for (int mode = 0; mode < 4; ++mode) {
+      auto launch = [&] {
+        switch (mode) {
+          case 0: hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 1: hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 2: hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          default: hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+        }
+      };
+      for (int i = 0; i < 300; ++i) launch();          // ~100 ms: let the clocks settle on this load
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 50; ++i) launch();
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 50;
+      std::vector<unsigned long long> st((size_t)blocks * 8);
+      CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> mhz, cyc;
+      for (int w = 0; w < blocks * 4; ++w) if (st[2 * w + 1]) { mhz.push_back(100.0 * st[2 * w] / st[2 * w + 1]); cyc.push_back((double)st[2 * w] / tiles); }
+      std::sort(mhz.begin(), mhz.end()); std::sort(cyc.begin(), cyc.end());
+      printf("%-52s %.4f ms per launch (256 tiles per wave, 4 waves/SIMD: x0.25 = one bench step's FIR) | %.0f cycles per tile per wave | in-kernel clock %.0f MHz\n",
+             names[mode], ms, cyc[cyc.size() / 2], mhz[mhz.size() / 2]);
+      fflush(stdout);
+    }
+  return 0;
+}
