@@ -38,18 +38,18 @@
 #define SXFIR_TILE2_VARIANTS(X) \
     X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 9) X(1, 11) \
     X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
-    X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51)
+    X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
+    X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65)
 // variants that also exist with phase stamps (ABL 5)
-#define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5)
+#define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69)
 #else
 #define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
 #endif
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
+#include "sxfir_decim_tile2.hip.h"
 #ifdef SXFIR_PROFILING
 #include "sxfir_decim_sgpr.hip.h"
-#include "sxfir_decim_tile2.hip.h"
-#include "sxfir_decim_s2.hip.h"
 #include "../../include/sxfir_prof.h"
 #endif
 #include "sxfir_kernels.hip.h"
@@ -102,9 +102,10 @@ struct sxfir_plan {
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int t2_wpg, t2_opt;    // profiling only: decim4_tile2_kernel variant (waves per workgroup, T2_* bits); wpg 0 = off
-    int s2_opt;            // profiling only: decim4_s2_kernel (scalar taps) with these T2_* bits; -1 = off
     int compute_units;
     float *taps_dev;
+    float *taps_scaled_dev;   // taps * 2^-31 (exact): scalar-tap kernel on S32 wire words
+    bool symmetric;           // taps[k] == taps[ntaps-1-k] bit for bit (every linear-phase design)
     void *hist_dev;        // current history: nchan * hist_len samples
     void *hist_alt;        // the tile kernel writes the next history here, then the two swap
     long long consumed, produced;
@@ -181,6 +182,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->compute_units = prop.multiProcessorCount;
     p->consumed = p->produced = 0;
     p->taps_dev = nullptr;
+    p->taps_scaled_dev = nullptr;
+    p->symmetric = true;
+    for (int k = 0; k < ntaps / 2; ++k)
+        if (memcmp(&taps[k], &taps[ntaps - 1 - k], sizeof(float)) != 0) p->symmetric = false;
     p->hist_dev = nullptr;
     p->hist_alt = nullptr;
     p->itile_capable = false;
@@ -235,7 +240,6 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
     p->t2_wpg = p->t2_opt = 0;
-    p->s2_opt = -1;
     p->occ_multi = 2;
     // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's prologue
     // (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16; the
@@ -289,8 +293,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     }
     if (p->tile_capable) {
         int nb = 0;
-        const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
-                                       : (const void *)sxfir::decim4_tile_kernel<64, false>;
+        // 128 symmetric taps (every linear-phase design): the scalar-tap form of the tile kernel
+        const void *ksb = (ntaps == 128 && p->symmetric)
+                              ? (fmt == SXFIR_S32 ? (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR, 0, true>
+                                                  : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR>)
+                              : (ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
+                                              : (const void *)sxfir::decim4_tile_kernel<64, false>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
 #ifdef SXFIR_PROFILING
         const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
@@ -298,24 +306,14 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kdb, 64, 0) == hipSuccess && nb > 0) p->occ_db = nb;
         if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
             p->tile_dbuf = (strcmp(v, "db") == 0);
+            // "sb", "db", "sg": the first-generation tile kernel (taps in VGPR pairs) also for symmetric taps
+            if (strcmp(v, "sb") == 0 || strcmp(v, "db") == 0 || strncmp(v, "sg", 2) == 0) p->symmetric = false;
             p->sgpr_r = strcmp(v, "sg") == 0 ? 8 : (strcmp(v, "sg4") == 0 ? 4 : 0);
             if (p->sgpr_r && ntaps == 128) {
                 const void *k = p->sgpr_r == 8 ? (const void *)sxfir::decim4_sgpr_kernel<8>
                                                : (const void *)sxfir::decim4_sgpr_kernel<4>;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0)
                     p->occ_sb = nb;
-            }
-            // "s2:<option bits>": decim4_s2_kernel (taps as scalar operands, sxfir_decim_s2.hip.h)
-            if (strncmp(v, "s2:", 3) == 0 && ntaps == 128 && fmt == SXFIR_CF32) {
-                const int opt = atoi(v + 3);
-                const void *k = opt == 0 ? (const void *)sxfir::decim4_s2_kernel<0>
-                                : opt == 1 ? (const void *)sxfir::decim4_s2_kernel<1> : nullptr;
-                if (!k) {
-                    delete p;
-                    return fail(SXFIR_EUNSUPPORTED, "no s2 variant %d", opt);
-                }
-                p->s2_opt = opt;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
             }
             // "t2:<waves per workgroup>:<option bits>": decim4_tile2_kernel (sxfir_decim_tile2.hip.h)
             if (strncmp(v, "t2:", 3) == 0 && ntaps == 128 && fmt == SXFIR_CF32) {
@@ -327,9 +325,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                         SXFIR_TILE2_VARIANTS(SXFIR_X)
 #undef SXFIR_X
                     }
-                    if (!k) {
+                    if (!k || ((opt & sxfir::T2_SCALAR) && !p->symmetric)) {
                         delete p;
-                        return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d", wpg, opt);
+                        return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d for these taps", wpg, opt);
                     }
                     p->t2_wpg = wpg;
                     p->t2_opt = opt;
@@ -347,12 +345,20 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     }
 
     hipError_t e = hipMalloc((void **)&p->taps_dev, sizeof(float) * (size_t)ntaps);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->taps_scaled_dev, sizeof(float) * (size_t)ntaps);
+
+    if (e == hipSuccess) {
+        std::vector<float> scaled(taps, taps + ntaps);
+        for (float &t : scaled) t *= 4.656612873077393e-10f;      // 2^-31: exact
+        e = hipMemcpy(p->taps_scaled_dev, scaled.data(), sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&p->hist_dev, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e == hipSuccess) e = hipMalloc(&p->hist_alt, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e == hipSuccess) e = hipMemcpy(p->taps_dev, taps, sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(p->hist_dev, 0, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e != hipSuccess) {
         if (p->taps_dev) (void)hipFree(p->taps_dev);
+        if (p->taps_scaled_dev) (void)hipFree(p->taps_scaled_dev);
         if (p->hist_dev) (void)hipFree(p->hist_dev);
         if (p->hist_alt) (void)hipFree(p->hist_alt);
         delete p;
@@ -366,6 +372,7 @@ int sxfir_destroy(sxfir_plan *p)
 {
     if (!p) return SXFIR_OK;
     (void)hipFree(p->taps_dev);
+    (void)hipFree(p->taps_scaled_dev);
     (void)hipFree(p->hist_dev);
     (void)hipFree(p->hist_alt);
     delete p;
@@ -575,6 +582,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.out = (float *)out_dev;
         *history_done = true;      // caller swaps hist_dev / hist_alt when it commits the call
         a.taps = p->taps_dev;
+        a.taps_scaled = p->taps_scaled_dev;
         a.n_in = (long long)n_in;
         a.n_out = n_out;
         a.in_stride = (long long)in_stride;
@@ -590,37 +598,6 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.sched = p->sched;
         a.stamps = nullptr;
 #ifdef SXFIR_PROFILING
-        if (p->s2_opt >= 0) {
-            long long G = ((long long)p->compute_units * p->occ_sb * p->oversub) / p->nchan;
-            if (G < 1) G = 1;
-            if (G > n_tiles) G = n_tiles;
-            a.n_waves = (int)G;
-            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
-            a.run_base = a.run_extra = 0;
-            {
-                const int t = (int)((n_tiles - 1) % G);
-                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
-            }
-            dim3 grid((unsigned)G, (unsigned)p->nchan);
-            if (p->ablate == 5) {
-                const size_t need = (size_t)G * p->nchan;
-                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
-                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
-                p->stamps_n = need;
-                a.stamps = (unsigned long long *)p->stamps_dev;
-            }
-            switch (p->s2_opt * 10 + (p->ablate == 1 || p->ablate == 5 ? p->ablate : 0)) {
-            case 0: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<0>), grid, dim3(64), 0, st, a); break;
-            case 1: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<0, 1>), grid, dim3(64), 0, st, a); break;
-            case 5: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<0, 5>), grid, dim3(64), 0, st, a); break;
-            case 10: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<1>), grid, dim3(64), 0, st, a); break;
-            case 11: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<1, 1>), grid, dim3(64), 0, st, a); break;
-            case 15: hipLaunchKernelGGL((sxfir::decim4_s2_kernel<1, 5>), grid, dim3(64), 0, st, a); break;
-            default: return fail(SXFIR_EUNSUPPORTED, "no s2 variant %d ablate %d", p->s2_opt, p->ablate);
-            }
-            HIPCHECK(hipGetLastError());
-            return SXFIR_OK;
-        }
         if (p->t2_wpg) {
             // decim4_tile2_kernel: G workgroups of t2_wpg waves per channel, wave ww of workgroup b takes tiles
             // (S(b) + i*G)*wpg + ww
@@ -643,10 +620,11 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 const int bb = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
                 a.hist_wave = bb * wpg + (int)(last % wpg);
             }
+            const unsigned grid_y = (unsigned)p->nchan;
             a.n_waves = (int)G;
-            dim3 grid((unsigned)G, (unsigned)p->nchan);
+            dim3 grid((unsigned)G, grid_y);
             if (p->ablate == 5) {
-                const size_t need = (size_t)G * p->nchan * wpg;
+                const size_t need = (size_t)G * grid_y * wpg;
                 if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
                 if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
                 p->stamps_n = need;
@@ -721,7 +699,13 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             return SXFIR_OK;
         }
 #endif
-        if (p->fmt == SXFIR_S32)
+        // (with one wave per workgroup both kernels take the same schedule constants)
+        if (p->ntaps == 128 && p->symmetric && p->sched != 1) {
+            if (p->fmt == SXFIR_S32)
+                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR, 0, true>), grid, dim3(64), 0, st, a);
+            else
+                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR>), grid, dim3(64), 0, st, a);
+        } else if (p->fmt == SXFIR_S32)
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
         else if (p->ntaps == 128)
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);

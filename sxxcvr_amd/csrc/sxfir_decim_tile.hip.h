@@ -44,6 +44,7 @@ struct DecimTileArgs {
     float *hist_out;        // where the wave of the last tile leaves the history for the next call
     float *out;             // channel 0, first output of this call
     const float *taps;      // NT floats (device)
+    const float *taps_scaled;   // the same taps times 2^-31 (S32 wire-word plans of the scalar-tap kernel)
     long long n_in;         // new input samples per channel
     long long n_out;        // outputs per channel
     long long in_stride;    // samples between channels

@@ -20,17 +20,28 @@
 //           LDS (one ds_read_b128 + ds_write_b128 per lane and tile) instead of
 //           fetching it again: 11 % fewer bytes through the L2 -> LDS path.
 //   PRIO    the wave raises its priority for the arithmetic of a tile.
+//   SCALAR  symmetric filters (h[k] == h[NT-1-k] bit for bit, which every linear-phase design is): the 64
+//           distinct taps live in SGPR pairs for the whole kernel and are the scalar operand of the packed
+//           FMAs.  Measured (tools/valu_power_probe.hip): this kernel is bound by its FMAs at the clock the
+//           chip's power management allows, and two VGPR operands per FMA instead of three let the same
+//           arithmetic run at a 13 % higher clock.  A scalar operand is wave-uniform, so the work split
+//           changes: every lane computes 4 consecutive outputs over ALL taps (window of 71 chunks read as
+//           two streams 64 samples apart, 78 ds_read_b128; no tap halves on lane pairs, no cross-lane
+//           reduction, 50 VGPRs fewer).  Same LDS image, same
+//           numeric contract (P1 = chain over taps 127..64, P0 over 63..0, y = P0 + P1 inside one lane).
 //
 // New code: the reference decimates inside the SX1255 (SoapySX.cpp:180-208 only
 // programs the divider); this kernel plays that role for SoapySX::readStream
 // (SoapySX.cpp:868-967).
 #pragma once
 
+#include <utility>
+
 #include "sxfir_decim_tile.hip.h"
 
 namespace sxfir {
 
-enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32 };
+enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64 };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -118,6 +129,81 @@ __device__ __forceinline__ void fir_tile_pk(const f32x4 *win, const f32x2 (&hp)[
     }
 }
 
+// the same packed FMAs with the tap pair in SGPRs
+__device__ __forceinline__ void pk_fma_s_lo(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_s_hi(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
+}
+
+// FIR arithmetic of one tile for a symmetric 128-tap filter, taps hs[m] = {h[2m], h[2m+1]}, m < 32, in SGPRs.
+// Lane l computes outputs 4l..4l+3 of the tile: output i meets tap k at window sample u = 4i + 128 - k
+// (window = chunks 8l .. 8l+70 of the image); walking u upwards gives every output its taps in descending
+// order, P1 (127..64) before P0 (63..0).  Tap k >= 64 is h[127-k].  w1 / w2: the lane's window base for
+// steps whose pad count is that of an even / odd lane (the image has one pad slot after every 16 chunks
+// and an odd lane's window starts in the middle of such a row).
+// One step (T of 39) of fir_tile_sym: window chunk T feeds the P1 chains (taps 127..64), chunk T + 32 -- the
+// samples 64 later -- the P0 chains (taps 63..0), so eight independent accumulators are in flight.  A
+// function template per step instead of a loop: every tap index must be a compile-time constant for the
+// taps to stay in SGPRs, and the loop form is too large for the unroller's budget (it then indexes the tap
+// array dynamically, through scratch memory).
+template <bool S32IN, int T>
+__device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], f32x2 (&a1)[4],
+                                             f32x2 (&a0)[4])
+{
+    constexpr int T0 = T + 32;
+    f32x4 v1 = ((T & 15) >= 8 ? w2 : w1)[T + (T >> 4)];
+    f32x4 v0 = ((T0 & 15) >= 8 ? w2 : w1)[T0 + (T0 >> 4)];
+    if constexpr (S32IN) {
+        v1 = (f32x4){(float)__float_as_int(v1.x), (float)__float_as_int(v1.y), (float)__float_as_int(v1.z),
+                     (float)__float_as_int(v1.w)};
+        v0 = (f32x4){(float)__float_as_int(v0.x), (float)__float_as_int(v0.y), (float)__float_as_int(v0.z),
+                     (float)__float_as_int(v0.w)};
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int u = 2 * T + s;                       // P1 meets window sample u, P0 sample u + 64
+        const f32x2 x1 = s ? __builtin_shufflevector(v1, v1, 2, 3) : __builtin_shufflevector(v1, v1, 0, 1);
+        const f32x2 x0 = s ? __builtin_shufflevector(v0, v0, 2, 3) : __builtin_shufflevector(v0, v0, 0, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k0 = 4 * i + 64 - u;             // P0's tap; P1's is k0 + 64 = h[127 - (k0 + 64)] = h[63 - k0]
+            if (k0 >= 0 && k0 < 64) {
+                const int k1 = 63 - k0;
+                if (k1 & 1) pk_fma_s_hi(a1[i], hs[k1 >> 1], x1);
+                else pk_fma_s_lo(a1[i], hs[k1 >> 1], x1);
+                if (k0 & 1) pk_fma_s_hi(a0[i], hs[k0 >> 1], x0);
+                else pk_fma_s_lo(a0[i], hs[k0 >> 1], x0);
+            }
+        }
+    }
+}
+
+template <bool S32IN, int... Ts>
+__device__ __forceinline__ void fir_sym_steps(std::integer_sequence<int, Ts...>, const f32x4 *w1, const f32x4 *w2,
+                                              const f32x2 (&hs)[32], f32x2 (&a1)[4], f32x2 (&a0)[4])
+{
+    (fir_sym_step<S32IN, Ts>(w1, w2, hs, a1, a0), ...);
+}
+
+template <bool S32IN>
+__device__ __forceinline__ void fir_tile_sym(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], float (&oi)[4],
+                                             float (&oq)[4])
+{
+    f32x2 a1[4], a0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a1[i] = (f32x2){0.0f, 0.0f}; a0[i] = (f32x2){0.0f, 0.0f}; }
+    fir_sym_steps<S32IN>(std::make_integer_sequence<int, 39>{}, w1, w2, hs, a1, a0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oi[i] = __fadd_rn(a0[i].x, a1[i].x);
+        oq[i] = __fadd_rn(a0[i].y, a1[i].y);
+    }
+}
+
 template <bool PLAIN>
 __device__ __forceinline__ void st16(const f32x4 &v, f32x4 *dst)
 {
@@ -135,7 +221,9 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
     using C = DecimTile4<NT>;
     constexpr bool DEFER = (OPT & T2_DEFER) != 0, TAPSEP = (OPT & T2_TAPSEP) != 0, DBUF = (OPT & T2_DBUF) != 0;
     constexpr bool PLAINST = (OPT & T2_PLAINST) != 0, HCARRY = (OPT & T2_HCARRY) != 0, PRIO = (OPT & T2_PRIO) != 0;
+    constexpr bool SCALAR = (OPT & T2_SCALAR) != 0;
     static_assert(!(HCARRY && DBUF), "halo carry-over is for the single-buffered loop");
+    static_assert(!SCALAR || (NT == 128 && !TAPSEP), "scalar taps: 128-tap symmetric filters, no tap staging");
     constexpr int IMG = C::SLOTS;                       // slots per tile image
     constexpr int NB = DBUF ? 2 : 1;
     __shared__ __attribute__((aligned(16))) f32x4 lds[WPG * NB * IMG + (TAPSEP ? NT / 4 : 0)];
@@ -209,28 +297,46 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
 
     if (b * WPG + ww == a.hist_wave) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
 
-    // taps of this lane's half as 64-bit pairs for the packed FMAs
-    f32x2 hp[C::TPL / 2];
+    // taps: this lane's half as 64-bit VGPR pairs, fetched once through an LDS broadcast -- or, for a
+    // symmetric filter, the 64 distinct taps as SGPR pairs (scalar loads from the constant address space;
+    // an S32 plan passes taps already scaled by 2^-31 here)
+    f32x2 hp[SCALAR ? 1 : C::TPL / 2];
+    f32x2 hs[32];
     auto read_taps = [&]() __attribute__((always_inline)) {
-        const f32x4 *tp = tapbuf + (C::TPL / 4) * c.p;
+        if constexpr (!SCALAR) {
+            const f32x4 *tp = tapbuf + (C::TPL / 4) * c.p;
 #pragma unroll
-        for (int k = 0; k < C::TPL / 4; ++k) {
-            f32x4 t = tp[k];
-            if constexpr (S32IN) t = t * 4.656612873077393e-10f;
-            hp[2 * k] = (f32x2){t.x, t.y};
-            hp[2 * k + 1] = (f32x2){t.z, t.w};
+            for (int k = 0; k < C::TPL / 4; ++k) {
+                f32x4 t = tp[k];
+                if constexpr (S32IN) t = t * 4.656612873077393e-10f;
+                hp[2 * k] = (f32x2){t.x, t.y};
+                hp[2 * k + 1] = (f32x2){t.z, t.w};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    if (c.lane < NT / 4) glds16(reinterpret_cast<const char *>(a.taps) + 16 * c.lane, tapbuf);
-    if constexpr (!TAPSEP) {
-        // through the (still empty) tile image: the reads must have returned before the first tile's DMA
-        SXFIR_WAIT_VMCNT(0);
-        read_taps();
+    if constexpr (SCALAR) {
+        const __attribute__((address_space(4))) f32x2 *tq =
+            (const __attribute__((address_space(4))) f32x2 *)(S32IN ? a.taps_scaled : a.taps);
+#pragma unroll
+        for (int m = 0; m < 32; ++m) hs[m] = tq[m];
+        hp[0] = (f32x2){0.0f, 0.0f};
+    } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) hs[m] = (f32x2){0.0f, 0.0f};
+        if (c.lane < NT / 4) glds16(reinterpret_cast<const char *>(a.taps) + 16 * c.lane, tapbuf);
+        if constexpr (!TAPSEP) {
+            // through the (still empty) tile image: the reads must have returned before the first tile's DMA
+            SXFIR_WAIT_VMCNT(0);
+            read_taps();
+        }
     }
 
-    const int u0c = 16 * c.g - (NT / 4) * c.p + NT / 4;   // this lane's first window chunk (multiple of 16)
+    // this lane's first window chunk: tap halves on lane pairs -> 16g + (1 - p) * NT/4 (a multiple of 16);
+    // scalar taps -> 8 * lane, with a second base one slot on for an odd lane's differently placed pads
+    const int u0c = SCALAR ? 8 * c.lane : 16 * c.g - (NT / 4) * c.p + NT / 4;
     const int woff = u0c + (u0c >> 4);
+    const int woff2 = woff + (c.lane & 1);
     // output transposition buffer inside the (dead) image; with HCARRY it must leave the carried halo alone
     constexpr int XB = HCARRY ? HS + 12 : 0;
 
@@ -264,10 +370,11 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             // memory side alone: staging + stores, no FIR
             const f32x4 v0 = buf[woff], v1 = buf[woff + 17];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { oi[i] = v0[i] + hp[0].x; oq[i] = v1[i] + hp[31 % (C::TPL / 2)].y; }
+            for (int i = 0; i < 4; ++i) { oi[i] = v0[i] + hp[0].x + hs[3].y; oq[i] = v1[i] + hp[SCALAR ? 0 : 31 % (C::TPL / 2)].y; }
         } else {
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
-            fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
+            if constexpr (SCALAR) fir_tile_sym<S32IN>(buf + woff, buf + woff2, hs, oi, oq);
+            else fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (ABL == 5) asm volatile("" ::"v"(oi[0]), "v"(oq[3]));   // the arithmetic ends here
@@ -275,7 +382,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         if (m0 + C::TILE_OUT <= c.n_out) {
             // through the now dead image: chunk 4g + 2p + {0,1} of the tile's 128 output chunks, read back
             // linearly, so that each global store instruction writes 1 KiB of consecutive addresses
-            const int oc = 4 * c.g + 2 * c.p;
+            const int oc = SCALAR ? 2 * c.lane : 4 * c.g + 2 * c.p;
             f32x4 *xb = buf + XB;
             xb[oc + (oc >> 4)] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
             xb[oc + 1 + (oc >> 4)] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
@@ -292,7 +399,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             }
         } else {
             // ragged last tile of the call: element by element, straight from the registers
-            const long long m = m0 + 8 * c.g + 4 * c.p;
+            const long long m = m0 + (SCALAR ? 4 * c.lane : 8 * c.g + 4 * c.p);
             float *dst = c.out + 2 * m;
 #pragma unroll
             for (int i = 0; i < 4; ++i)

@@ -234,3 +234,79 @@ def test_unaligned_and_odd_stride_inputs(oracle, taps):
     torch.cuda.synchronize()
     for c in range(2):
         assert_bit_exact(to_cpu(y2[c]), oracle.decim_f32(h, 4, xs[c], 2, 4), "odd stride channel %d" % c)
+
+
+@pytest.mark.parametrize("fmt", ["CF32", "S32"])
+def test_asymmetric_taps_take_the_vgpr_tile_kernel(oracle, fmt):
+    """128 symmetric taps run the scalar-tap form of the /4 tile kernel (taps in SGPRs); any other 128-tap
+    filter runs the form with per-lane tap registers.  Same contract, same bits, across calls."""
+    rng = np.random.default_rng(77)
+    h = (rng.standard_normal(128) / 128).astype(np.float32)
+    assert not np.array_equal(h, h[::-1])
+    lens = [1 << 16, 4 * 300, (1 << 14) + 4 * 9]
+    n = sum(lens)
+    if fmt == "S32":
+        words = rng.integers(-2 ** 31, 2 ** 31, size=2 * n, dtype=np.int64).astype(np.int32)
+        x = oracle.convert_rx(words)
+        feed = words.reshape(n, 2)
+    else:
+        x = oracle.synth_iq(SEED, 12, 0, n)
+        feed = x
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, fmt=fmt)
+    plan.set_kernel(KERNEL_TILED)
+    assert plan.contract == (2, 4)
+    outs, pos = [], 0
+    for m in lens:
+        outs.append(to_cpu(plan.process(to_gpu(feed[pos:pos + m]))))
+        pos += m
+    ref = oracle.decim_f32(h, 4, x, 2, 4)
+    assert_bit_exact(np.concatenate(outs), ref, "asymmetric taps " + fmt)
+
+
+@pytest.mark.parametrize("sym", [True, False])
+@pytest.mark.parametrize("n_in", [4097, 1023, 65537, 8191])
+def test_odd_block_lengths_view_ending_at_the_buffer_end(oracle, taps, sym, n_in):
+    """A call over an odd number of samples whose last sample is the last element of its allocation: the tile
+    kernels stage 16-byte chunks, and the chunk holding the last sample must not be fetched beyond it (the
+    view below ends exactly at the end of the tensor's storage).  The stream continues in a second call."""
+    import torch
+    h = taps["n128_d4"] if sym else (np.random.default_rng(3).standard_normal(128) / 128).astype(np.float32)
+    total = n_in + 4096
+    x = oracle.synth_iq(SEED, 14, 0, total)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4)
+    first = torch.empty(n_in, dtype=torch.complex64, device="cuda")        # storage of exactly n_in samples
+    first.copy_(to_gpu(x[:n_in]))
+    y1 = to_cpu(plan.process(first))
+    y2 = to_cpu(plan.process(to_gpu(x[n_in:])))
+    assert_bit_exact(np.concatenate([y1, y2]), oracle.decim_f32(h, 4, x, 2, 4), "odd n_in=%d" % n_in)
+
+
+@pytest.mark.parametrize("mode", ["decim", "interp"])
+def test_history_longer_than_2048_samples(oracle, mode):
+    """Ratio 96 x 32 taps per phase = 3072 taps (the Device's decim=auto at masterClock/1536 = 25 kS/s): the
+    carried-over history is longer than one workgroup's worth of registers; several calls, two channels."""
+    from sxxcvr_amd.resampler import INTERPOLATE
+    if mode == "decim":
+        ratio, ntaps = 96, 3072
+        h = sxxcvr_amd.design_lowpass(ntaps, ratio)
+        lens = [96 * 40, 96 * 3 + 17, 5000, 96 * 100 + 1, 7]
+        xs = [oracle.synth_iq(SEED, 40 + c, 0, sum(lens)) for c in range(2)]
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio, nchan=2)
+        js, cw = plan.contract
+        refs = [oracle.decim_f32(h, ratio, x, js, cw) for x in xs]
+    else:
+        ratio, ntaps = 2, 2 * 2500                      # 2500 rows of history
+        h = (np.random.default_rng(9).standard_normal(ntaps) / ntaps).astype(np.float32)
+        lens = [3000, 17, 4096, 1, 2600]
+        xs = [oracle.synth_iq(SEED, 50 + c, 0, sum(lens)) for c in range(2)]
+        plan = sxxcvr_amd.Resampler(INTERPOLATE, h, ratio, nchan=2)
+        js, _ = plan.contract
+        refs = [oracle.interp_f32(h, ratio, x, js) for x in xs]
+    x2 = np.stack(xs)
+    outs, pos = [], 0
+    for m in lens:
+        outs.append(to_cpu(plan.process(to_gpu(x2[:, pos:pos + m]))))
+        pos += m
+    got = np.concatenate(outs, axis=1)
+    for c in range(2):
+        assert_bit_exact(got[c], refs[c], "%s, long history, channel %d" % (mode, c))

@@ -565,6 +565,25 @@ def test_ratio_follows_sample_rate(oracle):
     assert_bit_exact(buf, oracle.decim_f32(h, 48, oracle.synth_iq(SEED, 0, 0, 700 * 48), 1, 48), "rx at 50 kS/s")
     dev.deactivateStream(rx)
     dev.closeStream(rx)
+    # 25 kS/s = master clock / 1536 -> ratio 96, 3072 taps: the carried-over history (3072 samples) is longer
+    # than one workgroup used to hold; read enough for several RX batches so that the history is carried
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 25000.0)
+    assert dev.readSetting("RX_DECIM") == "96" and dev.readSetting("RX_NTAPS") == str(32 * 96)
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    dev.activateStream(rx)
+    n_out = 3 * 4096 + 500
+    got = np.zeros(n_out, dtype=np.complex64)
+    pos = 0
+    while pos < n_out:
+        m = min(1000, n_out - pos)
+        buf = np.zeros(m, dtype=np.complex64)
+        assert dev.readStream(rx, [buf], m).ret == m
+        got[pos:pos + m] = buf
+        pos += m
+    h = sxxcvr_amd.design_lowpass(32 * 96, 96)
+    assert_bit_exact(got, oracle.decim_f32(h, 96, oracle.synth_iq(SEED, 0, 0, n_out * 96), 1, 96), "rx at 25 kS/s")
+    dev.deactivateStream(rx)
+    dev.closeStream(rx)
     with pytest.raises(RuntimeError, match="Unsupported sample rate"):
         dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 48000.0)
 

@@ -26,9 +26,6 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_ABLATE": "3"},
     {"SXFIR_TILE_VARIANT": "sg"},
     {"SXFIR_TILE_VARIANT": "sg4"},
-    {"SXFIR_TILE_VARIANT": "s2:0"},
-    {"SXFIR_TILE_VARIANT": "s2:1", "SXFIR_OVERSUB": "5"},
-    {"SXFIR_TILE_VARIANT": "s2:0", "SXFIR_OVERSUB": "64", "SXFIR_SCHED": "2"},
 ] + [{"SXFIR_TILE_VARIANT": "t2:%d:%d" % (w, o), "SXFIR_OVERSUB": ov, "SXFIR_SCHED": sc}
      for (w, o, ov, sc) in [(1, 0, "16", "0"), (1, 1, "16", "0"), (1, 2, "64", "2"), (1, 3, "3", "0"), (1, 4, "2", "0"),
                             (1, 5, "16", "0"), (1, 6, "1", "2"), (1, 7, "16", "0"), (1, 9, "16", "0"), (1, 11, "7", "0"),
@@ -36,7 +33,8 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
                             (2, 7, "3", "0"), (4, 2, "64", "2"), (4, 3, "16", "0"), (4, 7, "16", "0"), (8, 2, "64", "2"),
                             (8, 3, "16", "0"), (1, 16, "16", "0"), (1, 17, "16", "0"), (1, 19, "5", "0"), (2, 17, "16", "0"),
                             (2, 19, "64", "0"), (1, 32, "16", "0"), (1, 33, "16", "0"), (2, 35, "16", "0"), (1, 49, "3", "0"),
-                            (2, 51, "16", "0")]])
+                            (2, 51, "16", "0"), (1, 64, "16", "0"), (1, 65, "16", "0"), (1, 68, "4", "0"), (1, 69, "16", "0"),
+                            (1, 80, "16", "0"), (1, 81, "7", "0"), (2, 64, "64", "2"), (2, 65, "16", "0"), (4, 65, "16", "0")]])
 def test_variant_matches_oracle(oracle, monkeypatch, env):
     for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
