@@ -1,122 +1,314 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X resampling hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3rx|3tx|5|5h]
 
-One "step" = one streaming pass of the 128-tap decimate-by-4 CF32 polyphase
-FIR (sxfir_decimate through the C ABI: one kernel launch, history carry-over fused)
-over the rank's resident synthetic IQ block (2^28 complex samples per GPU,
-already in HBM when the timed region starts); consecutive steps are consecutive
-blocks of one continuous stream (filter history carried over on the GPU).  N = 1 runs BASELINE config 2
-(1 channel); N > 1 runs config 4's layout (8 independent channels per GPU,
-8*N in total, no data-path collective), and measures the RCCL gather of the
-decimated output to rank 0 separately (reported under "gather", never part of
-`value`: it is xGMI-link bound).
+One "step" = one streaming pass of the configuration's polyphase FIR (sxfir_decimate / sxfir_interpolate
+through the C ABI: one kernel launch, history carry-over fused) over the rank's resident synthetic IQ block
+(2^28 complex samples on the wideband side per GPU, already in HBM when the timed region starts);
+consecutive steps are consecutive blocks of one continuous stream (filter history carried over on the GPU).
 
-Rank 0 prints ONE JSON line.
+  --config 2   (default, the headline) 128-tap decimate-by-4, CF32          BASELINE config 2
+  --config 3rx 256-tap decimate-by-8, CF32      --config 3tx  256-tap interpolate-by-8, CF32 (config 3)
+  --config 5   1024-tap decimate-by-32, CF32    --config 5h   the same with IQ stored as CF16 (config 5)
+
+N = 1 runs one channel; N > 1 runs BASELINE config 4's layout (8 independent channels per GPU, 8*N in total,
+no data-path collective) and measures the RCCL gather of the decimated output to rank 0 separately (reported
+under "gather", never part of `value`: it is xGMI-link bound).  With N > 1 and no
+torch.distributed environment this script starts the N ranks itself (fresh child processes, before the parent
+touches a GPU); under torchrun it is one of the ranks.  Rank 0 prints ONE JSON line.
+
+After the timed region the outputs of the last step are compared with the CPU oracle (start of the block, a
+window in its middle, its end: the line carries "verified": true, and the script exits non-zero otherwise).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NTAPS, DECIM = 128, 4
 SEED = 0x51255
-BYTES_PER_INPUT_SAMPLE = 8 + 8 / DECIM          # 8 B read + 2 B written
-FLOP_PER_INPUT_SAMPLE = 4 * NTAPS / DECIM
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                            # measured float4 copy ceiling (same guide)
+VALU_PEAK_TFLOPS = 157.3                         # fp32 vector peak at 2.4 GHz (same guide)
+
+# algorithmic bytes and flops per WIDEBAND-side sample (input of a decimator, output
+# of the interpolator); halo and tap re-reads excluded.
+CONFIGS = {
+    "2": dict(mode="decim", ntaps=128, ratio=4, fmt="CF32", bytes=8 + 8 / 4, flop=128, gain=1.0,
+              kernel="sxfir::decim4_tile2_kernel<128, scalar taps>",
+              name="128-tap polyphase decim-by-4, 1 ch CF32 streaming (BASELINE config 2)"),
+    "3rx": dict(mode="decim", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=1.0,
+                kernel="sxfir::decim_multi_kernel<8, 4>",
+                name="256-tap polyphase decim-by-8 RX, 1 ch CF32 streaming (BASELINE config 3, RX half)"),
+    "3tx": dict(mode="interp", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=8.0,
+                kernel="sxfir::interp_tile_kernel<8>",
+                name="256-tap polyphase interp-by-8 TX, 1 ch CF32 streaming (BASELINE config 3, TX half)"),
+    "5": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF32", bytes=8 + 8 / 32, flop=128, gain=1.0,
+              kernel="sxfir::decim_multi_kernel<32, 4>",
+              name="1024-tap decim-by-32, 1 ch CF32 streaming (BASELINE config 5, CF32 leg)"),
+    "5h": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF16", bytes=4 + 4 / 32, flop=128, gain=1.0,
+               kernel="sxfir::decim_multi_kernel<32, 4, CF16>",
+               name="1024-tap decim-by-32, 1 ch CF16 storage, fp32 arithmetic (BASELINE config 5, fp16 IQ leg)"),
+}
 
 
-def cpu_baseline(seconds_target=12.0):
-    """The build's own CPU FIR (the reference has none), order-matched fp32
-    oracle, timed on this host on a bounded sample of the same workload."""
+# ----------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves
+# ----------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """Start n fresh child processes (one per GPU) running this script as torch.distributed ranks and wait for
+    them.  Called before the parent has imported torch or made any GPU call; nothing is exec'ed over a process
+    that has touched a GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SXFIR_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, deadline = 0, None
+    while procs:
+        for p in list(procs):
+            r = p.poll()
+            if r is None:
+                continue
+            procs.remove(p)
+            if r != 0:
+                rc = rc or r
+                if deadline is None:
+                    deadline = time.time() + 30.0       # a rank died: give the others a moment, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()                                 # exactly the processes started above
+            for p in procs:
+                p.wait()
+            procs = []
+            rc = rc or 1
+        time.sleep(0.05)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CPU side: oracle (checker and reported baseline)
+# ----------------------------------------------------------------------------------------------------------
+def load_oracle(fast=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib
     oracle_lib.build()
+    return oracle_lib.Oracle(fast=fast)
+
+
+def cpu_baseline(cfg, seconds_target=10.0):
+    """The build's own CPU FIR (the reference has none), order-matched fp32 oracle, timed on this host on a
+    bounded sample of the same workload; plus the reference-equivalent conversion-only figure
+    (convert_rx_buffer, SoapySX.cpp:103-112: all the per-sample arithmetic the reference's readStream does)."""
+    import numpy as np
     cpuinfo = open("/proc/cpuinfo").read()
     fast = (" avx2" in cpuinfo) and (" fma" in cpuinfo)
-    orc = oracle_lib.Oracle(fast=fast)
-    taps = orc.design_lowpass(NTAPS, DECIM)
+    orc = load_oracle(fast=fast)
+    ntaps, ratio = cfg["ntaps"], cfg["ratio"]
+    taps = orc.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
     threads = orc.max_threads()
     model = "unknown"
     for line in cpuinfo.splitlines():
         if line.startswith("model name"):
             model = line.split(":", 1)[1].strip()
             break
-    n_probe = 1 << 21
+    if cfg["mode"] == "decim":
+        js, cw = 2, 4
+
+        def run(x, nthr):
+            orc.decim_f32(taps, ratio, x, js, cw, threads=nthr)
+        n_probe, n = 1 << 21, 1 << 26
+        wide = lambda m: m                                      # wideband samples per call
+    else:
+        def run(x, nthr):
+            orc.interp_f32_mt(taps, ratio, x, 2, threads=nthr)
+        n_probe, n = (1 << 21) // ratio, (1 << 26) // ratio
+        wide = lambda m: m * ratio
     x = orc.synth_iq(SEED, 0, 0, n_probe)
     t0 = time.perf_counter()
-    orc.decim_f32(taps, DECIM, x, 2, 4, threads=1)
-    t1 = time.perf_counter() - t0
-    one_thread = n_probe / t1 / 1e6
-    # bounded sample: the first 2^26 input samples of the workload's stream, filtered repeatedly
-    # until about `seconds_target` of wall time has been spent
-    n = 1 << 26
-    x = orc.synth_iq(SEED, 0, 0, n)
-    orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)          # warm-up (page faults, thread pool)
+    run(x, 1)
+    one_thread = wide(n_probe) / (time.perf_counter() - t0) / 1e6
+    # bounded sample: the first 2^26 wideband samples of the workload's stream, filtered repeatedly
+    x = orc.synth_iq_mt(SEED, 0, 0, n, threads)
+    run(x, threads)                                             # warm-up (page faults, thread pool)
     reps, dt = 0, 0.0
     t0 = time.perf_counter()
     while dt < seconds_target and reps < 1000:
-        orc.decim_f32(taps, DECIM, x, 2, 4, threads=threads)
+        run(x, threads)
         reps += 1
         dt = time.perf_counter() - t0
+    # conversion only: S32_LE wire words -> CF32, the reference's actual per-sample work
+    m = 1 << 26
+    words = np.frombuffer(np.random.default_rng(1).bytes(8 * m), dtype=np.int32)
+    out = np.empty(2 * m, dtype=np.float32)
+    orc.convert_rx_into(words, out, 1)
+    t0 = time.perf_counter()
+    orc.convert_rx_into(words, out, 1)
+    conv1 = m / (time.perf_counter() - t0) / 1e6
+    orc.convert_rx_into(words, out, threads)
+    creps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        orc.convert_rx_into(words, out, threads)
+        creps += 1
+    convn = m * creps / (time.perf_counter() - t0) / 1e6
     return {
-        "value": round(n * reps / dt / 1e6, 2),
-        "unit": "MS/s (complex input samples)",
+        "value": round(wide(n) * reps / dt / 1e6, 2),
+        "unit": "MS/s (complex wideband-side samples)",
         "cores": threads,
         "kind": "port",
-        "sample": "first %d input samples of the same synthetic channel-0 stream filtered %d times, %d threads "
+        "sample": "first %d wideband samples of the same synthetic channel-0 stream filtered %d times, %d threads "
                   "(OpenMP over output blocks), %s build; the reference has no software FIR, this is the "
-                  "build's own CPU FIR" % (n, reps, threads, "AVX2+FMA" if fast else "portable"),
+                  "build's own CPU FIR" % (wide(n), reps, threads, "AVX2+FMA" if fast else "portable"),
         "one_thread_value": round(one_thread, 2),
         "cpu_model": model,
         "seconds": round(dt, 2),
+        "conversion_only": {
+            "what": "convert_rx_buffer (SoapySX.cpp:103-112), the reference's own per-sample readStream arithmetic: "
+                    "S32_LE wire words -> CF32, oracle sxo_convert_rx",
+            "one_thread_MS/s": round(conv1, 1),
+            "all_threads_MS/s": round(convn, 1),
+            "threads": threads,
+            "sample": "%d random wire-word samples converted repeatedly" % m,
+        },
     }
 
 
-def measure_gather(world, y, total_channels, host_collectives, cdev, per_gpu, elapsed, steps):
+def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc):
+    """Compare three windows of every local channel's output block (its start, one around the middle -- tile
+    seams of every kernel included --, its end) with the order-matched oracle.  history_from_block: the filter
+    entered this block with the block's own tail as history (steady-state streaming over the same buffer), else
+    with zero history (after a reset).  Returns (ok, outputs compared)."""
+    import numpy as np
+    ratio, ntaps, decim = cfg["ratio"], cfg["ntaps"], cfg["mode"] == "decim"
+    h = orc.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
+    js, cw = plan.contract
+    n_out = n_in // ratio if decim else n_in * ratio
+    win = min(2048, n_out)
+    starts = sorted(set([0, max(0, (n_out // 2 // 256) * 256 - win // 2), n_out - win]))
+    compared, ok = 0, True
+    yc = y if y.dim() == 2 else y.unsqueeze(0)
+    for c in range(yc.shape[0]):
+        ch = first_channel + c
+        for o0 in starts:
+            got = yc[c, o0:o0 + win].cpu().numpy()
+            if decim:
+                pad = ((ntaps + ratio - 1) // ratio) * ratio            # >= ntaps - 1, a multiple of the ratio
+                s0 = o0 * ratio - pad                                   # first input sample of the window
+                cnt = pad + win * ratio
+            else:
+                pad = ntaps // ratio                                    # input rows of history
+                s0 = o0 // ratio - pad
+                cnt = pad + (win + ratio - 1) // ratio + 1
+            cnt = min(cnt, n_in - s0)
+            if s0 < 0 and history_from_block:
+                # steady-state streaming over the same buffer: the samples before the block are its own tail
+                xw = np.concatenate([orc.synth_iq(SEED, ch, n_in + s0, -s0), orc.synth_iq(SEED, ch, 0, cnt + s0)])
+            else:
+                xw = orc.synth_iq(SEED, ch, s0, cnt)                    # zeros before the start of the stream
+            if cfg["fmt"] == "CF16":
+                xw = orc.f16_to_f32(orc.f32_to_f16(xw.view(np.float32))).view(np.complex64)
+            if decim:
+                ref = orc.decim_f32(h, ratio, xw, js, cw, m0=pad // ratio, n_out=win)
+            else:
+                ref = orc.interp_f32(h, ratio, xw, js, n0=pad * ratio + (o0 % ratio), n_out=win)
+            if cfg["fmt"] == "CF16":
+                same = np.array_equal(got.view(np.uint16), orc.f32_to_f16(ref.view(np.float32)).ravel())
+            else:
+                same = np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+            ok = ok and bool(same)
+            compared += win
+    return ok, compared
+
+
+def through_device():
+    """API-parity figures through the SoapySDR-style Device (readStream / writeStream incl. PCIe, staging and
+    launch overheads), decimate-by-4 / interpolate-by-4 at 600 kS/s; never part of `value`."""
+    import numpy as np
+    import sxxcvr_amd.soapy as SoapySDR
+    res = {"note": "through SoapySX-style readStream/writeStream (host buffers, PCIe, pageable caller memory); "
+                   "API-parity figures, never part of value"}
+    for blk, key in ((256, "256_sample_calls"), (65536, "65536_sample_calls")):
+        dev = SoapySDR.Device({"driver": "sx", "clock": "virtual"})
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 600000.0)
+        rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CF32", [0], {"period": str(blk)})
+        tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(blk)})
+        dev.activateStream(rx)
+        dev.activateStream(tx)
+        buf = np.zeros(blk, dtype=np.complex64)
+        n = max(8, min(2000, (1 << 24) // blk))
+        dev.readStream(rx, [buf], blk)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = dev.readStream(rx, [buf], blk)
+            if r.ret != blk:
+                raise RuntimeError("readStream returned %d" % r.ret)
+        dt_rx = (time.perf_counter() - t0) / n
+        dev.writeStream(tx, [buf], blk)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = dev.writeStream(tx, [buf], blk)
+            if r.ret != blk:
+                raise RuntimeError("writeStream returned %d" % r.ret)
+        dt_tx = (time.perf_counter() - t0) / n
+        res[key] = {"readStream_us_per_call": round(dt_rx * 1e6, 2), "readStream_out_MS/s": round(blk / dt_rx / 1e6, 1),
+                    "readStream_wideband_in_MS/s": round(4 * blk / dt_rx / 1e6, 1),
+                    "writeStream_us_per_call": round(dt_tx * 1e6, 2), "writeStream_in_MS/s": round(blk / dt_tx / 1e6, 1)}
+        dev.deactivateStream(rx)
+        dev.deactivateStream(tx)
+        dev.closeStream(rx)
+        dev.closeStream(tx)
+    return res
+
+
+def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps):
     """Exchange step of BASELINE config 4: RCCL gather of every rank's decimated output to rank 0 over xGMI,
-    timed after (and outside) the timed region."""
+    timed after (and outside) the timed region; rank 0 checks that the gathered tensor holds every rank's
+    channels in global channel order."""
     import torch
     import torch.distributed as dist
     import sxxcvr_amd.dist as sxdist
-    gather = None
-    if world > 1:
-        # exchange step of config 4: decimated output of every rank to rank 0 over xGMI
-        yg = y.cpu() if host_collectives else y
-        for _ in range(2):
-            sxdist.gather_channels(yg, total_channels, dst=0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            sxdist.gather_channels(yg, total_channels, dst=0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g = (time.perf_counter() - g0) / reps
-        t = torch.tensor([g], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        g = float(t.item())
-        peer_bytes = y.numel() * 8
-        gather = {
-            "ms": round(g * 1e3, 3),
-            "bytes_per_peer": peer_bytes,
-            "GB/s_into_root": round(peer_bytes * (world - 1) / g / 1e9, 2),
-            "GB/s_per_link": round(peer_bytes / g / 1e9, 2),
-            "value_with_gather": round(world * per_gpu * 1.0 / (elapsed / steps + g) / 1e6, 1),
-            "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part "
-                    "of value",
-        }
-
-    return gather
+    yg = y.cpu() if host_collectives else y
+    full = None
+    for _ in range(2):
+        full = sxdist.gather_channels(yg, total_channels, dst=0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    g0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        full = sxdist.gather_channels(yg, total_channels, dst=0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g = (time.perf_counter() - g0) / reps
+    t = torch.tensor([g], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    g = float(t.item())
+    peer_bytes = y.numel() * 8
+    out = {
+        "ms": round(g * 1e3, 3),
+        "bytes_per_peer": peer_bytes,
+        "GB/s_into_root": round(peer_bytes * (world - 1) / g / 1e9, 2),
+        "GB/s_per_link": round(peer_bytes / g / 1e9, 2),
+        "value_with_gather": round(world * wide_per_gpu * 1.0 / (elapsed / steps + g) / 1e6, 1),
+        "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part of value",
+    }
+    if dist.get_rank() == 0:
+        local = y.shape[0]
+        out["root_holds_own_channels"] = bool(torch.equal(full[:local].to(y.device), y))
+        out["gathered_shape"] = list(full.shape)
+    return out
 
 
 def main():
@@ -126,17 +318,26 @@ def main():
     # (kernel time swings 0.50 -> 0.77 -> 0.60 ms before it does), so warm up past that
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--log2-samples", type=int, default=28, help="input samples per GPU (log2)")
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--log2-samples", type=int, default=28, help="wideband-side samples per GPU (log2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle", type=int, default=150, help="untimed launches before the warm-up steps (clock settling)")
+    ap.add_argument("--no-through-device", action="store_true")
+    ap.add_argument("--settle", type=int, default=150,
+                    help="untimed launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher.  Nothing below this line has run in this process, so no GPU call has
+        # been made here; the ranks are fresh processes.
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import sxxcvr_amd
     from sxxcvr_amd import dist as sxdist
-    from sxxcvr_amd.resampler import DECIMATE
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE, ClockProbe
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
@@ -146,32 +347,45 @@ def main():
     backend = os.environ.get("SXFIR_DIST_BACKEND")
     host_collectives = backend == "gloo"
     rank, local_rank, world = sxdist.env_rank()
+    if not host_collectives and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d needs GPU %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     gpu_index = local_rank % torch.cuda.device_count() if host_collectives else local_rank
     torch.cuda.set_device(gpu_index)
     rank, local_rank, world = sxdist.init_process_group(backend=backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and args.config != "2":
+        raise SystemExit("the multi-GPU layout (BASELINE config 4) runs --config 2's filter")
     dev = torch.device("cuda", gpu_index)
     cdev = torch.device("cpu") if host_collectives else dev
+    backend_name = dist.get_backend() if world > 1 else None
 
-    per_gpu = 1 << args.log2_samples
+    ratio, ntaps, decim = cfg["ratio"], cfg["ntaps"], cfg["mode"] == "decim"
+    wide_per_gpu = 1 << args.log2_samples
     if world == 1:
         nchan_local, total_channels = 1, 1
-        workload = "1xMI355X: 128-tap polyphase decim-by-4, 1 ch CF32 streaming (BASELINE config 2)"
+        workload = "1xMI355X: " + cfg["name"]
     else:
         nchan_local, total_channels = 8, 8 * world
         workload = ("%dxMI355X: %d independent CF32 channels sharded 8/GPU, 128-tap decim-by-4 "
                     "(BASELINE config 4 layout)" % (world, total_channels))
-    n_in = per_gpu // nchan_local
+    wide = wide_per_gpu // nchan_local                       # wideband samples per channel
+    n_in = wide if decim else wide // ratio
+    n_out = wide // ratio if decim else wide
     lo, hi = sxdist.shard_channels(total_channels, world, rank)
     assert hi - lo == nchan_local
 
-    taps = sxxcvr_amd.design_lowpass(NTAPS, DECIM)
-    plan = sxxcvr_amd.Resampler(DECIMATE, taps, DECIM, nchan=nchan_local, device=gpu_index)
-    x = torch.empty((nchan_local, n_in), dtype=torch.complex64, device=dev)
-    sxxcvr_amd.synth_fill(x, SEED, first_channel=lo, start=0)
-    y = torch.empty((nchan_local, n_in // DECIM), dtype=torch.complex64, device=dev)
+    taps = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
+    plan = sxxcvr_amd.Resampler(DECIMATE if decim else INTERPOLATE, taps, ratio, nchan=nchan_local, fmt=cfg["fmt"],
+                                device=gpu_index)
+    dt = torch.complex64 if cfg["fmt"] == "CF32" else torch.int32
+    x = torch.empty((nchan_local, n_in), dtype=dt, device=dev)
+    sxxcvr_amd.synth_fill(x, SEED, first_channel=lo, start=0, fmt=cfg["fmt"])
+    y = torch.empty((nchan_local, n_out), dtype=dt, device=dev)
     torch.cuda.synchronize()
+    xs = x.stride(0) if nchan_local > 1 else n_in
+    ys = y.stride(0) if nchan_local > 1 else n_out
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         # one streaming pass: the block is the next 2^28 samples of a continuous stream (the filter
@@ -182,9 +396,7 @@ def main():
     # time swings 0.49 -> 0.84 -> 0.60 ms over the first ~20 launches); same launches
     # as a step, then the stream restarts at position 0.
     if args.settle > 0:
-        plan.time_decimate_ptr(x.data_ptr(), n_in, x.stride(0) if nchan_local > 1 else n_in, y.data_ptr(),
-                               y.stride(0) if nchan_local > 1 else n_in // DECIM, args.settle,
-                               torch.cuda.current_stream(dev).cuda_stream)
+        plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, args.settle, stream)
         plan.reset()
         torch.cuda.synchronize()
 
@@ -207,70 +419,115 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel alone, HIP events on the launch stream (not torch's event API)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # the last step's output against the oracle (steady-state streaming: the block entered with its own tail
+    # as history, unless it was the very first block of the stream)
+    orc = load_oracle()
+    first_block = (args.warmup + args.steps) <= 1
+    ok1, cmp1 = verify(cfg, plan, x, y, n_in, lo, not first_block, orc)
+
+    # dominant kernel alone, HIP events on the launch stream (not torch's event API) ...
     plan.reset()
     torch.cuda.synchronize()
-    kernel_ms = plan.time_decimate_ptr(x.data_ptr(), n_in, x.stride(0) if nchan_local > 1 else n_in, y.data_ptr(),
-                                       y.stride(0) if nchan_local > 1 else n_in // DECIM, min(max(args.steps, 20), 200), stream)
-    achieved = BYTES_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e9
+    iters = min(max(args.steps, 40), 200)
+    kernel_ms = plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, iters, stream)
+    # ... and once more with the in-kernel shader clock read beside it (a few probe waves on a second stream;
+    # their presence costs the kernel a few per cent, so this pass only supplies the clock)
+    probe = ClockProbe(gpu_index, 8000)
+    kernel_ms_probed = plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, iters, stream)
+    shader_mhz = probe.read()
+    ok2, cmp2 = verify(cfg, plan, x, y, n_in, lo, False, orc)          # these passes started from zero history
+    verified = ok1 and ok2
+    if world > 1:
+        t = torch.tensor([1.0 if verified else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        verified = bool(t.item() > 0.5)
+    achieved = cfg["bytes"] * wide_per_gpu / (kernel_ms * 1e-3) / 1e9
+    tflops = cfg["flop"] * wide_per_gpu / (kernel_ms * 1e-3) / 1e12
 
     def emit(gather):
         """Rank 0 prints the one JSON line."""
-        if rank == 0:
-            ms_per_step = elapsed / args.steps * 1e3
-            value = world * per_gpu * args.steps / elapsed / 1e6
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tp) and world == 1 and args.log2_samples == 28:     # measured for exactly this launch
-                try:
-                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            line = {
-                "metric": "complex MS/s, 128-tap decim-by-4 CF32 (input rate, whole job)",
-                "value": round(value, 1),
-                "unit": "MS/s",
-                "n_gpus": world,
-                "steps": args.steps,
-                "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 4),
-                "higher_is_better": True,
-                "scaling": "weak",
-                "vs_baseline": None,
-                "dtype": "f32",
-                "data": "synthetic",
-                "config": {
-                    "workload": workload,
-                    "ntaps": NTAPS, "decim": DECIM, "format": "CF32",
-                    "channels_per_gpu": nchan_local, "input_samples_per_gpu": per_gpu,
-                    "untimed_settle_launches": args.settle,
-                    "output_MS/s": round(value / DECIM, 1),
-                    "per_gpu_MS/s": round(value / world, 1),
-                },
-                "roofline": {
-                    "bound": "hbm",
-                    "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic,
-                    "kernel": "sxfir::decim4_tile_kernel<128>",
-                    "kernel_ms": round(kernel_ms, 4),
-                    "algorithmic_bytes_per_launch": int(BYTES_PER_INPUT_SAMPLE * per_gpu),
-                    "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                    "fp32_TFLOPs": round(FLOP_PER_INPUT_SAMPLE * per_gpu / (kernel_ms * 1e-3) / 1e12, 2),
-                },
-            }
-            if gather is not None:
-                line["gather"] = gather
-            if world == 1 and not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline()
-            print(json.dumps(line), flush=True)
+        if rank != 0:
+            return
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * wide_per_gpu * args.steps / elapsed / 1e6
+        traffic, traffic_source = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp) and world == 1 and args.log2_samples == 28:
+            try:
+                tj = json.load(open(tp))
+                ent = tj.get("configs", {}).get(args.config)
+                if ent:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_source = "not measured in this run: rocprofv3 PMC passes FETCH_SIZE/WRITE_SIZE of the same " \
+                                     "launch, " + ent.get("source", "profiles/")
+            except Exception:
+                traffic = None
+        side = "input" if decim else "output"
+        line = {
+            "metric": "complex MS/s, %d-tap %s-by-%d %s (%s rate, whole job)" % (
+                ntaps, "decim" if decim else "interp", ratio, cfg["fmt"], side),
+            "value": round(value, 1),
+            "unit": "MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "verified": verified,
+            "config": {
+                "workload": workload,
+                "bench_config": args.config,
+                "ntaps": ntaps, ("decim" if decim else "interp"): ratio, "format": cfg["fmt"],
+                "channels_per_gpu": nchan_local, "wideband_samples_per_gpu": wide_per_gpu,
+                "untimed_settle_launches": args.settle,
+                "narrowband_MS/s": round(value / ratio, 1),
+                "per_gpu_MS/s": round(value / world, 1),
+                "verified_outputs": cmp1 + cmp2,
+                "rccl_ranks": world if world > 1 else None,
+                "backend": backend_name,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                "kernel": cfg["kernel"],
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": int(cfg["bytes"] * wide_per_gpu),
+                "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                "fp32_TFLOPs": round(tflops, 2),
+                "shader_mhz": round(shader_mhz, 0),
+                "kernel_ms_beside_clock_probe": round(kernel_ms_probed, 4),
+                "valu": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs_at_2400MHz": VALU_PEAK_TFLOPS,
+                         "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+                         "frac_at_measured_clock": round(tflops / (VALU_PEAK_TFLOPS * shader_mhz / 2400.0), 4)},
+            },
+        }
+        if args.config == "5h":
+            line["roofline"]["note"] = ("CF16 storage halves the bytes but not the 128 flop per sample: this leg is "
+                                        "bound by fp32 VALU throughput at the clock the power management allows; "
+                                        "see roofline.valu")
+        if gather is not None:
+            line["gather"] = gather
+        if world == 1 and not args.no_through_device:
+            try:
+                line["through_device"] = through_device()
+            except Exception as e:                               # reported beside the value, never able to take it down
+                line["through_device"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
 
     # The exchange step (config 4's gather over xGMI) is reported beside `value`, never inside it, and must
     # not be able to take the line down with it: errors are recorded, and a watchdog prints the line without
-    # the gather figures if the collective does not come back.
+    # the gather figures -- and ends the rank with a failure status -- if the collective does not come back.
     gather = None
     if world > 1:
         import threading
@@ -279,11 +536,11 @@ def main():
         def watchdog():
             if not finished.wait(240.0):
                 emit({"error": "gather did not complete within 240 s"})
-                os._exit(0)
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            gather = measure_gather(world, y, total_channels, host_collectives, cdev, per_gpu, elapsed, args.steps)
+            gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps)
         except Exception as e:
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
         finished.set()
@@ -292,6 +549,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not verified:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

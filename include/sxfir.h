@@ -169,6 +169,16 @@ int sxfir_event_sync(void *event);
  * returns the mean milliseconds per pass of the resampling kernel. */
 int sxfir_time_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
                         void *out_dev, size_t out_stride, int iters, void *stream, float *ms_per_pass);
+int sxfir_time_interpolate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
+                           void *out_dev, size_t out_stride, int iters, void *stream, float *ms_per_pass);
+
+/* Shader clock the chip's power management holds while other work runs: a few single-wave workgroups on a
+ * stream of their own compare the shader-cycle counter with the 100 MHz real-time counter for duration_us
+ * (asynchronous); sxfir_clock_probe_read waits for them, returns the median in MHz and frees the probe.
+ * Start it, run the work to be measured for at least that long, then read. */
+typedef struct sxfir_clock_probe sxfir_clock_probe;
+int sxfir_clock_probe_start(sxfir_clock_probe **probe, int device, int duration_us);
+int sxfir_clock_probe_read(sxfir_clock_probe *probe, double *mhz);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,9 @@ def load_sxfir(profiling=False):
         "sxfir_decimate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
         "sxfir_interpolate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
         "sxfir_time_decimate": (ci, [vp, vp, sz, sz, vp, sz, ci, vp, P(C.c_float)]),
+        "sxfir_time_interpolate": (ci, [vp, vp, sz, sz, vp, sz, ci, vp, P(C.c_float)]),
+        "sxfir_clock_probe_start": (ci, [P(vp), ci, ci]),
+        "sxfir_clock_probe_read": (ci, [vp, P(dbl)]),
         "sxfir_synth_fill": (ci, [vp, sz, sz, ci, u64, C.c_uint32, i64, ci, vp]),
         "sxfir_convert_rx_s32": (ci, [vp, vp, sz, vp]),
         "sxfir_convert_tx_s32": (ci, [vp, vp, sz, C.c_float, vp]),

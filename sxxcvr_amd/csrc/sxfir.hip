@@ -39,9 +39,10 @@
     X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 9) X(1, 11) \
     X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
-    X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65)
+    X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
+    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224)
 // variants that also exist with phase stamps (ABL 5)
-#define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69)
+#define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
 #define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
 #endif
@@ -780,16 +781,11 @@ int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_str
     return SXFIR_OK;
 }
 
-int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
-                      size_t out_stride, size_t *n_out_p, void *stream)
+// Launch only the interpolation kernel (no history swap, no position change).
+static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                         size_t out_stride, long long n_out, hipStream_t st, bool *history_done)
 {
-    if (n_out_p) *n_out_p = 0;
-    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
-    const long long n_out = outputs_for(p, (long long)n_in);
-    int rc = check_io(p, SXFIR_INTERPOLATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
-    if (rc) return rc;
-    if (n_in == 0) return SXFIR_OK;
-    HIPCHECK(hipSetDevice(p->device));
+    *history_done = false;
     const bool tiled = p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && ((uintptr_t)out_dev % 16 == 0) &&
                        (p->nchan == 1 || out_stride % 2 == 0);
     if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
@@ -817,24 +813,21 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
-            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, S(stream), t); break;
-            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, S(stream), t); break;
-            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true>), grid, dim3(64), 0, S(stream), t); break;
-            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true>), grid, dim3(64), 0, S(stream), t); break;
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, st, t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, st, t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true>), grid, dim3(64), 0, st, t); break;
             }
         } else {
             switch (p->ratio) {
-            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, S(stream), t); break;
-            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, S(stream), t); break;
-            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, S(stream), t); break;
-            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, S(stream), t); break;
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, st, t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, st, t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, st, t); break;
             }
         }
         HIPCHECK(hipGetLastError());
-        std::swap(p->hist_dev, p->hist_alt);
-        p->consumed += (long long)n_in;
-        p->produced += n_out;
-        if (n_out_p) *n_out_p = (size_t)n_out;
+        *history_done = true;
         return SXFIR_OK;
     }
     sxfir::GenericArgs a;
@@ -856,14 +849,32 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
     a.thr2 = p->thr2;
     if (p->fmt == SXFIR_CF32)
-        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, S(stream), a);
+        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, st, a);
     else if (p->fmt == SXFIR_CF16)
-        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, S(stream), a);
+        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((sxfir::interp_generic_kernel<sxfir::CF32, sxfir::S32>), grid, dim3(256), 0, S(stream), a);
+        hipLaunchKernelGGL((sxfir::interp_generic_kernel<sxfir::CF32, sxfir::S32>), grid, dim3(256), 0, st, a);
     HIPCHECK(hipGetLastError());
-    rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+    return SXFIR_OK;
+}
+
+int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                      size_t out_stride, size_t *n_out_p, void *stream)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    const long long n_out = outputs_for(p, (long long)n_in);
+    int rc = check_io(p, SXFIR_INTERPOLATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
     if (rc) return rc;
+    if (n_in == 0) return SXFIR_OK;
+    HIPCHECK(hipSetDevice(p->device));
+    bool history_done = false;
+    rc = launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
+    if (rc) return rc;
+    if (!history_done) {
+        rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+        if (rc) return rc;
+    }
     std::swap(p->hist_dev, p->hist_alt);
     p->consumed += (long long)n_in;
     p->produced += n_out;
@@ -871,12 +882,14 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     return SXFIR_OK;
 }
 
-int sxfir_time_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
-                        size_t out_stride, int iters, void *stream, float *ms_per_pass)
+// Timed launches (bench.py): `iters` back-to-back passes of the resampling kernel over the same buffers and
+// from the same filter state, bracketed by HIP events on the launch stream.
+static int time_passes(sxfir_plan *p, int mode, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                       size_t out_stride, int iters, void *stream, float *ms_per_pass)
 {
     if (!p || !ms_per_pass || iters < 1) return fail(SXFIR_EINVAL, "bad argument");
     const long long n_out = outputs_for(p, (long long)n_in);
-    int rc = check_io(p, SXFIR_DECIMATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+    int rc = check_io(p, mode, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
     if (rc) return rc;
     if (n_out < 1) return fail(SXFIR_EINVAL, "nothing to do");
     HIPCHECK(hipSetDevice(p->device));
@@ -886,7 +899,9 @@ int sxfir_time_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     HIPCHECK(hipEventRecord(e0, S(stream)));
     for (int i = 0; i < iters; ++i) {
         bool history_done = false;   // history buffers are not swapped: every pass filters from the same state
-        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
+        rc = mode == SXFIR_DECIMATE
+                 ? launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done)
+                 : launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
         if (rc) break;
     }
     hipError_t e = hipEventRecord(e1, S(stream));
@@ -898,6 +913,91 @@ int sxfir_time_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     if (rc) return rc;
     if (e != hipSuccess) return fail(SXFIR_EHIP, "event timing failed: %s", hipGetErrorString(e));
     *ms_per_pass = ms / (float)iters;
+    return SXFIR_OK;
+}
+
+int sxfir_time_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                        size_t out_stride, int iters, void *stream, float *ms_per_pass)
+{
+    return time_passes(p, SXFIR_DECIMATE, in_dev, n_in, in_stride, out_dev, out_stride, iters, stream, ms_per_pass);
+}
+
+int sxfir_time_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                           size_t out_stride, int iters, void *stream, float *ms_per_pass)
+{
+    return time_passes(p, SXFIR_INTERPOLATE, in_dev, n_in, in_stride, out_dev, out_stride, iters, stream, ms_per_pass);
+}
+
+// In-kernel shader clock while other work runs: a few single-wave workgroups on a stream of their own spin on
+// s_memtime (shader cycles) against s_memrealtime (100 MHz) for `duration_us`; sxfir_clock_probe_read waits for
+// them and returns the median ratio.  They use one wave slot each and no LDS, so they sit beside a running
+// resampling kernel (bench.py: roofline.shader_mhz, the clock the chip's power management holds under it).
+struct sxfir_clock_probe {
+    hipStream_t stream;
+    unsigned long long *dev;
+    int n;
+};
+
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, unsigned long long ticks)
+{
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+int sxfir_clock_probe_start(sxfir_clock_probe **probe, int device, int duration_us)
+{
+    if (!probe || duration_us < 1 || duration_us > 10000000) return fail(SXFIR_EINVAL, "bad argument");
+    *probe = nullptr;
+    if (device >= 0) HIPCHECK(hipSetDevice(device));
+    sxfir_clock_probe *q = new (std::nothrow) sxfir_clock_probe();
+    if (!q) return fail(SXFIR_ENOMEM, "out of host memory");
+    q->n = 16;
+    q->dev = nullptr;
+    q->stream = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&q->dev, 16 * q->n);
+    if (e == hipSuccess) e = hipMemsetAsync(q->dev, 0, 16 * q->n, q->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(q->n), dim3(64), 0, q->stream, q->dev, 100ull * (unsigned long long)duration_us);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        if (q->dev) (void)hipFree(q->dev);
+        if (q->stream) (void)hipStreamDestroy(q->stream);
+        delete q;
+        return fail(SXFIR_EHIP, "clock probe: %s", hipGetErrorString(e));
+    }
+    *probe = q;
+    return SXFIR_OK;
+}
+
+int sxfir_clock_probe_read(sxfir_clock_probe *q, double *mhz)
+{
+    if (!q || !mhz) return fail(SXFIR_EINVAL, "NULL argument");
+    std::vector<unsigned long long> h(2 * (size_t)q->n);
+    hipError_t e = hipStreamSynchronize(q->stream);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), q->dev, 16 * q->n, hipMemcpyDeviceToHost);
+    (void)hipFree(q->dev);
+    (void)hipStreamDestroy(q->stream);
+    const int n = q->n;
+    delete q;
+    if (e != hipSuccess) return fail(SXFIR_EHIP, "clock probe: %s", hipGetErrorString(e));
+    std::vector<double> f;
+    for (int i = 0; i < n; ++i)
+        if (h[2 * i + 1] > 0) f.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+    if (f.empty()) return fail(SXFIR_EHIP, "clock probe recorded nothing");
+    std::sort(f.begin(), f.end());
+    *mhz = f[f.size() / 2];
     return SXFIR_OK;
 }
 

@@ -20,6 +20,14 @@
 //           LDS (one ds_read_b128 + ds_write_b128 per lane and tile) instead of
 //           fetching it again: 11 % fewer bytes through the L2 -> LDS path.
 //   PRIO    the wave raises its priority for the arithmetic of a tile.
+//   CUQ     one workgroup of WPG = 16 waves per CU, each wave with its private image, takes the tiles of the
+//           workgroup's share from a counter in LDS (ds_add_rtn, ~100 cycles) instead of a fixed tile list per
+//           wave.  Measured (profiles/round2i_wave_lifetimes.txt): with a fixed list the four waves of a SIMD
+//           finish 330 .. 520 us apart -- the SIMD's issue arbitration favours the older wave -- while every
+//           CU's mean is within 3 %; the kernel then lasts as long as its slowest wave, or it is cut into 16
+//           generations of short waves that each pay a prologue and a ~3 us hand-over.  With the queue the
+//           waves of a CU stay busy until its share is done: one generation, one prologue per wave.  The
+//           global tile order is the strided, XCD-blocked one (16 consecutive tiles per workgroup and pass).
 //   SCALAR  symmetric filters (h[k] == h[NT-1-k] bit for bit, which every linear-phase design is): the 64
 //           distinct taps live in SGPR pairs for the whole kernel and are the scalar operand of the packed
 //           FMAs.  Measured (tools/valu_power_probe.hip): this kernel is bound by its FMAs at the clock the
@@ -41,7 +49,7 @@
 
 namespace sxfir {
 
-enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64 };
+enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64, T2_CUQ = 128 };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -214,14 +222,16 @@ __device__ __forceinline__ void st16(const f32x4 &v, f32x4 *dst)
 // ABL (profiling): 0 = the real kernel, 1 = staging + stores without the FIR (memory side alone), 2 = FIR on
 // whatever LDS holds (no staging), 5 = the real kernel with s_memtime stamps around its phases (a.stamps:
 // per wave 8 x uint64 {tiles, cycles issuing DMAs, waiting for data, FIR arithmetic, output transposition +
-// stores, cycles from the wave's first to its last instruction, the same span in 100 MHz ticks, 0}).
+// stores, cycles from the wave's first to its last instruction, the same span in 100 MHz ticks, XCC_ID | HW_ID << 8}).
 template <int NT, int WPG, int OPT, int ABL = 0, bool S32IN = false>
 __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileArgs a)
 {
     using C = DecimTile4<NT>;
     constexpr bool DEFER = (OPT & T2_DEFER) != 0, TAPSEP = (OPT & T2_TAPSEP) != 0, DBUF = (OPT & T2_DBUF) != 0;
     constexpr bool PLAINST = (OPT & T2_PLAINST) != 0, HCARRY = (OPT & T2_HCARRY) != 0, PRIO = (OPT & T2_PRIO) != 0;
-    constexpr bool SCALAR = (OPT & T2_SCALAR) != 0;
+    constexpr bool SCALAR = (OPT & T2_SCALAR) != 0, CUQ = (OPT & T2_CUQ) != 0;
+    static_assert(!CUQ || (!DBUF && !HCARRY && !TAPSEP && (WPG & (WPG - 1)) == 0), "the LDS tile queue drives the single-buffered loop");
+    __shared__ unsigned cuq_next;                        // CUQ: tiles of this workgroup's share handed out so far
     static_assert(!(HCARRY && DBUF), "halo carry-over is for the single-buffered loop");
     static_assert(!SCALAR || (NT == 128 && !TAPSEP), "scalar taps: 128-tap symmetric filters, no tap staging");
     constexpr int IMG = C::SLOTS;                       // slots per tile image
@@ -293,9 +303,13 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         tile_end = a.n_tiles;
         tile_step = G * WPG;
     }
-    if (tile >= tile_end) return;
-
-    if (b * WPG + ww == a.hist_wave) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
+    if constexpr (CUQ) {
+        if (threadIdx.x == 0) cuq_next = 0u;
+        __syncthreads();
+    } else {
+        if (tile >= tile_end) return;
+        if (b * WPG + ww == a.hist_wave) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
+    }
 
     // taps: this lane's half as 64-bit VGPR pairs, fetched once through an LDS broadcast -- or, for a
     // symmetric filter, the 64 distinct taps as SGPR pairs (scalar loads from the constant address space;
@@ -410,7 +424,33 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
     };
 
     int ntile = 0;
-    if constexpr (!DBUF) {
+    if constexpr (CUQ) {
+        // k-th grab of this workgroup: pass k / WPG, tile k % WPG of the workgroup's WPG consecutive tiles
+        const int S0 = (a.sched == 0 && a.w8) ? (b & 7) * a.w8 + (b >> 3) : b;
+        auto grab = [&]() __attribute__((always_inline)) -> int {
+            unsigned k = 0;
+            if (c.lane == 0) k = __hip_atomic_fetch_add(&cuq_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+            const long long t = ((long long)S0 + (long long)(k / WPG) * G) * WPG + (k % WPG);
+            return t < a.n_tiles ? (int)t : -1;          // monotone in k: the first miss ends the wave
+        };
+        int t = grab();
+        while (t >= 0) {
+            // the wave that gets the channel's last tile carries the history over
+            if (t == a.n_tiles - 1) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
+            stage_full(t, img);
+            const int tn = grab();
+            SXFIR_T2_PHASE(1)
+            SXFIR_WAIT_VMCNT(0);
+            SXFIR_T2_PHASE(2)
+            if constexpr (DEFER) flush();
+            process(t, img);
+            ++ntile;
+            SXFIR_T2_PHASE(4)
+            t = tn;
+        }
+        if constexpr (DEFER) flush();
+    } else if constexpr (!DBUF) {
         stage_full(tile, img);
         SXFIR_T2_PHASE(1)
         SXFIR_WAIT_VMCNT(0);
@@ -484,7 +524,11 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             for (int k = 0; k < 5; ++k) rec[k] = ph[k];
             rec[5] = wave_c1 - wave_c0;
             rec[6] = wave_r1 - wave_r0;
-            rec[7] = 0;
+            // where the wave ran: XCC_ID in bits 0-3, HW_ID (wave, SIMD, CU, SH, SE ...) from bit 8 up
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            rec[7] = (unsigned long long)(xcc & 15u) | ((unsigned long long)hwid << 8);
         }
     }
 #undef SXFIR_T2_PHASE

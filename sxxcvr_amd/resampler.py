@@ -43,6 +43,21 @@ def synth_fill(out, seed, first_channel=0, start=0, fmt="CF32"):
     return out
 
 
+class ClockProbe:
+    """In-kernel shader clock while other work runs (sxfir_clock_probe_*): start, run the work, read()."""
+
+    def __init__(self, device=-1, duration_us=20000):
+        self._lib = load_sxfir()
+        self._h = C.c_void_p()
+        check(self._lib.sxfir_clock_probe_start(C.byref(self._h), int(device), int(duration_us)))
+
+    def read(self):
+        mhz = C.c_double()
+        h, self._h = self._h, C.c_void_p()
+        check(self._lib.sxfir_clock_probe_read(h, C.byref(mhz)))
+        return mhz.value
+
+
 class Resampler:
     """One sxfir plan: `nchan` independent channels of one GPU."""
 
@@ -104,9 +119,15 @@ class Resampler:
         return n_out.value
 
     def time_decimate_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream=0):
+        return self.time_passes_ptr(in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream)
+
+    def time_passes_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream=0):
+        """Mean milliseconds of `iters` back-to-back launches of the resampling kernel (HIP events on `stream`);
+        the filter state is left alone."""
         ms = C.c_float()
-        self._ck(self._lib.sxfir_time_decimate(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
-                                            out_stride, iters, C.c_void_p(stream), C.byref(ms)))
+        fn = self._lib.sxfir_time_decimate if self.mode == DECIMATE else self._lib.sxfir_time_interpolate
+        self._ck(fn(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr), out_stride, iters,
+                    C.c_void_p(stream), C.byref(ms)))
         return ms.value
 
     # -- torch tensors --------------------------------------------------------

@@ -52,6 +52,10 @@ def _load(name):
     lib.sxo_time_ns_to_ticks.restype = ll
     lib.sxo_time_ns_to_ticks.argtypes = [ll, dbl]
     lib.sxo_convert_rx.argtypes = [vp, vp, sz]
+    lib.sxo_convert_rx_mt.argtypes = [vp, vp, sz, C.c_int]
+    lib.sxo_synth_iq_mt.argtypes = [u64, C.c_uint32, i64, sz, vp, C.c_int]
+    lib.sxo_interp_f32_mt.restype = C.c_int
+    lib.sxo_interp_f32_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp, C.c_int]
     lib.sxo_convert_tx.argtypes = [vp, vp, sz, C.c_float]
     lib.sxo_synth_iq.argtypes = [u64, C.c_uint32, i64, sz, vp]
     lib.sxo_design_lowpass.argtypes = [C.c_int, C.c_int, dbl, dbl, vp]
@@ -96,6 +100,11 @@ class Oracle:
         self.lib.sxo_convert_rx(_fp(s32), _fp(out), n)
         return out
 
+    def convert_rx_into(self, s32, out, threads=1):
+        """convert_rx over `threads` threads into a caller-owned float32 array (timing aid: no allocation)."""
+        self.lib.sxo_convert_rx_mt(_fp(s32), _fp(out), s32.size // 2, int(threads))
+        return out
+
     def convert_tx(self, cf32, threshold2):
         cf32 = np.ascontiguousarray(cf32, dtype=np.complex64)
         out = np.empty(2 * cf32.size, dtype=np.int32)
@@ -106,6 +115,11 @@ class Oracle:
     def synth_iq(self, seed, channel, start, n):
         out = np.empty(n, dtype=np.complex64)
         self.lib.sxo_synth_iq(int(seed), int(channel), int(start), n, _fp(out))
+        return out
+
+    def synth_iq_mt(self, seed, channel, start, n, threads):
+        out = np.empty(n, dtype=np.complex64)
+        self.lib.sxo_synth_iq_mt(int(seed), int(channel), int(start), n, _fp(out), int(threads))
         return out
 
     def design_lowpass(self, ntaps, ratio, beta=8.0, gain=1.0):
@@ -148,6 +162,10 @@ class Oracle:
     def interp_f32(self, h, L, x, groups, n0=0, n_out=None):
         n_out = len(x) * L - n0 if n_out is None else n_out
         return self._run(self.lib.sxo_interp_f32, h, L, x, n0, n_out, groups=groups)
+
+    def interp_f32_mt(self, h, L, x, groups, n0=0, n_out=None, threads=1):
+        n_out = len(x) * L - n0 if n_out is None else n_out
+        return self._run(self.lib.sxo_interp_f32_mt, h, L, x, n0, n_out, groups=groups, threads=threads)
 
     def max_threads(self):
         return int(self.lib.sxo_max_threads())

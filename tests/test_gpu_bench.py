@@ -1,0 +1,84 @@
+"""bench.py as the driver runs it: the JSON line's contract, every --config, the self-spawned multi-rank path
+(gloo stand-in on a 1-GPU box; nccl = RCCL when two GPUs are visible), and the self-check of its outputs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "2", "--settle", "4", "--log2-samples", "22", "--no-cpu-baseline",
+         "--no-through-device"]
+
+
+def run_bench(extra, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)                                   # bench.py must start its own ranks
+    e.update(env or {})
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                         timeout=timeout, env=e)
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert len(lines) == 1, run.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", ["2", "3rx", "3tx", "5", "5h"])
+def test_bench_line_every_config(config):
+    line = run_bench(["--config", config] + SMALL)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "verified"):
+        assert key in line, key
+    assert line["verified"] is True and line["config"]["verified_outputs"] >= 4096
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 2
+    assert line["config"]["bench_config"] == config and "workload" in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 300.0 < r["shader_mhz"] < 2600.0
+    assert line["value"] > 0 and r["kernel_ms"] > 0
+
+
+def test_bench_reports_device_and_cpu_figures():
+    line = run_bench(["--steps", "3", "--warmup", "2", "--settle", "4", "--log2-samples", "22"], timeout=900)
+    assert line["verified"] is True
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["conversion_only"]["one_thread_MS/s"] > 0 and c["conversion_only"]["all_threads_MS/s"] > 0
+    t = line["through_device"]
+    assert "error" not in t, t
+    assert t["256_sample_calls"]["readStream_us_per_call"] > 0 and t["65536_sample_calls"]["readStream_out_MS/s"] > 0
+
+
+def test_bench_starts_its_own_ranks_gloo_stand_in():
+    """--gpus 2 with no launcher environment: bench.py spawns the two ranks itself.  On a 1-GPU box the ranks
+    share the GPU and the collectives run over gloo (SXFIR_DIST_BACKEND=gloo); the code path is the real one."""
+    line = run_bench(["--gpus", "2"] + SMALL, env={"SXFIR_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["config"]["channels_per_gpu"] == 8
+    g = line["gather"]
+    assert "error" not in g, g
+    assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
+
+
+def test_bench_two_ranks_over_rccl():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    line = run_bench(["--gpus", "2"] + SMALL)
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["config"]["backend"] == "nccl"
+    g = line["gather"]
+    assert "error" not in g, g
+    assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
+
+
+def test_bench_refuses_mismatched_world():
+    e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True,
+                         text=True, timeout=300, env=e)
+    assert run.returncode != 0 and "WORLD_SIZE" in (run.stdout + run.stderr)

@@ -34,7 +34,9 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
                             (8, 3, "16", "0"), (1, 16, "16", "0"), (1, 17, "16", "0"), (1, 19, "5", "0"), (2, 17, "16", "0"),
                             (2, 19, "64", "0"), (1, 32, "16", "0"), (1, 33, "16", "0"), (2, 35, "16", "0"), (1, 49, "3", "0"),
                             (2, 51, "16", "0"), (1, 64, "16", "0"), (1, 65, "16", "0"), (1, 68, "4", "0"), (1, 69, "16", "0"),
-                            (1, 80, "16", "0"), (1, 81, "7", "0"), (2, 64, "64", "2"), (2, 65, "16", "0"), (4, 65, "16", "0")]])
+                            (1, 80, "16", "0"), (1, 81, "7", "0"), (2, 64, "64", "2"), (2, 65, "16", "0"), (4, 65, "16", "0"),
+                            (16, 192, "1", "0"), (16, 193, "1", "0"), (16, 128, "1", "0"), (8, 192, "1", "0"), (4, 192, "2", "0"),
+                            (16, 224, "1", "2"), (16, 192, "3", "0")]])
 def test_variant_matches_oracle(oracle, monkeypatch, env):
     for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
@@ -97,3 +99,26 @@ def test_production_library_ignores_the_environment(oracle, monkeypatch):
         plan.set_kernel(KERNEL_TILED)
         assert plan.contract == (2, 4)
         assert_bit_exact(to_cpu(plan.process(to_gpu(x))), oracle.decim_f32(h, D, x, 2, 4), "production D=%d" % D)
+
+
+@pytest.mark.parametrize("opt", [192, 128])
+def test_cu_queue_variant_multichannel(oracle, monkeypatch, opt):
+    """One 16-wave workgroup per CU taking tiles from its LDS queue: three channels, several calls, a ragged last
+    call, history carried per channel by whichever wave gets the channel's last tile."""
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_TILE_VARIANT", "t2:16:%d" % opt)
+    monkeypatch.setenv("SXFIR_OVERSUB", "1")
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    nchan, lens = 3, [1 << 18, 8 * 1000, (1 << 16) + 8 * 33, 8 * 5]      # even output counts: tiled kernel in every call
+    total = sum(lens)
+    xs = np.stack([oracle.synth_iq(0x51255, 30 + c, 0, total) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, nchan=nchan, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        outs.append(to_cpu(plan.process(to_gpu(xs[:, pos:pos + n]))))
+        pos += n
+    got = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert_bit_exact(got[c], oracle.decim_f32(h, 4, xs[c], 2, 4), "CU queue variant %d channel %d" % (opt, c))

@@ -86,6 +86,20 @@ for c, p in zip(configs, plans):
                       c, len(r), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), per[:, 3].mean(), per.sum(1).mean(),
                       (r[:, 5] / r[:, 0]).mean(), (r[:, 5] - r[:, 1:5].sum(1)).mean(), r[:, 0].mean(),
                       *np.percentile(mhz, [10, 50, 90]), (r[:, 6] / 100.0).mean()))
+            life = r[:, 6] / 100.0
+            where = r[:, 7].astype(np.uint64)
+            xcc = (where & np.uint64(15)).astype(int)
+            hw = (where >> np.uint64(8)).astype(np.uint64)
+            simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(int)
+            cu = ((hw >> np.uint64(8)) & np.uint64(15)).astype(int)
+            se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(int)
+            print("   wave lifetime us p1/p10/p50/p90/p99/max: %s" % " ".join("%.1f" % v for v in np.percentile(life, [1, 10, 50, 90, 99, 100])))
+            print("   mean lifetime by XCC: %s" % " ".join("%d:%.1f" % (k, life[xcc == k].mean()) for k in sorted(set(xcc))))
+            cuid = xcc * 1000 + se * 100 + cu
+            per_cu = np.array([life[cuid == k].mean() for k in sorted(set(cuid))])
+            print("   %d distinct (XCC, SE, CU): mean lifetime per CU p1/p50/p99/max %s; SIMD means %s" % (
+                len(per_cu), " ".join("%.1f" % v for v in np.percentile(per_cu, [1, 50, 99, 100])),
+                " ".join("%d:%.1f" % (k, life[simd == k].mean()) for k in sorted(set(simd)))))
 for c in configs:
     a = np.array(res[c])
     gbs = (8.0 + 8.0 / D) * (1.0 if FMT == "CF32" else 0.5) * (1 << log2n) / (a * 1e-3) / 1e9

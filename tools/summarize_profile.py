@@ -1,95 +1,138 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/<tag>/ profiling directory (tools/profile_round.sh) into the
-tracked summaries under profiles/: kernel stats CSV, PMC per-launch figures, traffic.json."""
+"""Condense gpurun_out/<tag>/<config>/ (tools/profile_round.sh) into the tracked summaries under profiles/:
+<name>_<config>_kernel_stats.csv, <name>_<config>_summary.json and the per-config entry of traffic.json.
+
+    python3 tools/summarize_profile.py <tag> <name> [config ...]
+"""
 import csv
 import glob
 import json
 import os
+import re
+import subprocess
 import sys
 
-tag = sys.argv[1]
-name = sys.argv[2] if len(sys.argv) > 2 else tag
-src = os.path.join("gpurun_out", tag)
-dst = "profiles"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, name = sys.argv[1], sys.argv[2]
+configs = sys.argv[3:] or ["2"]
+dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = "decim4_tile_kernel"
+KERNELS = {"2": "decim4_tile", "3rx": "decim_multi_kernel<8", "3tx": "interp_tile_kernel<8", "5": "decim_multi_kernel<32",
+           "5h": "decim_multi_kernel<32"}
+BYTES = {"2": 10.0, "3rx": 9.0, "3tx": 9.0, "5": 8.25, "5h": 4.125}
 
 
-def one(pattern):
-    f = glob.glob(os.path.join(src, pattern), recursive=True)
-    return f[0] if f else None
-
-
-out = {"tag": name}
-stats = one("trace/**/*kernel_stats.csv")
-if stats:
-    rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(dst, name + "_kernel_stats.csv"), "w") as f:
-        w = csv.DictWriter(f, fieldnames=rows[0].keys())
-        w.writeheader()
-        w.writerows(rows)
-    for r in rows:
-        if KERNEL in r["Name"]:
-            out["kernel"] = r["Name"]
-            out["calls"] = int(r["Calls"])
-            out["avg_ns"] = float(r["AverageNs"])
-            out["min_ns"] = float(r["MinNs"])
-            out["max_ns"] = float(r["MaxNs"])
-trace = one("trace/**/*kernel_trace.csv")
-if trace:
-    rows = [r for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"]]
-    if rows:
-        r = rows[-1]
-        out["vgpr"] = r.get("VGPR_Count")
-        out["sgpr"] = r.get("SGPR_Count")
-        out["lds_bytes"] = r.get("LDS_Block_Size")
-        out["grid"] = [r.get("Grid_Size_X"), r.get("Grid_Size_Y")]
-        out["workgroup"] = r.get("Workgroup_Size_X")
-        # the profiled command is bench.py --steps 50 --warmup 50: its last 150 launches are warm-up steps,
-        # timed steps and the event-timed launches bench.py reports as roofline.kernel_ms; whatever comes
-        # before is the untimed settle phase (--settle), which contains the clock transient of the first
-        # ~20 launches
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-        if len(d) >= 150:
-            n = len(d)
-            out["avg_ns_by_phase"] = {"warmup": sum(d[n - 150:n - 100]) / 50.0, "timed": sum(d[n - 100:n - 50]) / 50.0,
-                                      "event_timed": sum(d[n - 50:]) / 50.0}
-            if n > 150:
-                out["avg_ns_by_phase"]["settle"] = sum(d[:n - 150]) / float(n - 150)
-                out["avg_ns_by_phase"]["settle_first_20"] = sum(d[:20]) / 20.0
-
-
-def counters(sub):
-    f = one(sub + "/**/*counter_collection.csv")
-    acc = {}
-    if not f:
-        return acc
-    for r in csv.DictReader(open(f)):
-        if KERNEL not in r.get("Kernel_Name", ""):
+def code_object_registers():
+    """VGPR / SGPR / LDS of every kernel as the compiler allocated them (hipcc's resource remarks on the
+    production build): rocprofv3's VGPR_Count column is not the code object's figure."""
+    cmd = ["hipcc", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--offload-arch=gfx950", "-O3", "--cuda-device-only",
+           "-c", os.path.join(ROOT, "sxxcvr_amd/csrc/sxfir.hip"), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    try:
+        err = subprocess.run(cmd, capture_output=True, text=True, timeout=900).stderr
+    except Exception:
+        return {}
+    table, cur = {}, None
+    for line in err.splitlines():
+        m = re.search(r"remark:\s+(Function Name|VGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
+        if not m:
             continue
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+        k, v = m.groups()
+        if k == "Function Name":
+            dem = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()
+            cur = table.setdefault(re.sub(r"\(.*\)$", "", dem).replace("void ", ""), {})
+        elif cur is not None:
+            cur[k.split(" ")[0]] = int(v)
+    return table
 
 
-pm = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    pm.update(counters(sub))
-out["pmc_mean_per_launch"] = pm
-if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-    # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
-    # exactly half of the bytes of a wide coalesced streaming read -> double it.
-    fetch = 2.0 * pm["FETCH_SIZE"] * 1024.0
-    write = pm["WRITE_SIZE"] * 1024.0
-    out["hbm_read_bytes_per_launch"] = fetch
-    out["hbm_write_bytes_per_launch"] = write
-    out["hbm_bytes_per_launch"] = fetch + write
-    json.dump({"hbm_bytes_per_launch": fetch + write, "read": fetch, "write": write, "source": name,
-               "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction)"},
-              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-b = os.path.join(src, "bench.json")
-if os.path.exists(b):
-    lines = [l for l in open(b) if l.startswith("{")]
-    if lines:
-        out["bench"] = json.loads(lines[-1])
-json.dump(out, open(os.path.join(dst, name + "_summary.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+REGS = code_object_registers()
+traffic_path = os.path.join(dst, "traffic.json")
+try:
+    traffic = json.load(open(traffic_path))
+    if "configs" not in traffic:
+        traffic = {"configs": {}}
+except Exception:
+    traffic = {"configs": {}}
+
+for cfg in configs:
+    src = os.path.join(ROOT, "gpurun_out", tag, cfg)
+    kern = KERNELS[cfg]
+
+    def one(pattern):
+        f = glob.glob(os.path.join(src, pattern), recursive=True)
+        return f[0] if f else None
+
+    out = {"tag": name, "config": cfg}
+    stats = one("trace/**/*kernel_stats.csv")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (name, cfg)), "w") as f:
+            w = csv.DictWriter(f, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(rows)
+        for r in rows:
+            if kern in r["Name"]:
+                out["kernel"] = r["Name"]
+                out["calls"] = int(r["Calls"])
+                out["avg_ns"] = float(r["AverageNs"])
+                out["min_ns"] = float(r["MinNs"])
+                out["max_ns"] = float(r["MaxNs"])
+    trace = one("trace/**/*kernel_trace.csv")
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace)) if kern in r["Kernel_Name"]]
+        if rows:
+            r = rows[-1]
+            out["trace_row"] = {"VGPR_Count_column": r.get("VGPR_Count"), "SGPR_Count_column": r.get("SGPR_Count"),
+                                "lds_bytes": r.get("LDS_Block_Size"), "grid": [r.get("Grid_Size_X"), r.get("Grid_Size_Y")],
+                                "workgroup": r.get("Workgroup_Size_X")}
+            # the profiled command is bench.py --steps 50 --warmup 50: its last launches are 50 warm-up steps, 50 timed
+            # steps and 2 x 50 event-timed launches (the second set beside the clock probe); whatever comes before
+            # is the untimed settle phase, which contains the clock transient of the first ~20 launches
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+            n = len(d)
+            if n >= 200:
+                out["avg_ns_by_phase"] = {"warmup": sum(d[n - 200:n - 150]) / 50.0, "timed": sum(d[n - 150:n - 100]) / 50.0,
+                                          "event_timed": sum(d[n - 100:n - 50]) / 50.0,
+                                          "event_timed_beside_clock_probe": sum(d[n - 50:]) / 50.0}
+                if n > 200:
+                    out["avg_ns_by_phase"]["settle"] = sum(d[:n - 200]) / float(n - 200)
+                    out["avg_ns_by_phase"]["settle_first_20"] = sum(d[:20]) / 20.0
+    for kname, regs in REGS.items():
+        if "kernel" in out and kname.replace("sxfir::", "") in out["kernel"].replace("void ", "").replace("sxfir::", ""):
+            out["code_object"] = dict(regs, name=kname)
+    pm = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_sq"):
+        f = one(sub + "/**/*counter_collection.csv")
+        if not f:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if kern not in r.get("Kernel_Name", ""):
+                continue
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        pm.update({k: sum(v) / len(v) for k, v in acc.items()})
+    out["pmc_mean_per_launch"] = pm
+    algorithmic = BYTES[cfg] * (1 << 28)
+    out["algorithmic_bytes_per_launch"] = algorithmic
+    if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+        # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of
+        # the bytes of a wide coalesced streaming read -> double it.
+        fetch = 2.0 * pm["FETCH_SIZE"] * 1024.0
+        write = pm["WRITE_SIZE"] * 1024.0
+        out["hbm_read_bytes_per_launch"] = fetch
+        out["hbm_write_bytes_per_launch"] = write
+        out["hbm_bytes_per_launch"] = fetch + write
+        out["traffic_over_algorithmic"] = (fetch + write) / algorithmic
+        traffic["configs"][cfg] = {"hbm_bytes_per_launch": fetch + write, "read": fetch, "write": write,
+                                   "source": "profiles/%s_%s_summary.json" % (name, cfg),
+                                   "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction)"}
+    if "GRBM_GUI_ACTIVE" in pm and out.get("avg_ns_by_phase"):
+        out["effective_clock_mhz_from_GRBM"] = pm["GRBM_GUI_ACTIVE"] / 8.0 / out["avg_ns_by_phase"]["timed"] * 1e3
+    b = os.path.join(src, "bench.json")
+    if os.path.exists(b):
+        lines = [l for l in open(b) if l.startswith("{")]
+        if lines:
+            out["bench"] = json.loads(lines[-1])
+    json.dump(out, open(os.path.join(dst, "%s_%s_summary.json" % (name, cfg)), "w"), indent=1)
+    print(cfg, json.dumps({k: out[k] for k in out if k not in ("bench", "pmc_mean_per_launch")})[:1500])
+json.dump(traffic, open(traffic_path, "w"), indent=1)
