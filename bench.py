@@ -337,7 +337,7 @@ def main():
     import torch.distributed as dist
     import sxxcvr_amd
     from sxxcvr_amd import dist as sxdist
-    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE, ClockProbe
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE, ClockProbe, StreamTimer
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
@@ -406,14 +406,21 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # the timed region: wall clock for `value`; HIP events on the launch stream around the same K launches for
+    # the kernel's average duration (one launch per step, so the event span / K is that average plus whatever
+    # gap the host leaves between launches)
+    timer = StreamTimer(stream)
     t0 = time.perf_counter()
+    timer.start()
     for _ in range(args.steps):
         step()
+    timer.stop()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kernel_ms = timer.elapsed_ms() / args.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -425,11 +432,11 @@ def main():
     first_block = (args.warmup + args.steps) <= 1
     ok1, cmp1 = verify(cfg, plan, x, y, n_in, lo, not first_block, orc)
 
-    # dominant kernel alone, HIP events on the launch stream (not torch's event API) ...
+    # the same launches once more, back to back from one C loop ...
     plan.reset()
     torch.cuda.synchronize()
     iters = min(max(args.steps, 40), 200)
-    kernel_ms = plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, iters, stream)
+    kernel_ms_loop = plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, iters, stream)
     # ... and once more with the in-kernel shader clock read beside it (a few probe waves on a second stream;
     # their presence costs the kernel a few per cent, so this pass only supplies the clock)
     probe = ClockProbe(gpu_index, 8000)
@@ -504,6 +511,8 @@ def main():
                 "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
                 "fp32_TFLOPs": round(tflops, 2),
                 "shader_mhz": round(shader_mhz, 0),
+                "kernel_ms_how": "HIP events on the launch stream around the K timed steps (one launch per step) / K",
+                "kernel_ms_back_to_back_loop": round(kernel_ms_loop, 4),
                 "kernel_ms_beside_clock_probe": round(kernel_ms_probed, 4),
                 "valu": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs_at_2400MHz": VALU_PEAK_TFLOPS,
                          "frac": round(tflops / VALU_PEAK_TFLOPS, 4),

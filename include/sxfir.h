@@ -161,6 +161,10 @@ int sxfir_stream_destroy(void *stream);
 /* Events: completion of the work queued on a stream so far, without draining what is queued later. */
 int sxfir_event_create(void **event);
 int sxfir_event_destroy(void *event);
+/* Events that carry a timestamp: record one before and one after a run of launches on their stream;
+ * sxfir_event_elapsed_ms waits for `stop` and returns the GPU time between the two. */
+int sxfir_event_create_timing(void **event);
+int sxfir_event_elapsed_ms(void *start, void *stop, float *ms);
 int sxfir_event_record(void *event, void *stream);
 int sxfir_event_sync(void *event);
 

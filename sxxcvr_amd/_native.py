@@ -84,6 +84,8 @@ def load_sxfir(profiling=False):
         "sxfir_stream_destroy": (ci, [vp]),
         "sxfir_event_create": (ci, [P(vp)]),
         "sxfir_event_destroy": (ci, [vp]),
+        "sxfir_event_create_timing": (ci, [P(vp)]),
+        "sxfir_event_elapsed_ms": (ci, [vp, vp, P(C.c_float)]),
         "sxfir_event_record": (ci, [vp, vp]),
         "sxfir_event_sync": (ci, [vp]),
         "sxfir_memcpy_h2d": (ci, [vp, vp, sz, vp]),

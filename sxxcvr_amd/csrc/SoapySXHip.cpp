@@ -176,7 +176,7 @@ public:
      ******************************************************************/
 
     SoapySDR::Stream *setupStream(const int direction, const std::string &format, const std::vector<size_t> &channels,
-                                  const SoapySDR::Kwargs &args)
+                                  const SoapySDR::Kwargs &args) override
     {
         // The reference has one channel and ignores the list (:747).  With `channels=N` a stream carries
         // all N channels, buffs[c] = channel c: the list may be empty ("automatic") or name exactly those.
@@ -216,14 +216,14 @@ public:
         return reinterpret_cast<SoapySDR::Stream *>(stream);
     }
 
-    void closeStream(SoapySDR::Stream *handle)
+    void closeStream(SoapySDR::Stream *handle) override
     {
         auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
         std::scoped_lock lock(stream->mutex);
         stream->setup_done = 0;
     }
 
-    int activateStream(SoapySDR::Stream *handle, const int flags, const long long timeNs, const size_t numElems)
+    int activateStream(SoapySDR::Stream *handle, const int flags, const long long timeNs, const size_t numElems) override
     {
         (void)flags; (void)timeNs; (void)numElems;   // ignored like the reference, :810
         std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
@@ -239,7 +239,7 @@ public:
         return 0;
     }
 
-    int deactivateStream(SoapySDR::Stream *handle, const int flags, const long long timeNs)
+    int deactivateStream(SoapySDR::Stream *handle, const int flags, const long long timeNs) override
     {
         (void)flags; (void)timeNs;
         std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
@@ -262,7 +262,7 @@ public:
         return 0;
     }
 
-    size_t getStreamMTU(SoapySDR::Stream *handle) const
+    size_t getStreamMTU(SoapySDR::Stream *handle) const override
     {
         auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
         std::scoped_lock lock(stream->mutex);
@@ -270,7 +270,7 @@ public:
     }
 
     int readStream(SoapySDR::Stream *handle, void *const *buffs, const size_t numElems, int &flags, long long &timeNs,
-                   const long timeoutUs)
+                   const long timeoutUs) override
     {
         auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
         std::scoped_lock lock(stream->mutex);
@@ -331,7 +331,7 @@ public:
     }
 
     int writeStream(SoapySDR::Stream *handle, const void *const *buffs, const size_t numElems, int &flags,
-                    const long long timeNs, const long timeoutUs)
+                    const long long timeNs, const long timeoutUs) override
     {
         auto *stream = reinterpret_cast<sx::SynthPcm *>(handle);
         std::scoped_lock lock(stream->mutex);
@@ -425,7 +425,7 @@ public:
         return (int)samples_written;
     }
 
-    long long getHardwareTime(const std::string &what) const
+    long long getHardwareTime(const std::string &what) const override
     {
         if (what == "") {
             // TX side on purpose: does not contend with an RX thread, :1110-1125
@@ -439,13 +439,13 @@ public:
         throw std::runtime_error("Unsupported time");
     }
 
-    bool hasHardwareTime(const std::string &what) const { return what == ""; }
+    bool hasHardwareTime(const std::string &what) const override { return what == ""; }
 
     /*******************************************************************
      * Sample rates
      ******************************************************************/
 
-    std::vector<double> listSampleRates(const int direction, const size_t channel) const
+    std::vector<double> listSampleRates(const int direction, const size_t channel) const override
     {
         (void)direction; (void)channel;
         std::vector<double> sampleRates;
@@ -453,14 +453,14 @@ public:
         return sampleRates;
     }
 
-    SoapySDR::RangeList getSampleRateRange(const int direction, const size_t channel) const
+    SoapySDR::RangeList getSampleRateRange(const int direction, const size_t channel) const override
     {
         SoapySDR::RangeList ranges;
         for (const auto rate : listSampleRates(direction, channel)) ranges.push_back({rate, rate, 0});
         return ranges;
     }
 
-    void setSampleRate(const int direction, const size_t channel, const double rate)
+    void setSampleRate(const int direction, const size_t channel, const double rate) override
     {
         (void)direction; (void)channel;
         std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex, reg_mutex);
@@ -483,7 +483,7 @@ public:
         if (new_rx || new_tx) rebuild_chains(new_rx, new_tx);
     }
 
-    double getSampleRate(const int direction, const size_t channel) const
+    double getSampleRate(const int direction, const size_t channel) const override
     {
         (void)direction; (void)channel;
         std::scoped_lock lock(reg_mutex);
@@ -495,19 +495,19 @@ public:
      * shadow: same registers and bit fields, no SPI traffic (Sx1255Shadow.hpp)
      ******************************************************************/
 
-    void setFrequency(const int direction, const size_t, const double frequency, const SoapySDR::Kwargs &)
+    void setFrequency(const int direction, const size_t, const double frequency, const SoapySDR::Kwargs &) override
     {
         std::scoped_lock lock(reg_mutex);
         chip.tune(direction == SOAPY_SDR_RX, frequency);
     }
 
-    double getFrequency(const int direction, const size_t) const
+    double getFrequency(const int direction, const size_t) const override
     {
         std::scoped_lock lock(reg_mutex);
         return chip.tuned(direction == SOAPY_SDR_RX);
     }
 
-    std::vector<std::string> listGains(const int direction, const size_t) const
+    std::vector<std::string> listGains(const int direction, const size_t) const override
     {
         std::vector<std::string> names;
         for (const auto &e : sx::Sx1255Shadow::elements())
@@ -515,14 +515,14 @@ public:
         return names;
     }
 
-    SoapySDR::Range getGainRange(const int direction, const size_t, const std::string &name) const
+    SoapySDR::Range getGainRange(const int direction, const size_t, const std::string &name) const override
     {
         const auto *e = sx::Sx1255Shadow::find(direction == SOAPY_SDR_RX, name);
         return e ? SoapySDR::Range(e->lo, e->hi, e->step) : SoapySDR::Range(0, 0, 0);
     }
 
     // SoapySDR's default for the overall range: element ranges added up (RX 0..78 dB, TX 0..39 dB)
-    SoapySDR::Range getGainRange(const int direction, const size_t channel) const
+    SoapySDR::Range getGainRange(const int direction, const size_t channel) const override
     {
         double lo = 0.0, hi = 0.0;
         for (const auto &name : listGains(direction, channel)) {
@@ -533,66 +533,66 @@ public:
         return SoapySDR::Range(lo, hi);
     }
 
-    void setGain(const int direction, const size_t, const std::string &name, const double value)
+    void setGain(const int direction, const size_t, const std::string &name, const double value) override
     {
         std::scoped_lock lock(reg_mutex);
         chip.set_gain(direction == SOAPY_SDR_RX, name, value);
     }
 
-    double getGain(const int direction, const size_t, const std::string &name) const
+    double getGain(const int direction, const size_t, const std::string &name) const override
     {
         std::scoped_lock lock(reg_mutex);
         return chip.gain(direction == SOAPY_SDR_RX, name);
     }
 
-    void setGain(const int direction, const size_t, const double value)
+    void setGain(const int direction, const size_t, const double value) override
     {
         std::scoped_lock lock(reg_mutex);
         chip.set_overall_gain(direction == SOAPY_SDR_RX, value);
     }
 
     // SoapySDR's default for the overall gain: the sum of the elements
-    double getGain(const int direction, const size_t channel) const
+    double getGain(const int direction, const size_t channel) const override
     {
         double total = 0.0;
         for (const auto &name : listGains(direction, channel)) total += getGain(direction, channel, name);
         return total;
     }
 
-    std::vector<std::string> listAntennas(const int direction, const size_t) const
+    std::vector<std::string> listAntennas(const int direction, const size_t) const override
     {
         // digital loop-back ("DLB") can be selected but is not advertised, as in the reference (:1407-1408)
         if (direction == SOAPY_SDR_RX) return {"RX", "LB"};
         return {"TX", "NONE"};
     }
 
-    void setAntenna(const int direction, const size_t, const std::string &name)
+    void setAntenna(const int direction, const size_t, const std::string &name) override
     {
         std::scoped_lock lock(reg_mutex);
         chip.set_antenna(direction == SOAPY_SDR_RX, name);
     }
 
-    std::string getAntenna(const int direction, const size_t) const
+    std::string getAntenna(const int direction, const size_t) const override
     {
         std::scoped_lock lock(reg_mutex);
         return chip.antenna(direction == SOAPY_SDR_RX);
     }
 
-    std::vector<unsigned> readRegisters(const std::string &, const unsigned addr, const size_t length) const
+    std::vector<unsigned> readRegisters(const std::string &, const unsigned addr, const size_t length) const override
     {
         std::scoped_lock lock(reg_mutex);
         return chip.read(addr, length);
     }
 
-    unsigned readRegister(const std::string &name, const unsigned addr) const { return readRegisters(name, addr, 1).at(0); }
+    unsigned readRegister(const std::string &name, const unsigned addr) const override { return readRegisters(name, addr, 1).at(0); }
 
-    void writeRegisters(const std::string &, const unsigned addr, const std::vector<unsigned> &value)
+    void writeRegisters(const std::string &, const unsigned addr, const std::vector<unsigned> &value) override
     {
         std::scoped_lock lock(reg_mutex);
         chip.write(addr, value);
     }
 
-    void writeRegister(const std::string &name, const unsigned addr, const unsigned value)
+    void writeRegister(const std::string &name, const unsigned addr, const unsigned value) override
     {
         writeRegisters(name, addr, std::vector<unsigned>{value});
     }
@@ -602,7 +602,7 @@ public:
      * and inspected here (new; the reference only has "PA", :1472-1493)
      ******************************************************************/
 
-    void writeSetting(const std::string &key, const std::string &value)
+    void writeSetting(const std::string &key, const std::string &value) override
     {
         if (key == "CLOCK_ADVANCE") {
             clock.advance(std::stoll(value));
@@ -617,7 +617,7 @@ public:
         }
     }
 
-    std::string readSetting(const std::string &key) const
+    std::string readSetting(const std::string &key) const override
     {
         if (key == "CLOCK_NOW") return std::to_string(clock.now());
         if (key == "RX_POSITION") return std::to_string(pcm_rx.position);
@@ -643,10 +643,10 @@ public:
      * Other hardware and driver information
      ******************************************************************/
 
-    std::string getDriverKey(void) const { return "sx"; }
-    std::string getHardwareKey(void) const { return "sx"; }
+    std::string getDriverKey(void) const override { return "sx"; }
+    std::string getHardwareKey(void) const override { return "sx"; }
 
-    SoapySDR::Kwargs getHardwareInfo(void) const
+    SoapySDR::Kwargs getHardwareInfo(void) const override
     {
         SoapySDR::Kwargs args;
         args["soapysx_tag"] = SoapySXHip_tag;
@@ -663,16 +663,16 @@ public:
         return args;
     }
 
-    size_t getNumChannels(const int direction) const { (void)direction; return (size_t)nchan; }
+    size_t getNumChannels(const int direction) const override { (void)direction; return (size_t)nchan; }
 
-    std::string getNativeStreamFormat(const int direction, const size_t channel, double &fullScale) const
+    std::string getNativeStreamFormat(const int direction, const size_t channel, double &fullScale) const override
     {
         (void)direction; (void)channel;
         fullScale = 1.0;
         return "CF32";
     }
 
-    std::vector<std::string> getStreamFormats(const int direction, const size_t channel) const
+    std::vector<std::string> getStreamFormats(const int direction, const size_t channel) const override
     {
         (void)direction; (void)channel;
         return {"CF32"};

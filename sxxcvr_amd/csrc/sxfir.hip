@@ -1207,6 +1207,23 @@ int sxfir_event_create(void **event)
     return SXFIR_OK;
 }
 
+int sxfir_event_create_timing(void **event)
+{
+    if (!event) return fail(SXFIR_EINVAL, "NULL argument");
+    hipEvent_t e = nullptr;
+    HIPCHECK(hipEventCreate(&e));
+    *event = (void *)e;
+    return SXFIR_OK;
+}
+
+int sxfir_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!start || !stop || !ms) return fail(SXFIR_EINVAL, "NULL argument");
+    HIPCHECK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SXFIR_OK;
+}
+
 int sxfir_event_destroy(void *event)
 {
     if (event) HIPCHECK(hipEventDestroy((hipEvent_t)event));

@@ -346,11 +346,24 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         }
     }
 
+    // Scalar taps: lane -> output group r (outputs 4r..4r+3 of the tile, window from chunk 8r).  A
+    // ds_read_b128 is served 16 lanes at a time, in the groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), and
+    // is conflict free when those lanes hit 16 different 16-byte slots mod 16.  With one pad slot per 16 chunks
+    // an even r = 2m sits at slot residue m + const and an odd r = 2m+1 at m + 8 or m + 9 depending on the
+    // step, so a group must not mix the two parities: the first group of each half-wave takes the even r,
+    // the second the odd r, m = 0..15 in both (SQ_LDS_BANK_CONFLICT: 160 -> 32 cycles per tile and wave).
+    int rgrp = c.lane;
+    if constexpr (SCALAR) {
+        const int l5 = c.lane & 31;
+        const bool first = l5 < 4 || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+        const int idx = first ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
+        rgrp = 2 * idx + (first ? 0 : 1) + (c.lane & 32);
+    }
     // this lane's first window chunk: tap halves on lane pairs -> 16g + (1 - p) * NT/4 (a multiple of 16);
-    // scalar taps -> 8 * lane, with a second base one slot on for an odd lane's differently placed pads
-    const int u0c = SCALAR ? 8 * c.lane : 16 * c.g - (NT / 4) * c.p + NT / 4;
+    // scalar taps -> 8r, with a second base one slot on for an odd r's differently placed pads
+    const int u0c = SCALAR ? 8 * rgrp : 16 * c.g - (NT / 4) * c.p + NT / 4;
     const int woff = u0c + (u0c >> 4);
-    const int woff2 = woff + (c.lane & 1);
+    const int woff2 = woff + (rgrp & 1);
     // output transposition buffer inside the (dead) image; with HCARRY it must leave the carried halo alone
     constexpr int XB = HCARRY ? HS + 12 : 0;
 
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         if (m0 + C::TILE_OUT <= c.n_out) {
             // through the now dead image: chunk 4g + 2p + {0,1} of the tile's 128 output chunks, read back
             // linearly, so that each global store instruction writes 1 KiB of consecutive addresses
-            const int oc = SCALAR ? 2 * c.lane : 4 * c.g + 2 * c.p;
+            const int oc = SCALAR ? 2 * rgrp : 4 * c.g + 2 * c.p;
             f32x4 *xb = buf + XB;
             xb[oc + (oc >> 4)] = (f32x4){oi[0], oq[0], oi[1], oq[1]};
             xb[oc + 1 + (oc >> 4)] = (f32x4){oi[2], oq[2], oi[3], oq[3]};
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             }
         } else {
             // ragged last tile of the call: element by element, straight from the registers
-            const long long m = m0 + (SCALAR ? 4 * c.lane : 8 * c.g + 4 * c.p);
+            const long long m = m0 + (SCALAR ? 4 * rgrp : 8 * c.g + 4 * c.p);
             float *dst = c.out + 2 * m;
 #pragma unroll
             for (int i = 0; i < 4; ++i)

@@ -43,6 +43,36 @@ def synth_fill(out, seed, first_channel=0, start=0, fmt="CF32"):
     return out
 
 
+class StreamTimer:
+    """GPU time of whatever is launched on `stream` between start() and stop(): HIP events recorded on that
+    stream through the C ABI (torch.cuda.Event would only see torch's current stream)."""
+
+    def __init__(self, stream=0):
+        self._lib = load_sxfir()
+        self._stream = C.c_void_p(stream)
+        self._e0, self._e1 = C.c_void_p(), C.c_void_p()
+        check(self._lib.sxfir_event_create_timing(C.byref(self._e0)))
+        check(self._lib.sxfir_event_create_timing(C.byref(self._e1)))
+
+    def start(self):
+        check(self._lib.sxfir_event_record(self._e0, self._stream))
+
+    def stop(self):
+        check(self._lib.sxfir_event_record(self._e1, self._stream))
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        check(self._lib.sxfir_event_elapsed_ms(self._e0, self._e1, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            self._lib.sxfir_event_destroy(self._e0)
+            self._lib.sxfir_event_destroy(self._e1)
+        except Exception:
+            pass
+
+
 class ClockProbe:
     """In-kernel shader clock while other work runs (sxfir_clock_probe_*): start, run the work, read()."""
 

@@ -1,0 +1,144 @@
+"""Whole-stream parity at BASELINE.json's full sizes: EVERY output of one call over 2^28 wideband-side samples is
+compared with the order-matched CPU oracle, for configs 2, 3 (RX and TX) and 5 (CF32 and CF16).
+
+The stream is regenerated on the host (sxo_synth_iq, all cores), filtered by the oracle's multi-threaded entry
+points (AVX2+FMA build of the same C source where the host has it, checked bit for bit against the portable
+build on a sample first) and compared in blocks of 2^20 outputs, so that a mismatch is located.  The window
+tests in test_gpu_fullsize.py stay as the fast path; these are the exhaustive ones (about a second of oracle
+time each on the GPU box's 128 threads)."""
+import numpy as np
+import pytest
+
+import sxxcvr_amd
+from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE, KERNEL_TILED
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x51255
+LOG2N = 28
+BLOCK = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def fast_oracle(oracle):
+    """The oracle the whole-stream runs use: the AVX2+FMA build when the host supports it (same source, explicit
+    fmaf, -ffp-contract=off: the bits of the portable build, which a sample confirms), else the portable one."""
+    import oracle_lib
+    cpuinfo = open("/proc/cpuinfo").read()
+    if " avx2" not in cpuinfo or " fma" not in cpuinfo:
+        return oracle
+    fast = oracle_lib.Oracle(fast=True)
+    x = oracle.synth_iq(SEED, 7, 0, 1 << 16)
+    for ntaps, ratio in ((128, 4), (256, 8), (1024, 32)):
+        h = oracle.design_lowpass(ntaps, ratio)
+        a = oracle.decim_f32(h, ratio, x, 2, 4)
+        b = fast.decim_f32(h, ratio, x, 2, 4, threads=4)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), "fast oracle build differs (decimator %d/%d)" % (ntaps, ratio)
+    h = oracle.design_lowpass(256, 8, 8.0, 8.0)
+    a = oracle.interp_f32(h, 8, x[:8192], 2)
+    b = fast.interp_f32_mt(h, 8, x[:8192], 2, threads=4)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), "fast oracle build differs (interpolator)"
+    return fast
+
+
+def _enough_memory(gib):
+    try:
+        import psutil
+        if psutil.virtual_memory().available < gib * (1 << 30):
+            pytest.skip("needs %d GiB of host memory" % gib)
+    except ImportError:
+        pass
+
+
+def _compare_blocks(got, ref, what):
+    """got, ref: 1-D arrays of equal dtype/length holding bit patterns; reports the first differing block."""
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    n = got.size
+    for b0 in range(0, n, BLOCK):
+        g, r = got[b0:b0 + BLOCK], ref[b0:b0 + BLOCK]
+        if not np.array_equal(g, r):
+            bad = np.nonzero(g != r)[0]
+            raise AssertionError("%s: block %d (outputs %d..%d): %d outputs differ, first at %d: got %#x want %#x" % (
+                what, b0 // BLOCK, b0, b0 + g.size - 1, bad.size, b0 + int(bad[0]), int(g[bad[0]]), int(r[bad[0]])))
+    return n
+
+
+@pytest.mark.parametrize("name,ntaps,ratio", [("config 2", 128, 4), ("config 3 RX", 256, 8), ("config 5 CF32", 1024, 32)])
+def test_whole_stream_decimators_cf32(fast_oracle, name, ntaps, ratio):
+    import torch
+    _enough_memory(8)
+    orc = fast_oracle
+    n = 1 << LOG2N
+    threads = orc.max_threads()
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda")
+    sxxcvr_amd.synth_fill(x, SEED, 0, 0)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio)
+    plan.set_kernel(KERNEL_TILED)
+    y = plan.process(x)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().view(np.uint64)
+    xs = orc.synth_iq_mt(SEED, 0, 0, n, threads)
+    # the stream the GPU filtered is the oracle's stream (checked on its first and last 2^20 samples and one block in between)
+    for s0 in (0, (n // 3) & ~(BLOCK - 1), n - BLOCK):
+        assert np.array_equal(x[s0:s0 + BLOCK].cpu().numpy().view(np.uint64), xs[s0:s0 + BLOCK].view(np.uint64)), "source"
+    del x
+    ref = orc.decim_f32(h, ratio, xs, *plan.contract, threads=threads).view(np.uint64)
+    compared = _compare_blocks(got, ref, name)
+    assert compared == n // ratio
+    print("%s: %d outputs compared bit for bit" % (name, compared))
+
+
+def test_whole_stream_interpolator_config3_tx(fast_oracle):
+    import torch
+    _enough_memory(8)
+    orc = fast_oracle
+    ratio, ntaps = 8, 256
+    n_in = (1 << LOG2N) // ratio
+    threads = orc.max_threads()
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, float(ratio))
+    x = torch.empty(n_in, dtype=torch.complex64, device="cuda")
+    sxxcvr_amd.synth_fill(x, SEED, 1, 0)
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, ratio)
+    plan.set_kernel(KERNEL_TILED)
+    y = plan.process(x)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().view(np.uint64)
+    del y
+    xs = orc.synth_iq_mt(SEED, 1, 0, n_in, threads)
+    assert np.array_equal(x.cpu().numpy().view(np.uint64), xs.view(np.uint64)), "source"
+    ref = orc.interp_f32_mt(h, ratio, xs, plan.contract[0], threads=threads).view(np.uint64)
+    compared = _compare_blocks(got, ref, "config 3 TX")
+    assert compared == 1 << LOG2N
+    print("config 3 TX: %d outputs compared bit for bit" % compared)
+
+
+def test_whole_stream_decimator_cf16_config5(fast_oracle):
+    """CF16 storage: the GPU's half-precision stream is copied back, widened exactly to fp32 on the host, filtered
+    by the oracle and rounded to half once; every output half-pair must match."""
+    import torch
+    _enough_memory(10)
+    orc = fast_oracle
+    ratio, ntaps = 32, 1024
+    n = 1 << LOG2N
+    threads = orc.max_threads()
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio)
+    x16 = torch.empty(n, dtype=torch.int32, device="cuda")               # one word = (I, Q) as IEEE halves
+    sxxcvr_amd.synth_fill(x16, SEED, 2, 0, fmt="CF16")
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio, fmt="CF16")
+    plan.set_kernel(KERNEL_TILED)
+    y = plan.process(x16)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().view(np.uint32)
+    words = x16.cpu().numpy()
+    del x16
+    # the source in half precision is the oracle's source rounded once (sample of 2^20), then widened exactly
+    probe = orc.f32_to_f16(orc.synth_iq(SEED, 2, 0, BLOCK).view(np.float32)).view(np.uint32)
+    assert np.array_equal(words[:BLOCK].view(np.uint32), probe), "CF16 source"
+    xq = words.view(np.float16).astype(np.float32).view(np.complex64)
+    del words
+    ref32 = orc.decim_f32(h, ratio, xq, *plan.contract, threads=threads)
+    ref = orc.f32_to_f16(ref32.view(np.float32)).view(np.uint32)
+    compared = _compare_blocks(got, ref, "config 5 CF16")
+    assert compared == n // ratio
+    print("config 5 CF16: %d outputs compared bit for bit" % compared)
