@@ -238,29 +238,37 @@ def through_device():
     import sxxcvr_amd.soapy as SoapySDR
     res = {"note": "through SoapySX-style readStream/writeStream (host buffers, PCIe, pageable caller memory); "
                    "API-parity figures, never part of value"}
-    for blk, key in ((256, "256_sample_calls"), (65536, "65536_sample_calls")):
+    import sxxcvr_amd
+    for blk, key, pin in ((256, "256_sample_calls", False), (65536, "65536_sample_calls", False),
+                          (1 << 20, "1048576_sample_calls", False), (1 << 20, "1048576_sample_calls_registered_buffer", True)):
         dev = SoapySDR.Device({"driver": "sx", "clock": "virtual"})
         dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 600000.0)
-        rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CF32", [0], {"period": str(blk)})
-        tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(blk)})
+        rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CF32", [0], {"period": str(min(blk, 65536))})
+        tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(min(blk, 65536))})
         dev.activateStream(rx)
         dev.activateStream(tx)
         buf = np.zeros(blk, dtype=np.complex64)
-        n = max(8, min(2000, (1 << 24) // blk))
-        dev.readStream(rx, [buf], blk)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            r = dev.readStream(rx, [buf], blk)
-            if r.ret != blk:
-                raise RuntimeError("readStream returned %d" % r.ret)
-        dt_rx = (time.perf_counter() - t0) / n
-        dev.writeStream(tx, [buf], blk)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            r = dev.writeStream(tx, [buf], blk)
-            if r.ret != blk:
-                raise RuntimeError("writeStream returned %d" % r.ret)
-        dt_tx = (time.perf_counter() - t0) / n
+        if pin:
+            sxxcvr_amd.pin_array(buf)                    # page-locked: the decimator stores straight into it
+        try:
+            n = max(8, min(2000, (1 << 24) // blk))
+            dev.readStream(rx, [buf], blk)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = dev.readStream(rx, [buf], blk)
+                if r.ret != blk:
+                    raise RuntimeError("readStream returned %d" % r.ret)
+            dt_rx = (time.perf_counter() - t0) / n
+            dev.writeStream(tx, [buf], blk)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = dev.writeStream(tx, [buf], blk)
+                if r.ret != blk:
+                    raise RuntimeError("writeStream returned %d" % r.ret)
+            dt_tx = (time.perf_counter() - t0) / n
+        finally:
+            if pin:
+                sxxcvr_amd.unpin_array(buf)
         res[key] = {"readStream_us_per_call": round(dt_rx * 1e6, 2), "readStream_out_MS/s": round(blk / dt_rx / 1e6, 1),
                     "readStream_wideband_in_MS/s": round(4 * blk / dt_rx / 1e6, 1),
                     "writeStream_us_per_call": round(dt_tx * 1e6, 2), "writeStream_in_MS/s": round(blk / dt_tx / 1e6, 1)}

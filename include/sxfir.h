@@ -130,6 +130,11 @@ int sxfir_synth_fill(void *out_dev, size_t n, size_t stride, int nchan, uint64_t
 int sxfir_convert_rx_s32(const int32_t *src_dev, float *dst_dev, size_t n, void *stream);
 int sxfir_convert_tx_s32(const float *src_dev, int32_t *dst_dev, size_t n, float tx_threshold2,
                          void *stream);
+/* Transmitter keying count of convert_tx_buffer (SX.cpp:132-133): adds to *counter the number of the n complex
+ * CF32 samples at src whose squared magnitude reaches tx_threshold2.  src: device memory or device-visible
+ * (pinned / registered) host memory; counter: 8-byte aligned word in DEVICE memory (sxfir_malloc; read it back
+ * with sxfir_memcpy_d2h). */
+int sxfir_count_keyed(const float *src, size_t n, float tx_threshold2, unsigned long long *counter, void *stream);
 /* CF32 <-> CF16 storage conversion (n complex samples). */
 int sxfir_cf32_to_cf16(const float *src_dev, void *dst_dev, size_t n, void *stream);
 int sxfir_cf16_to_cf32(const void *src_dev, float *dst_dev, size_t n, void *stream);
@@ -156,6 +161,13 @@ int sxfir_stream_sync(void *stream);
 int sxfir_set_device(int device);
 int sxfir_host_alloc(void **host, size_t bytes);
 int sxfir_host_free(void *host);
+/* Page-lock memory the caller already owns (e.g. the buffers it passes to readStream) so that the GPU can
+ * store into it directly, and undo it.  sxfir_host_device_pointer: the device-side address of [host, host +
+ * bytes) when that range is pinned or registered; SXFIR_EUNSUPPORTED (no message) for ordinary pageable
+ * memory. */
+int sxfir_host_register(void *host, size_t bytes);
+int sxfir_host_unregister(void *host);
+int sxfir_host_device_pointer(const void *host, size_t bytes, void **dev);
 int sxfir_stream_create(void **stream);
 int sxfir_stream_destroy(void *stream);
 /* Events: completion of the work queued on a stream so far, without draining what is queued later. */

@@ -70,6 +70,7 @@ def load_sxfir(profiling=False):
         "sxfir_synth_fill": (ci, [vp, sz, sz, ci, u64, C.c_uint32, i64, ci, vp]),
         "sxfir_convert_rx_s32": (ci, [vp, vp, sz, vp]),
         "sxfir_convert_tx_s32": (ci, [vp, vp, sz, C.c_float, vp]),
+        "sxfir_count_keyed": (ci, [vp, sz, C.c_float, vp, vp]),
         "sxfir_cf32_to_cf16": (ci, [vp, vp, sz, vp]),
         "sxfir_cf16_to_cf32": (ci, [vp, vp, sz, vp]),
         "sxfir_ticks_to_time_ns": (ll, [ll, dbl]),
@@ -80,6 +81,9 @@ def load_sxfir(profiling=False):
         "sxfir_set_device": (ci, [ci]),
         "sxfir_host_alloc": (ci, [P(vp), sz]),
         "sxfir_host_free": (ci, [vp]),
+        "sxfir_host_register": (ci, [vp, sz]),
+        "sxfir_host_unregister": (ci, [vp]),
+        "sxfir_host_device_pointer": (ci, [vp, sz, P(vp)]),
         "sxfir_stream_create": (ci, [P(vp)]),
         "sxfir_stream_destroy": (ci, [vp]),
         "sxfir_event_create": (ci, [P(vp)]),

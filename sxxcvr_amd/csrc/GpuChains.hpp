@@ -35,6 +35,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace sx {
@@ -42,6 +43,29 @@ namespace sx {
 inline void gpu_check(int rc, const char *what)
 {
     if (rc != SXFIR_OK) throw std::runtime_error(std::string(what) + ": " + sxfir_last_error());
+}
+
+// memcpy of a large block by a few threads: one core moves ~12 GB/s out of write-combined-free pinned staging,
+// the GS/s block sizes of the wideband configurations want more
+inline void block_copy(void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t kParallelFrom = size_t(4) << 20;
+    if (bytes < kParallelFrom) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    unsigned n = std::thread::hardware_concurrency();
+    n = n < 2 ? 1 : (n > 8 ? 8 : n);
+    const size_t piece = ((bytes / n) + 4095) & ~size_t(4095);
+    std::vector<std::thread> workers;
+    for (unsigned i = 1; i < n; ++i) {
+        const size_t off = piece * i;
+        if (off >= bytes) break;
+        const size_t len = std::min(piece, bytes - off);
+        workers.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
+    }
+    std::memcpy(dst, src, std::min(piece, bytes));
+    for (auto &w : workers) w.join();
 }
 
 class DeviceBuffer {
@@ -63,6 +87,7 @@ public:
         ptr_ = nullptr;
         bytes_ = 0;
     }
+    bool fits(size_t bytes) const { return bytes <= bytes_; }
     void *get() const { return ptr_; }
     char *at(size_t byte_offset) const { return static_cast<char *>(ptr_) + byte_offset; }
 
@@ -91,6 +116,7 @@ public:
         ptr_ = nullptr;
         bytes_ = 0;
     }
+    bool fits(size_t bytes) const { return bytes <= bytes_; }
     float *floats() const { return static_cast<float *>(ptr_); }
 
 private:
@@ -113,8 +139,10 @@ private:
 
 class RxChain {
 public:
-    static constexpr size_t kMinBatch = 4096;       // stream samples per channel and GPU pass
-    static constexpr size_t kMaxBatch = 1u << 16;
+    static constexpr size_t kMinBatch = 4096;          // stream samples per channel and GPU pass
+    static constexpr size_t kMaxBatchCap = 1u << 20;   // ... at most (large reads), and never more than
+    static constexpr size_t kMaxSource = 1u << 24;     // this many wideband samples per pass over all channels
+    static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long go straight into page-locked caller memory
 
     // wire_s32: the synthetic ADC stream is S32_LE I2S words and the decimator converts them on
     // load (the reference's wire format, SoapySX.cpp:103-112); otherwise CF32 end to end.
@@ -128,12 +156,20 @@ public:
         std::vector<float> taps((size_t)ntaps_);
         gpu_check(sxfir_design_lowpass(ntaps_, decim_, 8.0, 1.0, taps.data()), "sxfir_design_lowpass");
         gpu_check(sxfir_create(&plan_, SXFIR_DECIMATE, taps.data(), ntaps_, decim_, nchan_, fmt_, gpu_), "sxfir_create(rx)");
-        in_.reserve(8 * kMaxBatch * (size_t)decim_ * (size_t)nchan_);
-        for (int k = 0; k < 2; ++k) stage_[k].reserve(8 * kMaxBatch * (size_t)nchan_);
+        max_batch_ = kMinBatch;
+        while (max_batch_ < kMaxBatchCap && 2 * max_batch_ * (size_t)decim_ * (size_t)nchan_ <= kMaxSource) max_batch_ *= 2;
+        for (int k = 0; k < 2; ++k) {
+            done_[k] = nullptr;
+            gpu_check(sxfir_event_create(&done_[k]), "sxfir_event_create");
+        }
+        direct_done_ = nullptr;
+        gpu_check(sxfir_event_create(&direct_done_), "sxfir_event_create");
     }
     ~RxChain()
     {
         sxfir_stream_sync(stream_->get());
+        for (int k = 0; k < 2; ++k) sxfir_event_destroy(done_[k]);
+        sxfir_event_destroy(direct_done_);
         sxfir_destroy(plan_);
     }
     RxChain(const RxChain &) = delete;
@@ -142,6 +178,7 @@ public:
     int decim() const { return decim_; }
     int ntaps() const { return ntaps_; }
     int channels() const { return nchan_; }
+    int64_t direct_samples() const { return direct_samples_; }
 
     void reset()
     {
@@ -155,15 +192,44 @@ public:
     void produce(int64_t pos, size_t n, float *const *dsts)
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
+        // Large reads into page-locked (pinned / registered) caller memory: the decimator stores straight into
+        // it, no staging and no host copy.  Everything else goes through the pinned staging slots.
+        float *direct = nullptr;
+        size_t direct_stride = 0;
+        const bool go_direct = n >= kDirectFrom && (pos != next_ || n > staged_from(pos)) &&
+                               direct_target(dsts, n, &direct, &direct_stride);
         if (pos != next_) {
             // a jump (overrun skip, restart): whatever was read ahead is for the wrong positions
             slot_[0].n = slot_[1].n = 0;
             prime(pos);
-            batch_ = pick_batch(n);
-            launch(cur_, pos, batch_);
-            launch(cur_ ^ 1, pos + (int64_t)batch_, batch_);
+            if (!go_direct) {
+                batch_ = pick_batch(n);
+                launch(cur_, pos, batch_);
+                launch(cur_ ^ 1, pos + (int64_t)batch_, batch_);
+            }
         }
         size_t done = 0;
+        if (go_direct) {
+            // what the read-ahead already holds is handed out first: the filter has moved past it
+            done = drain_slots(pos, n, dsts);
+            int64_t p = pos + (int64_t)done;
+            void *st = stream_->get();
+            while (done < n) {
+                const size_t m = std::min(n - done, max_batch_);
+                run(p, m, direct + 2 * done, direct_stride, st);
+                p += (int64_t)m;
+                done += m;
+            }
+            gpu_check(sxfir_event_record(direct_done_, st), "sxfir_event_record");
+            gpu_check(sxfir_event_sync(direct_done_), "sxfir_event_sync");
+            direct_samples_ += (int64_t)n;
+            next_ = pos + (int64_t)n;
+            // keep the next batches in flight for whoever reads next
+            batch_ = pick_batch(n);
+            launch(cur_, next_, batch_);
+            launch(cur_ ^ 1, next_ + (int64_t)batch_, batch_);
+            return;
+        }
         while (done < n) {
             Slot &s = slot_[cur_];
             const int64_t p = pos + (int64_t)done;
@@ -182,7 +248,7 @@ public:
             const size_t off = (size_t)(p - s.pos);
             const size_t m = std::min(n - done, s.n - off);
             for (int c = 0; c < nchan_; ++c)
-                std::memcpy(dsts[c] + 2 * done, stage_[cur_].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+                block_copy(dsts[c] + 2 * done, stage_[cur_].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
             done += m;
         }
         next_ = pos + (int64_t)n;
@@ -198,34 +264,119 @@ private:
     size_t pick_batch(size_t request) const
     {
         size_t b = kMinBatch;
-        while (b < 4 * request && b < kMaxBatch) b *= 2;
+        while (b < 4 * request && b < max_batch_) b *= 2;
         return b;
+    }
+
+    // Are the caller's buffers device visible, 16-byte aligned and one uniform channel stride apart?  Then
+    // *dev / *stride (samples) describe them as one multi-channel output block.
+    bool direct_target(float *const *dsts, size_t n, float **dev, size_t *stride) const
+    {
+        if ((reinterpret_cast<uintptr_t>(dsts[0]) & 15) != 0) return false;
+        size_t st = n;
+        if (nchan_ > 1) {
+            const ptrdiff_t d = reinterpret_cast<const char *>(dsts[1]) - reinterpret_cast<const char *>(dsts[0]);
+            if (d <= 0 || d % 16 != 0 || (size_t)d < 8 * n) return false;
+            for (int c = 2; c < nchan_; ++c)
+                if (reinterpret_cast<const char *>(dsts[c]) - reinterpret_cast<const char *>(dsts[c - 1]) != d) return false;
+            st = (size_t)d / 8;
+        }
+        void *d0 = nullptr;
+        if (sxfir_host_device_pointer(dsts[0], 8 * (st * (size_t)(nchan_ - 1) + n), &d0) != SXFIR_OK) return false;
+        *dev = static_cast<float *>(d0);
+        *stride = st;
+        return true;
+    }
+
+    // hand out whatever the two slots hold of [pos, pos+n), in stream order; returns the samples delivered.
+    // Afterwards both slots are empty (the filter state is at the end of the last launched batch).
+    size_t drain_slots(int64_t pos, size_t n, float *const *dsts)
+    {
+        size_t done = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int k = pass == 0 ? cur_ : cur_ ^ 1;
+            Slot &s = slot_[k];
+            const int64_t p = pos + (int64_t)done;
+            if (s.n == 0) continue;
+            if (p >= s.pos && p < s.pos + (int64_t)s.n && done < n) {
+                wait(k);
+                const size_t off = (size_t)(p - s.pos);
+                const size_t m = std::min(n - done, s.n - off);
+                for (int c = 0; c < nchan_; ++c)
+                    block_copy(dsts[c] + 2 * done, stage_[k].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+                done += m;
+            }
+        }
+        // the filter has consumed the source up to the end of the furthest batch: the direct passes continue there
+        int64_t frontier = pos + (int64_t)done;
+        for (int k = 0; k < 2; ++k)
+            if (slot_[k].n) frontier = std::max(frontier, slot_[k].pos + (int64_t)slot_[k].n);
+        if (frontier != pos + (int64_t)done) {
+            // read-ahead beyond what this call can use from staging (the request ends inside it, or the slots
+            // are ahead of a short tail): re-prime at the hand-over point instead of skipping samples
+            prime(pos + (int64_t)done);
+        }
+        slot_[0].n = slot_[1].n = 0;
+        return done;
+    }
+
+    // stream samples [pos, pos+m) of all channels -> `out` (device-visible, channel stride out_stride samples)
+    void run(int64_t pos, size_t m, float *out, size_t out_stride, void *st)
+    {
+        size_t n_out = 0;
+        grow(in_, 8 * m * (size_t)decim_ * (size_t)nchan_);
+        gpu_check(sxfir_synth_fill(in_.get(), m * (size_t)decim_, m * (size_t)decim_, nchan_, seed_, first_channel_,
+                                   pos * decim_, fmt_, st),
+                  "sxfir_synth_fill");
+        gpu_check(sxfir_decimate(plan_, in_.get(), m * (size_t)decim_, m * (size_t)decim_, out, out_stride, &n_out, st),
+                  "sxfir_decimate");
+        if (n_out != m) throw std::runtime_error("rx chain: decimator produced an unexpected block size");
     }
 
     // stream samples [pos, pos+m) of all channels -> staging slot k, asynchronously on the chain's stream
     void launch(int k, int64_t pos, size_t m)
     {
-        size_t n_out = 0;
         void *st = stream_->get();
-        gpu_check(sxfir_synth_fill(in_.get(), m * (size_t)decim_, m * (size_t)decim_, nchan_, seed_, first_channel_,
-                                   pos * decim_, fmt_, st),
-                  "sxfir_synth_fill");
+        grow(stage_[k], 8 * m * (size_t)nchan_);
         // the decimator stores straight into the pinned staging buffer (device-visible host memory): the
         // outputs are 1/decim of the traffic and cross PCIe as they are produced, no separate D2H copy
-        gpu_check(sxfir_decimate(plan_, in_.get(), m * (size_t)decim_, m * (size_t)decim_, stage_[k].floats(), m, &n_out, st),
-                  "sxfir_decimate");
-        if (n_out != m) throw std::runtime_error("rx chain: decimator produced an unexpected block size");
+        run(pos, m, stage_[k].floats(), m, st);
+        gpu_check(sxfir_event_record(done_[k], st), "sxfir_event_record");
         slot_[k].pos = pos;
         slot_[k].n = m;
         slot_[k].ready = false;
     }
 
+    // a buffer is replaced by a larger one only when nothing queued on the chain's stream can still use it
+    template <class Buffer>
+    void grow(Buffer &b, size_t bytes)
+    {
+        if (b.fits(bytes)) return;
+        stream_->sync();
+        b.reserve(bytes);
+    }
+
+    // samples of [pos, ...) the two staging slots hold, contiguously from pos
+    size_t staged_from(int64_t pos) const
+    {
+        size_t have = 0;
+        int64_t p = pos;
+        for (int pass = 0; pass < 2; ++pass) {
+            const Slot &s = slot_[pass == 0 ? cur_ : cur_ ^ 1];
+            if (s.n && p >= s.pos && p < s.pos + (int64_t)s.n) {
+                have += (size_t)(s.pos + (int64_t)s.n - p);
+                p = s.pos + (int64_t)s.n;
+            }
+        }
+        return have;
+    }
+
+    // wait for THIS slot's pass only: the batch read ahead behind it stays in flight
     void wait(int k)
     {
         if (slot_[k].ready) return;
-        stream_->sync();                 // one stream, in order: everything launched so far has landed
-        slot_[0].ready = slot_[0].n != 0;
-        slot_[1].ready = slot_[1].n != 0;
+        gpu_check(sxfir_event_sync(done_[k]), "sxfir_event_sync");
+        slot_[k].ready = true;
     }
 
     // After a skip (overrun) or a restart the filter history is rebuilt from
@@ -235,7 +386,8 @@ private:
         void *st = stream_->get();
         gpu_check(sxfir_reset(plan_, st), "sxfir_reset");
         const int64_t warm = (ntaps_ + decim_ - 1) / decim_;     // outputs whose inputs cover ntaps samples
-        scratch_.reserve(8 * (size_t)warm * (size_t)nchan_);
+        grow(scratch_, 8 * (size_t)warm * (size_t)nchan_);
+        grow(in_, 8 * (size_t)(warm * decim_) * (size_t)nchan_);
         const int64_t from = pos - warm;                          // may be negative: source index < 0 is zero
         size_t n_out = 0;
         gpu_check(sxfir_synth_fill(in_.get(), (size_t)(warm * decim_), (size_t)(warm * decim_), nchan_, seed_,
@@ -255,9 +407,12 @@ private:
     DeviceBuffer in_, scratch_;      // wideband source block; outputs of the priming pass (discarded)
     PinnedBuffer stage_[2];
     Slot slot_[2];
+    void *done_[2];                  // recorded behind each slot's pass
+    void *direct_done_;
     int64_t next_;
     int cur_;
-    size_t batch_;
+    size_t batch_, max_batch_;
+    int64_t direct_samples_ = 0;     // samples delivered by passes that stored into caller memory
 };
 
 class TxChain {
@@ -282,6 +437,8 @@ public:
                   "sxfir_create(tx)");
         ring_.reserve(8 * ring_len_ * (size_t)nchan_);
         stage_.reserve(8 * kSlotFrames * (size_t)nchan_ * kSlots);
+        keyed_.reserve(64);
+        zero_keyed();
         for (int k = 0; k < kSlots; ++k) {
             busy_[k] = false;
             done_[k] = nullptr;
@@ -300,7 +457,24 @@ public:
     int interp() const { return interp_; }
     int channels() const { return nchan_; }
     int64_t written() const { return written_; }
-    void set_threshold2(float thr2) { gpu_check(sxfir_set_tx_threshold(plan_, thr2), "sxfir_set_tx_threshold"); }
+    void set_threshold2(float thr2)
+    {
+        thr2_ = thr2;
+        gpu_check(sxfir_set_tx_threshold(plan_, thr2), "sxfir_set_tx_threshold");
+    }
+
+    // Transmitter keying of convert_tx_buffer (SoapySX.cpp:132-133): how many application samples of channel 0
+    // reached the squared-magnitude threshold since the last reset.  Counted on the GPU as the staged blocks
+    // pass (sxfir_count_keyed into a device counter), so writeStream makes no pass of its own over the samples.
+    int64_t keyed_samples()
+    {
+        gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
+        flush();
+        unsigned long long v = 0;
+        gpu_check(sxfir_memcpy_d2h(&v, keyed_.get(), sizeof(v), stream_->get()), "sxfir_memcpy_d2h");
+        drain();
+        return (int64_t)v;
+    }
 
     void reset()
     {
@@ -311,6 +485,8 @@ public:
         next_ = 0;
         accepted_ = 0;
         written_ = 0;
+        zero_keyed();
+        data_.clear();
     }
 
     // Stream samples [pos, pos+n) of every channel from host memory (srcs[c]).  Positions the
@@ -370,8 +546,13 @@ private:
             float *host = stage_.floats() + 2 * kSlotFrames * (size_t)nchan_ * (size_t)slot_;
             for (int c = 0; c < nchan_; ++c) {
                 float *dst = host + 2 * ((size_t)c * kSlotFrames + pend_);
-                if (srcs) std::memcpy(dst, srcs[c] + 2 * done, 8 * m);
+                if (srcs) block_copy(dst, srcs[c] + 2 * done, 8 * m);
                 else std::memset(dst, 0, 8 * m);
+            }
+            if (srcs) {
+                // application data (not silence): these samples take part in the keying count
+                if (!data_.empty() && data_.back().first + data_.back().second == pend_) data_.back().second += m;
+                else data_.emplace_back(pend_, m);
             }
             pend_ += m;
             accepted_ += (int64_t)m;
@@ -400,10 +581,22 @@ private:
             next_ += (int64_t)m;
             done += m;
         }
+        for (const auto &r : data_)
+            gpu_check(sxfir_count_keyed(reinterpret_cast<const float *>(host + 8 * r.first), r.second, thr2_, keyed_counter(), st),
+                      "sxfir_count_keyed");
+        data_.clear();
         gpu_check(sxfir_event_record(done_[slot_], st), "sxfir_event_record");
         busy_[slot_] = true;
         slot_ = (slot_ + 1) % kSlots;
         pend_ = 0;
+    }
+
+    unsigned long long *keyed_counter() const { return static_cast<unsigned long long *>(keyed_.get()); }
+    void zero_keyed()
+    {
+        static const unsigned long long zero = 0;
+        gpu_check(sxfir_memcpy_h2d(keyed_.get(), &zero, sizeof(zero), stream_->get()), "sxfir_memcpy_h2d");
+        stream_->sync();
     }
 
     int gpu_, interp_, ntaps_, nchan_;
@@ -412,6 +605,9 @@ private:
     std::unique_ptr<GpuStream> stream_;
     DeviceBuffer ring_;
     PinnedBuffer stage_;
+    DeviceBuffer keyed_;                                  // the keying counter (device memory, read back on demand)
+    float thr2_ = 1.0e-6f;
+    std::vector<std::pair<size_t, size_t>> data_;         // (offset, length) of application data in the current slot
     bool busy_[kSlots];
     void *done_[kSlots];  // recorded behind each slot's GPU pass
     int64_t next_;        // stream samples passed to the GPU so far (written + silence)

@@ -67,19 +67,6 @@ std::string arg(const SoapySDR::Kwargs &args, const char *key, const char *dflt)
     return it == args.end() ? std::string(dflt) : it->second;
 }
 
-// samples whose squared magnitude reaches the keying threshold (the PTT bit of convert_tx_buffer, :132-133);
-// branch-free so that the compiler vectorises it: at GS/s block sizes a scalar loop is the slowest thing
-// writeStream does
-__attribute__((optimize("O3"))) int64_t count_keyed(const float *iq, int64_t n, float threshold2)
-{
-    int64_t count = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const float fi = iq[2 * i], fq = iq[2 * i + 1];
-        const float ii = fi * fi, qq = fq * fq;
-        count += (ii + qq >= threshold2) ? 1 : 0;
-    }
-    return count;
-}
 
 }  // namespace
 
@@ -105,7 +92,6 @@ private:
     bool wire_s32;
     std::unique_ptr<sx::RxChain> rx_chain;
     std::unique_ptr<sx::TxChain> tx_chain;
-    int64_t tx_ptt_samples;     // written samples at or above the TX threshold (PTT bit of :132-133)
     sx::Sx1255Shadow chip;      // RF front-end control surface: register values only, no SPI
 
     int64_t timestamp_to_samples(long long timestamp) const { return SoapySDR::timeNsToTicks(timestamp, sampleRate); }
@@ -132,7 +118,6 @@ private:
         pcm_tx.reset();
         if (rx_chain) rx_chain->reset();
         if (tx_chain) tx_chain->reset();
-        tx_ptt_samples = 0;
     }
 
 public:
@@ -155,7 +140,6 @@ public:
           capture_channel(0),
           seed(std::stoull(arg(args, "seed", "0x51255"), nullptr, 0)),
           wire_s32(arg(args, "wire", "cf32") == "s32"),
-          tx_ptt_samples(0),
           chip(masterClock)
     {
         SoapySDR_logf(SOAPY_SDR_INFO, "Initializing SoapySX (MI355X synthetic-IQ build)");
@@ -412,10 +396,8 @@ public:
         const int64_t samples_written = stream->begin_write((int64_t)length, &first);
         if (samples_written < 0) return pcm_error_to_soapy_tx((int)samples_written);
         try {
-            const float *src = static_cast<const float *>(buffs[0]);
-            // transmitter keying of convert_tx_buffer (:132-133): count the samples whose
-            // squared magnitude reaches the threshold (the PTT bit of the I2S word)
-            tx_ptt_samples += count_keyed(src, samples_written, tx_threshold2);
+            // (transmitter keying of convert_tx_buffer, :132-133, is counted on the GPU as the block passes:
+            // TxChain::keyed_samples)
             tx_chain->consume(first, (size_t)samples_written, reinterpret_cast<const float *const *>(buffs));
         } catch (const std::exception &e) {
             SoapySDR_logf(SOAPY_SDR_ERROR, "tx chain: %s", e.what());
@@ -623,7 +605,11 @@ public:
         if (key == "RX_POSITION") return std::to_string(pcm_rx.position);
         if (key == "TX_POSITION") return std::to_string(pcm_tx.position);
         if (key == "TX_WRITTEN") return std::to_string(tx_chain->written());
-        if (key == "TX_PTT_SAMPLES") return std::to_string(tx_ptt_samples);
+        if (key == "TX_PTT_SAMPLES") {
+            std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
+            return std::to_string(tx_chain->keyed_samples());
+        }
+        if (key == "RX_DIRECT_SAMPLES") return std::to_string(rx_chain->direct_samples());
         if (key == "RX_DECIM") return std::to_string(decim);
         if (key == "TX_INTERP") return std::to_string(interp);
         if (key == "RX_NTAPS") return std::to_string(rx_chain->ntaps());

@@ -1051,6 +1051,16 @@ int sxfir_convert_tx_s32(const float *src, int32_t *dst, size_t n, float thr2, v
     return SXFIR_OK;
 }
 
+int sxfir_count_keyed(const float *src, size_t n, float thr2, unsigned long long *counter, void *stream)
+{
+    if (n == 0) return SXFIR_OK;
+    if (!src || !counter) return fail(SXFIR_EINVAL, "NULL buffer");
+    hipLaunchKernelGGL(sxfir::count_keyed_kernel, dim3(stream_grid(n) > 256 ? 256 : stream_grid(n)), dim3(256), 0, S(stream),
+                       (const float2 *)src, (long long)n, thr2, counter);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
 int sxfir_cf32_to_cf16(const float *src, void *dst, size_t n, void *stream)
 {
     if (n == 0) return SXFIR_OK;
@@ -1174,6 +1184,47 @@ int sxfir_host_alloc(void **host, size_t bytes)
     hipError_t e = hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault);
     if (e == hipErrorOutOfMemory) return fail(SXFIR_ENOMEM, "hipHostMalloc(%zu) out of memory", bytes);
     if (e != hipSuccess) return fail(SXFIR_EHIP, "hipHostMalloc: %s", hipGetErrorString(e));
+    return SXFIR_OK;
+}
+
+int sxfir_host_register(void *host, size_t bytes)
+{
+    if (!host || !bytes) return fail(SXFIR_EINVAL, "NULL argument");
+    hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(SXFIR_EHIP, "hipHostRegister: %s", hipGetErrorString(e));
+    return SXFIR_OK;
+}
+
+int sxfir_host_unregister(void *host)
+{
+    if (host) HIPCHECK(hipHostUnregister(host));
+    return SXFIR_OK;
+}
+
+int sxfir_host_device_pointer(const void *host, size_t bytes, void **dev)
+{
+    if (!host || !dev) return fail(SXFIR_EINVAL, "NULL argument");
+    *dev = nullptr;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, host);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();                        // plain pageable memory: not an error, just not visible
+        return SXFIR_EUNSUPPORTED;
+    }
+    if (at.type != hipMemoryTypeHost) return SXFIR_EUNSUPPORTED;
+    // the last byte must belong to the same page-locked range
+    hipPointerAttribute_t end;
+    if (bytes > 1 && (hipPointerGetAttributes(&end, (const char *)host + bytes - 1) != hipSuccess || end.type != hipMemoryTypeHost)) {
+        (void)hipGetLastError();
+        return SXFIR_EUNSUPPORTED;
+    }
+    void *d = nullptr;
+    e = hipHostGetDevicePointer(&d, const_cast<void *>(host), 0);
+    if (e != hipSuccess || !d) {
+        (void)hipGetLastError();
+        return SXFIR_EUNSUPPORTED;
+    }
+    *dev = d;
     return SXFIR_OK;
 }
 

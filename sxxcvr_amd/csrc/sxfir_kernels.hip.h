@@ -264,6 +264,26 @@ __global__ __launch_bounds__(256) void convert_tx_kernel(const float2 *src, int2
     }
 }
 
+// Transmitter keying count (convert_tx_buffer, SoapySX.cpp:132-133): how many of n complex samples reach the
+// squared-magnitude threshold.  One atomic per workgroup into a counter in device memory.
+__global__ __launch_bounds__(256) void count_keyed_kernel(const float2 *src, long long n, float thr2, unsigned long long *counter)
+{
+    unsigned cnt = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 f = src[i];
+        const float ii = __fmul_rn(f.x, f.x), qq = __fmul_rn(f.y, f.y);
+        cnt += (__fadd_rn(ii, qq) >= thr2) ? 1u : 0u;
+    }
+    __shared__ unsigned block_total;
+    if (threadIdx.x == 0) block_total = 0;
+    __syncthreads();
+    // wave total by ballot-free shuffle reduction, then one LDS add per wave
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&block_total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_total) atomicAdd(counter, (unsigned long long)block_total);
+}
+
 __global__ __launch_bounds__(256) void cf32_to_cf16_kernel(const float2 *src, __half2 *dst, long long n)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -43,6 +43,18 @@ def synth_fill(out, seed, first_channel=0, start=0, fmt="CF32"):
     return out
 
 
+def pin_array(a):
+    """Page-lock a numpy array's memory (sxfir_host_register) so that the GPU can store into it directly: large
+    readStream calls into such a buffer skip the staging copy.  Undo with unpin_array before the array is freed."""
+    lib = load_sxfir()
+    check(lib.sxfir_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+    return a
+
+
+def unpin_array(a):
+    check(load_sxfir().sxfir_host_unregister(C.c_void_p(a.ctypes.data)))
+
+
 class StreamTimer:
     """GPU time of whatever is launched on `stream` between start() and stop(): HIP events recorded on that
     stream through the C ABI (torch.cuda.Event would only see torch's current stream)."""

@@ -57,6 +57,39 @@ static void rx_test()
     }
     // batching really happens: the 10 sequential reads above took far fewer GPU passes than samples / 256
     std::printf("rx_launches %d\n", launches_sequential);
+
+    // Large reads into page-locked caller memory: the decimator stores straight into it.  One block holds all
+    // channels at a uniform stride (what a numpy [nch, n] array registered with sxfir_host_register looks like);
+    // the reads continue the stream where the staged batches end, then small reads continue after them.
+    {
+        const size_t n = 40000, stride = 40960;
+        void *blk = nullptr;
+        sxfir_host_alloc(&blk, 8 * stride * NCH);
+        float *base = static_cast<float *>(blk);
+        int64_t p = 5000;
+        float *dsts[NCH];
+        for (int c = 0; c < NCH; ++c) dsts[c] = base + 2 * stride * c;
+        for (int rep = 0; rep < 2; ++rep) {
+            std::memset(blk, 0xff, 8 * stride * NCH);
+            chain.produce(p, n, dsts);
+            for (int c = 0; c < NCH; ++c) check("rx_direct", dsts[c], ref[c].data() + 2 * p, 2 * n);
+            p += (int64_t)n;
+        }
+        std::printf("rx_direct_samples %lld\n", (long long)chain.direct_samples());
+        const size_t m = 700;
+        for (int c = 0; c < NCH; ++c) { buf[c].assign(2 * m, -1.0f); dsts[c] = buf[c].data(); }
+        chain.produce(p, m, dsts);
+        for (int c = 0; c < NCH; ++c) check("rx_after_direct", buf[c].data(), ref[c].data() + 2 * p, 2 * m);
+        // the same size into ordinary memory takes the staged path
+        const long long before = (long long)chain.direct_samples();
+        std::vector<std::vector<float>> big(NCH, std::vector<float>(2 * n));
+        for (int c = 0; c < NCH; ++c) dsts[c] = big[c].data();
+        p += (int64_t)m;
+        chain.produce(p, n, dsts);
+        for (int c = 0; c < NCH; ++c) check("rx_large_pageable", dsts[c], ref[c].data() + 2 * p, 2 * n);
+        std::printf("rx_direct_unchanged %d\n", before == (long long)chain.direct_samples());
+        sxfir_host_free(blk);
+    }
 }
 
 static void tx_test()
@@ -82,6 +115,28 @@ static void tx_test()
         chain.consume(b.pos, b.n, srcs);
     }
     std::printf("tx_written %lld\n", (long long)chain.written());
+    // keying count (SoapySX.cpp:132-133) of channel 0's application samples, silence excluded, as the GPU pass counts it
+    {
+        chain.set_threshold2(0.25f);
+        // (the threshold applies to blocks flushed from now on; count what a fresh chain sees instead)
+        sx::TxChain kc(0, L, 32, ring_frames, NCH, false);
+        kc.set_threshold2(0.25f);
+        long long want = 0;
+        for (const Blk &b : blocks) {
+            std::vector<std::vector<float>> tmp(NCH, std::vector<float>(2 * b.n));
+            const float *srcs[NCH];
+            for (int c = 0; c < NCH; ++c) { sxo_synth_iq(99, 10 + c, b.pos, b.n, tmp[c].data()); srcs[c] = tmp[c].data(); }
+            for (size_t i = 0; i < b.n; ++i) {
+                const float ii = tmp[0][2 * i] * tmp[0][2 * i], qq = tmp[0][2 * i + 1] * tmp[0][2 * i + 1];
+                want += (ii + qq >= 0.25f) ? 1 : 0;
+            }
+            kc.consume(b.pos, b.n, srcs);
+        }
+        std::printf("tx_keyed %lld want %lld\n", (long long)kc.keyed_samples(), want);
+        bad += kc.keyed_samples() != want;
+        kc.reset();
+        std::printf("tx_keyed_after_reset %lld\n", (long long)kc.keyed_samples());
+    }
     // the sink holds the last ring_frames stream samples' worth of output: compare the retained tail
     const int64_t end = 65000;
     const int64_t from = end - (int64_t)ring_frames;

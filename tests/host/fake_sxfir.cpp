@@ -22,6 +22,8 @@ struct sxfir_plan {
 };
 
 static std::string g_err;
+// "page-locked" ranges: what sxfir_host_alloc returned and what sxfir_host_register was told about
+static std::vector<std::pair<const char *, size_t>> g_locked;
 static int fail(const char *m) { g_err = m; return SXFIR_EINVAL; }
 int g_fake_launches = 0;          // GPU passes (decimate / interpolate calls), read by the test
 
@@ -32,8 +34,35 @@ const char *sxfir_last_error(void) { return g_err.c_str(); }
 int sxfir_set_device(int) { return SXFIR_OK; }
 int sxfir_malloc(void **dev, size_t bytes) { *dev = std::malloc(bytes ? bytes : 1); return *dev ? SXFIR_OK : SXFIR_ENOMEM; }
 int sxfir_free(void *dev) { std::free(dev); return SXFIR_OK; }
-int sxfir_host_alloc(void **host, size_t bytes) { return sxfir_malloc(host, bytes); }
-int sxfir_host_free(void *host) { return sxfir_free(host); }
+int sxfir_host_alloc(void **host, size_t bytes)
+{
+    const int rc = sxfir_malloc(host, bytes);
+    if (rc == SXFIR_OK) g_locked.emplace_back((const char *)*host, bytes ? bytes : 1);
+    return rc;
+}
+static void unlock(const void *host)
+{
+    for (size_t i = 0; i < g_locked.size(); ++i)
+        if (g_locked[i].first == (const char *)host) { g_locked.erase(g_locked.begin() + i); return; }
+}
+int sxfir_host_free(void *host) { unlock(host); return sxfir_free(host); }
+int sxfir_host_register(void *host, size_t bytes) { g_locked.emplace_back((const char *)host, bytes); return SXFIR_OK; }
+int sxfir_host_unregister(void *host) { unlock(host); return SXFIR_OK; }
+int sxfir_host_device_pointer(const void *host, size_t bytes, void **dev)
+{
+    *dev = nullptr;
+    for (const auto &r : g_locked)
+        if ((const char *)host >= r.first && (const char *)host + bytes <= r.first + r.second) { *dev = const_cast<void *>(host); return SXFIR_OK; }
+    return SXFIR_EUNSUPPORTED;
+}
+int sxfir_count_keyed(const float *src, size_t n, float thr2, unsigned long long *counter, void *)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float ii = src[2 * i] * src[2 * i], qq = src[2 * i + 1] * src[2 * i + 1];
+        *counter += (ii + qq >= thr2) ? 1u : 0u;
+    }
+    return SXFIR_OK;
+}
 int sxfir_stream_create(void **stream) { *stream = (void *)0x1; return SXFIR_OK; }
 int sxfir_stream_destroy(void *) { return SXFIR_OK; }
 int sxfir_stream_sync(void *) { return SXFIR_OK; }

@@ -599,3 +599,102 @@ def test_repeater_example_runs():
                              capture_output=True, text=True, timeout=300)
         assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
         assert "TX placed at sample" in run.stdout
+
+
+def test_large_reads_into_registered_memory_skip_the_staging_copy(oracle):
+    """readStream with a block of >= 32768 samples into page-locked caller memory (sxxcvr_amd.pin_array = 
+    sxfir_host_register): the decimator stores straight into the caller's buffer.  Same samples as the staged
+    path, which ordinary (pageable) memory of the same size takes; small reads continue the stream seamlessly."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536"})
+    dev.activateStream(rx)
+    n = 1 << 17
+    ref = rx_reference(oracle, 4, 3 * n + 1000)
+    small = np.zeros(1000, dtype=np.complex64)
+    assert dev.readStream(rx, [small], 1000).ret == 1000
+    assert_bit_exact(small, ref[:1000], "first small read")
+    pinned = sxxcvr_amd.pin_array(np.zeros(n, dtype=np.complex64))
+    try:
+        pos = 1000
+        for rep in range(2):
+            pinned[:] = 0
+            assert dev.readStream(rx, [pinned], n).ret == n
+            assert_bit_exact(pinned, ref[pos:pos + n], "registered buffer, read %d" % rep)
+            pos += n
+        direct = int(dev.readSetting("RX_DIRECT_SAMPLES"))
+        assert direct >= n                                   # at least the first large read went direct
+        plain = np.zeros(n, dtype=np.complex64)
+        assert dev.readStream(rx, [plain], n).ret == n
+        assert_bit_exact(plain, ref[pos:pos + n], "pageable buffer")
+        assert int(dev.readSetting("RX_DIRECT_SAMPLES")) == direct
+    finally:
+        sxxcvr_amd.unpin_array(pinned)
+    dev.deactivateStream(rx)
+    dev.closeStream(rx)
+
+
+def test_keying_count_on_the_gpu_matches_the_reference_rule(oracle):
+    """TX_PTT_SAMPLES: the number of written samples whose squared magnitude reaches threshold^2 (the PTT bit of
+    convert_tx_buffer, SX.cpp:126-135), counted by the GPU as the staged blocks pass; silence from timed gaps
+    is not counted."""
+    dev = make()
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"threshold": "0.5"})
+    dev.activateStream(tx)
+    rng = np.random.default_rng(4)
+    want = 0
+    for blk in (256, 1000, 5000, 256):
+        x = (rng.uniform(-1, 1, blk) + 1j * rng.uniform(-1, 1, blk)).astype(np.complex64)
+        f = x.view(np.float32).reshape(-1, 2)
+        want += int(np.count_nonzero(f[:, 0] * f[:, 0] + f[:, 1] * f[:, 1] >= np.float32(0.25)))
+        assert dev.writeStream(tx, [x], blk).ret == blk
+    assert int(dev.readSetting("TX_PTT_SAMPLES")) == want and want > 0
+    dev.deactivateStream(tx)
+    dev.closeStream(tx)
+
+
+@pytest.mark.parametrize("shards_per_gpu", [1, 2])
+def test_config4_channel_shards_through_the_device_path(oracle, shards_per_gpu):
+    """BASELINE config 4 in its natural SoapySDR form: one process, one Device per shard of 8 channels (gpu=k,
+    channels=8, first_channel=8k; one Device per visible GPU, times shards_per_gpu to exercise several shards on a
+    1-GPU box), one reader thread each, no inter-GPU traffic (buffs[c] are host buffers).  Every channel of every
+    shard is compared with the oracle; all shards run concurrently."""
+    import threading
+    import torch
+    ngpu = torch.cuda.device_count()
+    shards = [(g, s) for g in range(ngpu) for s in range(shards_per_gpu)]
+    per, n_read, blocks = 8, 20000, (256, 4096, 256, 15000, 392)
+    assert sum(blocks) == n_read
+    devs = []
+    for k, (g, s) in enumerate(shards):
+        devs.append(make(gpu=str(g), channels=str(per), first_channel=str(per * k)))
+    results, errors = [None] * len(shards), []
+
+    def reader(k):
+        try:
+            dev = devs[k]
+            rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, list(range(per)), {})
+            dev.activateStream(rx)
+            got = [[] for _ in range(per)]
+            for b in blocks:
+                bufs = [np.zeros(b, dtype=np.complex64) for _ in range(per)]
+                r = dev.readStream(rx, bufs, b)
+                assert r.ret == b
+                for c in range(per):
+                    got[c].append(bufs[c])
+            dev.deactivateStream(rx)
+            dev.closeStream(rx)
+            results[k] = [np.concatenate(g) for g in got]
+        except Exception as e:                               # surfaced in the main thread below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=reader, args=(k,)) for k in range(len(shards))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    for k in range(len(shards)):
+        for c in range(per):
+            ref = oracle.decim_f32(h, 4, oracle.synth_iq(SEED, per * k + c, 0, 4 * n_read), 2, 4)
+            assert_bit_exact(results[k][c], ref, "shard %d (gpu %d) channel %d" % (k, shards[k][0], per * k + c))

@@ -112,3 +112,9 @@ def test_gpu_chains_over_fake_backend(oracle, tmp_path):
     # ten sequential reads (154k samples per channel) in a handful of batched passes, not one per read
     launches = int([l for l in lines if l.startswith("rx_launches")][0].split()[1])
     assert launches <= 12
+    # a large read into page-locked caller memory is stored by the decimator itself (the first of the two reads of
+    # 40000 per channel: the second finds its samples already read ahead in staging); the same size into ordinary
+    # memory goes through staging
+    assert "rx_direct_samples 40000" in lines and "rx_direct_unchanged 1" in lines
+    keyed = [l for l in lines if l.startswith("tx_keyed ")][0].split()
+    assert keyed[1] == keyed[3] and int(keyed[1]) > 0 and "tx_keyed_after_reset 0" in lines
