@@ -85,15 +85,16 @@ for cfg in configs:
             out["trace_row"] = {"VGPR_Count_column": r.get("VGPR_Count"), "SGPR_Count_column": r.get("SGPR_Count"),
                                 "lds_bytes": r.get("LDS_Block_Size"), "grid": [r.get("Grid_Size_X"), r.get("Grid_Size_Y")],
                                 "workgroup": r.get("Workgroup_Size_X")}
-            # the profiled command is bench.py --steps 50 --warmup 50: its last launches are 50 warm-up steps, 50 timed
-            # steps and 2 x 50 event-timed launches (the second set beside the clock probe); whatever comes before
-            # is the untimed settle phase, which contains the clock transient of the first ~20 launches
+            # the profiled command is bench.py --steps 50 --warmup 50: its last launches are 50 warm-up steps, the 50
+            # timed steps (bracketed by the HIP events bench.py reports as roofline.kernel_ms), 50 launches from one
+            # back-to-back C loop and 50 more beside the clock probe; whatever comes before is the untimed settle
+            # phase, which contains the clock transient of the first ~20 launches
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             n = len(d)
             if n >= 200:
                 out["avg_ns_by_phase"] = {"warmup": sum(d[n - 200:n - 150]) / 50.0, "timed": sum(d[n - 150:n - 100]) / 50.0,
-                                          "event_timed": sum(d[n - 100:n - 50]) / 50.0,
-                                          "event_timed_beside_clock_probe": sum(d[n - 50:]) / 50.0}
+                                          "back_to_back_loop": sum(d[n - 100:n - 50]) / 50.0,
+                                          "beside_clock_probe": sum(d[n - 50:]) / 50.0}
                 if n > 200:
                     out["avg_ns_by_phase"]["settle"] = sum(d[:n - 200]) / float(n - 200)
                     out["avg_ns_by_phase"]["settle_first_20"] = sum(d[:20]) / 20.0
