@@ -43,6 +43,7 @@
 
 #include "GpuChains.hpp"
 #include "Sx1255Shadow.hpp"
+#include "StreamRules.hpp"
 #include "SynthPcm.hpp"
 
 const char *SoapySXHip_tag = "sx-mi355x";
@@ -271,29 +272,21 @@ public:
         }
         SoapySDR_logf(SOAPY_SDR_DEBUG, "rx avail_delay: %d %ld %ld", avail_ret, (long)pcm_avail, (long)pcm_delay);
 
-        // More available than the ring holds: the oldest samples were
-        // overwritten.  Skip whole periods plus a 1-2 period margin, :910-927.
-        if (pcm_avail > (int64_t)stream->hwp_buffer_size) {
-            const uint64_t overwritten = (uint64_t)pcm_avail - stream->hwp_buffer_size;
-            const uint64_t samples_to_skip = (overwritten / stream->hwp_period_size + 2) * stream->hwp_period_size;
-            const int64_t forwarded = stream->forward((int64_t)samples_to_skip);
-            if (forwarded >= 0) {
-                stream->position += forwarded;
-                pcm_avail -= forwarded;
-                SoapySDR_logf(SOAPY_SDR_WARNING, "RX buffer overrun. Skipped %ld samples", (long)forwarded);
-            } else {
+        // Overrun (the oldest samples were overwritten): jump ahead by the rule's catch-up distance, :910-927.
+        if (const int64_t samples_to_skip = sx::rules::rx_overrun_skip(pcm_avail, stream->hwp_buffer_size, stream->hwp_period_size)) {
+            const int64_t forwarded = stream->forward(samples_to_skip);
+            if (forwarded < 0) {
                 SoapySDR_logf(SOAPY_SDR_ERROR, "rx forward: %ld", (long)forwarded);
                 return pcm_error_to_soapy_rx((int)forwarded);
             }
+            stream->position += forwarded;
+            pcm_avail -= forwarded;
+            SoapySDR_logf(SOAPY_SDR_WARNING, "RX buffer overrun. Skipped %ld samples", (long)forwarded);
         }
 
-        uint64_t length = (uint64_t)std::min(numElems, (size_t)ULONG_MAX);
-        if (timeoutUs <= 0) {   // non-blocking: what is there now, :934-942
-            if (pcm_avail <= 0) length = 0;
-            else if ((uint64_t)pcm_avail < length) length = (uint64_t)pcm_avail;
-        }
+        // blocking: the whole request; non-blocking: what is there now, :934-942
+        uint64_t length = sx::rules::request_length((uint64_t)std::min(numElems, (size_t)INT_MAX), pcm_avail, timeoutUs);
         if (length == 0) return 0;
-        if (length > (uint64_t)INT_MAX) length = (uint64_t)INT_MAX;
 
         int64_t first = 0;
         const int64_t samples_read = stream->begin_read((int64_t)length, &first);
@@ -331,31 +324,20 @@ public:
         }
         SoapySDR_logf(SOAPY_SDR_DEBUG, "tx avail_delay: %d %ld %ld", avail_ret, (long)pcm_avail, (long)pcm_delay);
 
-        const int64_t playback_position = stream->position - pcm_delay;   // :1000
-        int64_t write_position;
-        uint64_t length = (uint64_t)std::min(numElems, (size_t)ULONG_MAX);
-        if (length > (uint64_t)INT_MAX) length = (uint64_t)INT_MAX;
-
-        if (flags & SOAPY_SDR_HAS_TIME) {
-            // place the block at the position its timestamp names; a timestamp
-            // in the past is dropped but reported as written, :1009-1023
-            write_position = timestamp_to_samples(timeNs);
-            const int64_t diff = playback_position - write_position;
-            if (diff > 0) {
-                SoapySDR_logf(SOAPY_SDR_WARNING, "Discarding TX %ld samples in the past", (long)diff);
-                return (int)length;
-            }
-        } else {
-            // continue where the last write ended; after an underrun skip
-            // ahead by whole periods plus a 1-2 period margin, :1024-1038
-            write_position = stream->position;
-            int64_t diff = playback_position - write_position;
-            if (diff > 0) {
-                diff = (diff / (int64_t)stream->hwp_period_size + 2) * (int64_t)stream->hwp_period_size;
-                write_position += diff;
-                SoapySDR_logf(SOAPY_SDR_WARNING, "TX buffer underrun. Forwarding TX stream by %ld samples", (long)diff);
-            }
+        uint64_t length = (uint64_t)std::min(numElems, (size_t)INT_MAX);
+        // where the block lands: at its timestamp, behind the previous block, or past an underrun, :1000-1038
+        const bool timed = (flags & SOAPY_SDR_HAS_TIME) != 0;
+        const sx::rules::TxPlacement place = sx::rules::tx_placement(stream->position, pcm_delay, stream->hwp_period_size, timed,
+                                                                    timed ? timestamp_to_samples(timeNs) : 0);
+        if (place.kind == sx::rules::TxPlacement::IN_THE_PAST) {
+            // dropped, but reported as written (:1014-1022)
+            SoapySDR_logf(SOAPY_SDR_WARNING, "Discarding TX %ld samples in the past", (long)place.late);
+            return (int)length;
         }
+        if (place.kind == sx::rules::TxPlacement::PAST_UNDERRUN)
+            SoapySDR_logf(SOAPY_SDR_WARNING, "TX buffer underrun. Forwarding TX stream by %ld samples",
+                          (long)(place.write_position - stream->position));
+        const int64_t write_position = place.write_position;
 
         // forward to the write position; what is skipped plays as silence, :1043-1073
         int64_t posdiff = write_position - stream->position;
@@ -386,10 +368,7 @@ public:
             pcm_avail -= forwarded;
         }
 
-        if (timeoutUs <= 0) {   // non-blocking: what fits now, :1076-1085
-            if (pcm_avail <= 0) length = 0;
-            else if ((uint64_t)pcm_avail < length) length = (uint64_t)pcm_avail;
-        }
+        length = sx::rules::request_length(length, pcm_avail, timeoutUs);   // non-blocking: what fits now, :1076-1085
         if (length == 0) return 0;
 
         int64_t first = 0;

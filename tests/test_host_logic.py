@@ -118,3 +118,17 @@ def test_gpu_chains_over_fake_backend(oracle, tmp_path):
     assert "rx_direct_samples 40000" in lines and "rx_direct_unchanged 1" in lines
     keyed = [l for l in lines if l.startswith("tx_keyed ")][0].split()
     assert keyed[1] == keyed[3] and int(keyed[1]) > 0 and "tx_keyed_after_reset 0" in lines
+
+
+def test_stream_placement_rules_against_the_oracle(tmp_path):
+    """StreamRules.hpp -- the overrun skip, the non-blocking clamp and the playback placement (timestamp / in
+    sequence / past an underrun / in the past) that SoapySXHip::readStream and writeStream apply -- swept over
+    400 000 random and edge-case counter sets against the oracle's restatement of SoapySX.cpp:897-1100."""
+    exe = str(tmp_path / "stream_rules_probe")
+    odir = os.path.join(ROOT, "oracle")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "sxxcvr_amd", "csrc"), "-I" + odir,
+           os.path.join(ROOT, "tests", "host", "stream_rules_probe.cpp"), "-o", exe, "-L" + odir, "-lsxoracle",
+           "-Wl,-rpath," + odir]
+    subprocess.run(cmd, check=True)
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0 and run.stdout.strip().endswith("cases 400000 mismatches 0"), run.stdout[-1500:]
