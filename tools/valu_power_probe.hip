@@ -1,8 +1,8 @@
 // What does the chip sustain on the FIR's arithmetic alone, and does the operand source matter?
 // 4 waves per SIMD on every CU run loops of 512 packed FMAs per "tile" on random data, as the /4 tile kernel
 // does, in four forms: taps in VGPR pairs (3 VGPR operands per v_pk_fma_f32, the shipped form), taps in
-// SGPR pairs (2 VGPR operands), scalar v_fmac_f32 with an SGPR tap, and the VGPR form with the kernel's 47
-// ds_read_b128 per tile interleaved.  Reports wall time per tile and SIMD, and the in-kernel shader clock
+// SGPR pairs (2 VGPR operands), scalar v_fmac_f32 with an SGPR tap, and both packed forms with 39 / 47 / 71
+// ds_read_b128 per tile interleaved (the LDS read counts of the kernels' work splits).  Reports wall time per tile and SIMD, and the in-kernel shader clock
 // (s_memtime / s_memrealtime), after a warm-up long enough for the power management to settle.
 // Profiling aid: hipcc --offload-arch=gfx950 -O3 tools/valu_power_probe.hip -o /tmp/valu_power_probe
 #include <hip/hip_runtime.h>
@@ -26,8 +26,9 @@ __device__ __forceinline__ void pks_hi(f2& acc, const f2& h, const f2& x) {
   asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(h), "v"(x));
 }
 
-// MODE 0: VGPR taps, 1: SGPR taps, 2: scalar fmac with SGPR taps, 3: VGPR taps + 47 LDS reads per tile
-template <int MODE>
+// MODE 0: VGPR taps, 1: SGPR taps, 2: scalar fmac with SGPR taps; READS = ds_read_b128 per 512 packed FMAs (their
+// values are only kept alive, no extra VALU work)
+template <int MODE, int READS = 0>
 __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, float* __restrict__ out, int tiles,
                                              unsigned long long* stamps) {
   __shared__ f4 lds[640 * 4];
@@ -56,18 +57,18 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
   for (int t = 0; t < tiles; ++t) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {          // 8 x 64 = 512 packed FMAs
-      if (MODE == 3) {
+      if (READS > 0) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {        // ~47 reads per tile
-          if (r * 6 + q < 47) {
-            const f4 v = win[(r * 6 + q) % 60];
-            x[q & 3] = x[q & 3] + (f2){v.x, v.w} * 1e-6f;
+        for (int q = 0; q < (READS + 7) / 8; ++q) {
+          if (r * ((READS + 7) / 8) + q < READS) {
+            const f4 v = win[(r * 9 + q) % 60 + ((r * 9 + q) % 60) / 16];
+            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
           }
         }
       }
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        if (MODE == 0 || MODE == 3) {
+        if (MODE == 0) {
           pkv_lo(acc[(2 * k) & 7], hv[k], x[k & 3]);
           pkv_hi(acc[(2 * k + 1) & 7], hv[k], x[(k + 1) & 3]);
         } else if (MODE == 1) {
@@ -105,16 +106,22 @@ int main() {
   CK(hipMemcpy(taps, h, 512, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int tiles = 256;                   // per wave and launch: one launch = the FIR work of one bench step
-  const char* names[4] = {"v_pk_fma_f32, taps in VGPR pairs (shipped)", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
-                          "v_pk_fma_f32 VGPR taps + 47 ds_read_b128 per tile"};
+  const char* names[8] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
+                          "VGPR taps + 47 ds_read_b128 per tile (first-generation kernel's mix)", "SGPR taps + 47 ds_read_b128 per tile",
+                          "SGPR taps + 71 ds_read_b128 per tile (shipped scalar kernel's mix)", "SGPR taps + 39 ds_read_b128 per tile",
+                          "VGPR taps + 71 ds_read_b128 per tile"};
   for (int rep = 0; rep < 2; ++rep)
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
       auto launch = [&] {
         switch (mode) {
           case 0: hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 1: hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 2: hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
-          default: hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 3: hipLaunchKernelGGL((probe<0, 47>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 4: hipLaunchKernelGGL((probe<1, 47>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 5: hipLaunchKernelGGL((probe<1, 71>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 6: hipLaunchKernelGGL((probe<1, 39>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          default: hipLaunchKernelGGL((probe<0, 71>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
         }
       };
       for (int i = 0; i < 300; ++i) launch();          // ~100 ms: let the clocks settle on this load
@@ -127,7 +134,7 @@ int main() {
       std::vector<double> mhz, cyc;
       for (int w = 0; w < blocks * 4; ++w) if (st[2 * w + 1]) { mhz.push_back(100.0 * st[2 * w] / st[2 * w + 1]); cyc.push_back((double)st[2 * w] / tiles); }
       std::sort(mhz.begin(), mhz.end()); std::sort(cyc.begin(), cyc.end());
-      printf("%-52s %.4f ms per launch (256 tiles per wave, 4 waves/SIMD: x0.25 = one bench step's FIR) | %.0f cycles per tile per wave | in-kernel clock %.0f MHz\n",
+      printf("%-72s %.4f ms per launch (256 tiles per wave, 4 waves/SIMD: x0.25 = one bench step's FIR) | %.0f cycles per tile per wave | in-kernel clock %.0f MHz\n",
              names[mode], ms, cyc[cyc.size() / 2], mhz[mhz.size() / 2]);
       fflush(stdout);
     }
