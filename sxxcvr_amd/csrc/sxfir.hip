@@ -49,6 +49,7 @@
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
+#include "sxfir_decim_pair.hip.h"
 #ifdef SXFIR_PROFILING
 #include "sxfir_decim_sgpr.hip.h"
 #include "../../include/sxfir_prof.h"
@@ -103,6 +104,9 @@ struct sxfir_plan {
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
     int t2_wpg, t2_opt;    // profiling only: decim4_tile2_kernel variant (waves per workgroup, T2_* bits); wpg 0 = off
+    bool pair;             // decim4_pair_kernel: the two tap halves on the two waves of a workgroup
+    bool pair_xsep;        // ... with a separate exchange buffer (two barriers per tile instead of four)
+    int occ_pair;          // its resident workgroups per CU
     int compute_units;
     float *taps_dev;
     float *taps_scaled_dev;   // taps * 2^-31 (exact): scalar-tap kernel on S32 wire words
@@ -241,6 +245,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
     p->t2_wpg = p->t2_opt = 0;
+    p->pair = false;
+    p->pair_xsep = false;
+    p->occ_pair = 8;
     p->occ_multi = 2;
     // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's prologue
     // (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16; the
@@ -301,6 +308,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                               : (ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
                                               : (const void *)sxfir::decim4_tile_kernel<64, false>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
+        if (ntaps == 128) {
+            const void *kp = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_pair_kernel<0, true> : (const void *)sxfir::decim4_pair_kernel<0, false>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 128, 0) == hipSuccess && nb > 0) p->occ_pair = nb;
+        }
 #ifdef SXFIR_PROFILING
         const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
                                        : (const void *)sxfir::decim4_tile_kernel<64, true>;
@@ -315,6 +326,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                                : (const void *)sxfir::decim4_sgpr_kernel<4>;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0)
                     p->occ_sb = nb;
+            }
+            // "pair": decim4_pair_kernel (sxfir_decim_pair.hip.h)
+            if (strncmp(v, "pair", 4) == 0 && ntaps == 128) {
+                p->pair = true;
+                p->pair_xsep = strcmp(v, "pairx") == 0;
+                if (p->pair_xsep) p->occ_pair = 7;
             }
             // "t2:<waves per workgroup>:<option bits>": decim4_tile2_kernel (sxfir_decim_tile2.hip.h)
             if (strncmp(v, "t2:", 3) == 0 && ntaps == 128 && fmt == SXFIR_CF32) {
@@ -598,6 +615,43 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.sched = p->sched;
         a.stamps = nullptr;
+        if (p->pair && p->ntaps == 128) {
+            // decim4_pair_kernel: tiles of 512 outputs, one 2-wave workgroup each, strided XCD-blocked passes
+            const long long n_tiles2 = (n_out + 511) / 512;
+            long long G = ((long long)p->compute_units * p->occ_pair * p->oversub) / p->nchan;
+            if (G < 1) G = 1;
+            if (G > n_tiles2) G = n_tiles2;
+            a.n_tiles = (int)n_tiles2;
+            a.n_waves = (int)G;
+            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
+            a.run_base = a.run_extra = 0;
+            {
+                const int t = (int)((n_tiles2 - 1) % G);
+                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+            }
+            dim3 grid((unsigned)G, (unsigned)p->nchan);
+            int abl = 0;
+#ifdef SXFIR_PROFILING
+            abl = p->ablate;
+            if (abl == 5) {
+                const size_t need = (size_t)G * p->nchan * 2;
+                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
+                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
+                p->stamps_n = need;
+                a.stamps = (unsigned long long *)p->stamps_dev;
+            }
+#endif
+            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, true>), grid, dim3(128), 0, st, a);
+#ifdef SXFIR_PROFILING
+            else if (p->pair_xsep && abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false, true>), grid, dim3(128), 0, st, a);
+            else if (p->pair_xsep) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false, true>), grid, dim3(128), 0, st, a);
+            else if (abl == 1) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<1, false>), grid, dim3(128), 0, st, a);
+            else if (abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false>), grid, dim3(128), 0, st, a);
+#endif
+            else hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false>), grid, dim3(128), 0, st, a);
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
+        }
 #ifdef SXFIR_PROFILING
         if (p->t2_wpg) {
             // decim4_tile2_kernel: G workgroups of t2_wpg waves per channel, wave ww of workgroup b takes tiles

@@ -26,6 +26,11 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_ABLATE": "3"},
     {"SXFIR_TILE_VARIANT": "sg"},
     {"SXFIR_TILE_VARIANT": "sg4"},
+    {"SXFIR_TILE_VARIANT": "pair"},
+    {"SXFIR_TILE_VARIANT": "pair", "SXFIR_OVERSUB": "3"},
+    {"SXFIR_TILE_VARIANT": "pairx"},
+    {"SXFIR_TILE_VARIANT": "pairx", "SXFIR_OVERSUB": "5"},
+    {"SXFIR_TILE_VARIANT": "pair", "SXFIR_OVERSUB": "64", "SXFIR_SCHED": "2"},
 ] + [{"SXFIR_TILE_VARIANT": "t2:%d:%d" % (w, o), "SXFIR_OVERSUB": ov, "SXFIR_SCHED": sc}
      for (w, o, ov, sc) in [(1, 0, "16", "0"), (1, 1, "16", "0"), (1, 2, "64", "2"), (1, 3, "3", "0"), (1, 4, "2", "0"),
                             (1, 5, "16", "0"), (1, 6, "1", "2"), (1, 7, "16", "0"), (1, 9, "16", "0"), (1, 11, "7", "0"),
