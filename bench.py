@@ -237,7 +237,7 @@ def through_device():
     import numpy as np
     import sxxcvr_amd.soapy as SoapySDR
     res = {"note": "through SoapySX-style readStream/writeStream (host buffers, PCIe, pageable caller memory); "
-                   "API-parity figures, never part of value"}
+                   "API-parity figures (median call; 256-sample calls: mean), never part of value"}
     import sxxcvr_amd
     for blk, key, pin in ((256, "256_sample_calls", False), (65536, "65536_sample_calls", False),
                           (1 << 20, "1048576_sample_calls", False), (1 << 20, "1048576_sample_calls_registered_buffer", True)):
@@ -251,21 +251,24 @@ def through_device():
         if pin:
             sxxcvr_amd.pin_array(buf)                    # page-locked: the decimator stores straight into it
         try:
-            n = max(8, min(2000, (1 << 24) // blk))
-            dev.readStream(rx, [buf], blk)
-            t0 = time.perf_counter()
-            for _ in range(n):
-                r = dev.readStream(rx, [buf], blk)
-                if r.ret != blk:
-                    raise RuntimeError("readStream returned %d" % r.ret)
-            dt_rx = (time.perf_counter() - t0) / n
-            dev.writeStream(tx, [buf], blk)
-            t0 = time.perf_counter()
-            for _ in range(n):
-                r = dev.writeStream(tx, [buf], blk)
-                if r.ret != blk:
-                    raise RuntimeError("writeStream returned %d" % r.ret)
-            dt_tx = (time.perf_counter() - t0) / n
+            n = max(24, min(2000, (1 << 24) // blk))
+
+            def per_call(fn):
+                # median of the per-call times: a short loop's mean is at the mercy of one slow call
+                fn()
+                fn()
+                ts = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    r = fn()
+                    ts.append(time.perf_counter() - t0)
+                    if r.ret != blk:
+                        raise RuntimeError("stream call returned %d" % r.ret)
+                ts.sort()
+                return ts[len(ts) // 2] if blk >= 4096 else sum(ts) / len(ts)
+
+            dt_rx = per_call(lambda: dev.readStream(rx, [buf], blk))
+            dt_tx = per_call(lambda: dev.writeStream(tx, [buf], blk))
         finally:
             if pin:
                 sxxcvr_amd.unpin_array(buf)

@@ -179,6 +179,9 @@ int sxfir_event_create_timing(void **event);
 int sxfir_event_elapsed_ms(void *start, void *stop, float *ms);
 int sxfir_event_record(void *event, void *stream);
 int sxfir_event_sync(void *event);
+/* Work queued on `stream` after this call starts only when `event` (recorded on another stream) has fired: the
+ * GPU-side ordering between a compute stream and a copy stream, without the host waiting. */
+int sxfir_stream_wait_event(void *stream, void *event);
 
 /* Timed launches for bench.py: runs `iters` back-to-back decimate passes of
  * the same buffers on `stream` bracketed by hipEvents ON THAT STREAM and

@@ -92,6 +92,7 @@ def load_sxfir(profiling=False):
         "sxfir_event_elapsed_ms": (ci, [vp, vp, P(C.c_float)]),
         "sxfir_event_record": (ci, [vp, vp]),
         "sxfir_event_sync": (ci, [vp]),
+        "sxfir_stream_wait_event": (ci, [vp, vp]),
         "sxfir_memcpy_h2d": (ci, [vp, vp, sz, vp]),
         "sxfir_memcpy_d2h": (ci, [vp, vp, sz, vp]),
         "sxfir_stream_sync": (ci, [vp]),

@@ -8,8 +8,9 @@
 //            pinned host staging (zero copy) -> caller
 //   TxChain: caller -> pinned host staging, read in place by the polyphase
 //            FIR interpolator (HIP) -> DAC-rate ring in HBM (the synthetic sink)
-// The narrow side of either resampler is 1/ratio of the traffic, so it crosses
-// PCIe inside the kernel and the wide side never leaves HBM.
+// The narrow side of either resampler is 1/ratio of the traffic and is the only one that crosses PCIe: inside
+// the kernel for small passes (zero copy), as one DMA-engine copy next to the kernel for passes of a megabyte
+// and more; the wide side never leaves HBM.  Page-locked caller memory is used as it is (no staging copy).
 //
 // Both are batched and asynchronous, which is what a GPU behind a 256-sample
 // API needs: the RX side produces the stream in batches of thousands of
@@ -30,9 +31,12 @@
 #include <sxfir.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -45,28 +49,102 @@ inline void gpu_check(int rc, const char *what)
     if (rc != SXFIR_OK) throw std::runtime_error(std::string(what) + ": " + sxfir_last_error());
 }
 
-// memcpy of a large block by a few threads: one core moves ~12 GB/s out of write-combined-free pinned staging,
-// the GS/s block sizes of the wideband configurations want more
-inline void block_copy(void *dst, const void *src, size_t bytes)
-{
-    constexpr size_t kParallelFrom = size_t(4) << 20;
-    if (bytes < kParallelFrom) {
-        std::memcpy(dst, src, bytes);
-        return;
+// memcpy of large blocks by a few PERSISTENT threads: one core moves ~10 GB/s between pageable caller memory and
+// pinned staging, the GS/s block sizes of the wideband configurations want more, and starting threads per call
+// costs as much as copying a megabyte.  Four threads by default: 8 and 16 measured no faster on the boxes seen
+// (tools/devpath_probe.py; SX_COPY_THREADS overrides).  One pool per chain (RX and TX run on different application threads); the
+// workers are started by the first block that is large enough and sleep on a condition variable in between.
+class CopyPool {
+public:
+    static constexpr size_t kParallelFrom = size_t(1) << 20;   // smaller blocks: plain memcpy on the calling thread
+    static constexpr size_t kMinPiece = size_t(256) << 10;
+
+    explicit CopyPool(unsigned max_threads = 4) : stop_(false), remaining_(0)
+    {
+        unsigned n = std::thread::hardware_concurrency();
+        // SX_COPY_THREADS: upper bound of the threads one large copy is split over (1 = never start any)
+        if (const char *e = std::getenv("SX_COPY_THREADS")) {
+            const long v = std::strtol(e, nullptr, 10);
+            if (v >= 1 && v <= 64) max_threads = (unsigned)v;
+        }
+        nthreads_ = n < 2 ? 1 : (n > max_threads ? max_threads : n);
     }
-    unsigned n = std::thread::hardware_concurrency();
-    n = n < 2 ? 1 : (n > 8 ? 8 : n);
-    const size_t piece = ((bytes / n) + 4095) & ~size_t(4095);
-    std::vector<std::thread> workers;
-    for (unsigned i = 1; i < n; ++i) {
-        const size_t off = piece * i;
-        if (off >= bytes) break;
-        const size_t len = std::min(piece, bytes - off);
-        workers.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        work_.notify_all();
+        for (auto &w : workers_) w.join();
     }
-    std::memcpy(dst, src, std::min(piece, bytes));
-    for (auto &w : workers) w.join();
-}
+    CopyPool(const CopyPool &) = delete;
+    CopyPool &operator=(const CopyPool &) = delete;
+
+    unsigned threads() const { return nthreads_; }
+    size_t parallel_copies() const { return parallel_copies_; }
+
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        if (bytes < kParallelFrom || nthreads_ < 2) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        size_t parts = std::min<size_t>(nthreads_, bytes / kMinPiece);
+        const size_t piece = ((bytes / parts) + 4095) & ~size_t(4095);
+        if (workers_.empty()) {
+            jobs_.resize(nthreads_ - 1);
+            for (unsigned i = 0; i + 1 < nthreads_; ++i) workers_.emplace_back([this, i] { serve(i); });
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t i = 1; i < parts; ++i) {
+                const size_t off = piece * i;
+                if (off >= bytes) break;
+                jobs_[i - 1] = Job{static_cast<char *>(dst) + off, static_cast<const char *>(src) + off,
+                                   std::min(piece, bytes - off), true};
+                ++remaining_;
+            }
+        }
+        work_.notify_all();
+        std::memcpy(dst, src, std::min(piece, bytes));      // the caller takes the first piece
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return remaining_ == 0; });
+        ++parallel_copies_;
+    }
+
+private:
+    struct Job {
+        char *dst = nullptr;
+        const char *src = nullptr;
+        size_t bytes = 0;
+        bool pending = false;
+    };
+
+    void serve(unsigned i)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            work_.wait(lk, [&] { return stop_ || jobs_[i].pending; });
+            if (stop_) return;
+            const Job j = jobs_[i];
+            jobs_[i].pending = false;
+            lk.unlock();
+            std::memcpy(j.dst, j.src, j.bytes);
+            lk.lock();
+            if (--remaining_ == 0) done_.notify_one();
+        }
+    }
+
+    unsigned nthreads_;
+    std::mutex m_;
+    std::condition_variable work_, done_;
+    std::vector<std::thread> workers_;
+    std::vector<Job> jobs_;
+    bool stop_;
+    size_t remaining_;
+    size_t parallel_copies_ = 0;
+};
 
 class DeviceBuffer {
 public:
@@ -143,6 +221,10 @@ public:
     static constexpr size_t kMaxBatchCap = 1u << 20;   // ... at most (large reads), and never more than
     static constexpr size_t kMaxSource = 1u << 24;     // this many wideband samples per pass over all channels
     static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long go straight into page-locked caller memory
+    // A pass whose output is at least this large lands in HBM and crosses PCIe as ONE DMA-engine copy behind the
+    // kernel (57 GB/s on the boxes measured); smaller ones are stored across PCIe by the kernel itself (no copy
+    // to queue, lowest latency, ~33 GB/s).
+    static constexpr size_t kSdmaFromBytes = size_t(1) << 20;
 
     // wire_s32: the synthetic ADC stream is S32_LE I2S words and the decimator converts them on
     // load (the reference's wire format, SoapySX.cpp:103-112); otherwise CF32 end to end.
@@ -153,14 +235,17 @@ public:
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
         stream_.reset(new GpuStream());
+        copy_.reset(new GpuStream());
         std::vector<float> taps((size_t)ntaps_);
         gpu_check(sxfir_design_lowpass(ntaps_, decim_, 8.0, 1.0, taps.data()), "sxfir_design_lowpass");
         gpu_check(sxfir_create(&plan_, SXFIR_DECIMATE, taps.data(), ntaps_, decim_, nchan_, fmt_, gpu_), "sxfir_create(rx)");
         max_batch_ = kMinBatch;
         while (max_batch_ < kMaxBatchCap && 2 * max_batch_ * (size_t)decim_ * (size_t)nchan_ <= kMaxSource) max_batch_ *= 2;
         for (int k = 0; k < 2; ++k) {
-            done_[k] = nullptr;
+            done_[k] = ran_[k] = nullptr;
+            out_used_[k] = false;
             gpu_check(sxfir_event_create(&done_[k]), "sxfir_event_create");
+            gpu_check(sxfir_event_create(&ran_[k]), "sxfir_event_create");
         }
         direct_done_ = nullptr;
         gpu_check(sxfir_event_create(&direct_done_), "sxfir_event_create");
@@ -168,7 +253,11 @@ public:
     ~RxChain()
     {
         sxfir_stream_sync(stream_->get());
-        for (int k = 0; k < 2; ++k) sxfir_event_destroy(done_[k]);
+        sxfir_stream_sync(copy_->get());
+        for (int k = 0; k < 2; ++k) {
+            sxfir_event_destroy(done_[k]);
+            sxfir_event_destroy(ran_[k]);
+        }
         sxfir_event_destroy(direct_done_);
         sxfir_destroy(plan_);
     }
@@ -214,14 +303,31 @@ public:
             done = drain_slots(pos, n, dsts);
             int64_t p = pos + (int64_t)done;
             void *st = stream_->get();
+            // passes of a quarter of the read (a megabyte at least): the DMA copy of one runs beside the kernels of the next
+            size_t chunk = max_batch_;
+            while (chunk / 2 >= (n + 3) / 4 && 8 * (chunk / 2) * (size_t)nchan_ >= kSdmaFromBytes) chunk /= 2;
+            int k = 0;
+            bool copies[2] = {false, false};
             while (done < n) {
-                const size_t m = std::min(n - done, max_batch_);
-                run(p, m, direct + 2 * done, direct_stride, st);
+                const size_t m = std::min(n - done, chunk);
+                if (8 * m * (size_t)nchan_ >= kSdmaFromBytes) {
+                    run_to_hbm(k, p, m, st);
+                    for (int c = 0; c < nchan_; ++c)
+                        gpu_check(sxfir_memcpy_d2h(dsts[c] + 2 * done, out_[k].at(8 * (size_t)c * m), 8 * m, copy_->get()),
+                                  "sxfir_memcpy_d2h");
+                    gpu_check(sxfir_event_record(done_[k], copy_->get()), "sxfir_event_record");
+                    copies[k] = true;
+                    k ^= 1;
+                } else {
+                    run(p, m, direct + 2 * done, direct_stride, st);
+                }
                 p += (int64_t)m;
                 done += m;
             }
             gpu_check(sxfir_event_record(direct_done_, st), "sxfir_event_record");
             gpu_check(sxfir_event_sync(direct_done_), "sxfir_event_sync");
+            for (int q = 0; q < 2; ++q)
+                if (copies[q]) gpu_check(sxfir_event_sync(done_[q]), "sxfir_event_sync");
             direct_samples_ += (int64_t)n;
             next_ = pos + (int64_t)n;
             // keep the next batches in flight for whoever reads next
@@ -248,7 +354,7 @@ public:
             const size_t off = (size_t)(p - s.pos);
             const size_t m = std::min(n - done, s.n - off);
             for (int c = 0; c < nchan_; ++c)
-                block_copy(dsts[c] + 2 * done, stage_[cur_].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+                pool_.copy(dsts[c] + 2 * done, stage_[cur_].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
             done += m;
         }
         next_ = pos + (int64_t)n;
@@ -303,7 +409,7 @@ private:
                 const size_t off = (size_t)(p - s.pos);
                 const size_t m = std::min(n - done, s.n - off);
                 for (int c = 0; c < nchan_; ++c)
-                    block_copy(dsts[c] + 2 * done, stage_[k].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+                    pool_.copy(dsts[c] + 2 * done, stage_[k].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
                 done += m;
             }
         }
@@ -333,15 +439,46 @@ private:
         if (n_out != m) throw std::runtime_error("rx chain: decimator produced an unexpected block size");
     }
 
-    // stream samples [pos, pos+m) of all channels -> staging slot k, asynchronously on the chain's stream
+    // a DMA copy queued for buffer pair k (possibly of a batch that a jump dropped) comes before anything new
+    // that writes out_[k] or stage_[k]: ordered on the GPU, the host does not wait
+    void settle_copy(int k, void *st)
+    {
+        if (!out_used_[k]) return;
+        gpu_check(sxfir_stream_wait_event(st, done_[k]), "sxfir_stream_wait_event");
+        out_used_[k] = false;
+    }
+
+    // stream samples [pos, pos+m) of all channels -> out_[k] in HBM (channel stride m); the copy stream then waits
+    // for that pass, so that the caller can queue the block's DMA copies on it
+    void run_to_hbm(int k, int64_t pos, size_t m, void *st)
+    {
+        grow(out_[k], 8 * m * (size_t)nchan_);
+        settle_copy(k, st);
+        run(pos, m, static_cast<float *>(out_[k].get()), m, st);
+        gpu_check(sxfir_event_record(ran_[k], st), "sxfir_event_record");
+        gpu_check(sxfir_stream_wait_event(copy_->get(), ran_[k]), "sxfir_stream_wait_event");
+        out_used_[k] = true;
+    }
+
+    // stream samples [pos, pos+m) of all channels -> staging slot k, asynchronously on the chain's streams
     void launch(int k, int64_t pos, size_t m)
     {
         void *st = stream_->get();
         grow(stage_[k], 8 * m * (size_t)nchan_);
-        // the decimator stores straight into the pinned staging buffer (device-visible host memory): the
-        // outputs are 1/decim of the traffic and cross PCIe as they are produced, no separate D2H copy
-        run(pos, m, stage_[k].floats(), m, st);
-        gpu_check(sxfir_event_record(done_[k], st), "sxfir_event_record");
+        const size_t bytes = 8 * m * (size_t)nchan_;
+        if (bytes >= kSdmaFromBytes) {
+            // large batch: HBM, then one DMA-engine copy into the pinned staging buffer on the copy stream, beside
+            // the kernels of the batch after it
+            run_to_hbm(k, pos, m, st);
+            gpu_check(sxfir_memcpy_d2h(stage_[k].floats(), out_[k].get(), bytes, copy_->get()), "sxfir_memcpy_d2h");
+            gpu_check(sxfir_event_record(done_[k], copy_->get()), "sxfir_event_record");
+        } else {
+            // the decimator stores straight into the pinned staging buffer (device-visible host memory): the
+            // outputs are 1/decim of the traffic and cross PCIe as they are produced, no separate D2H copy
+            settle_copy(k, st);
+            run(pos, m, stage_[k].floats(), m, st);
+            gpu_check(sxfir_event_record(done_[k], st), "sxfir_event_record");
+        }
         slot_[k].pos = pos;
         slot_[k].n = m;
         slot_[k].ready = false;
@@ -353,6 +490,7 @@ private:
     {
         if (b.fits(bytes)) return;
         stream_->sync();
+        copy_->sync();
         b.reserve(bytes);
     }
 
@@ -405,9 +543,14 @@ private:
     sxfir_plan *plan_;
     std::unique_ptr<GpuStream> stream_;
     DeviceBuffer in_, scratch_;      // wideband source block; outputs of the priming pass (discarded)
+    std::unique_ptr<GpuStream> copy_;   // DMA copies of large passes, beside the kernels on stream_
+    DeviceBuffer out_[2];            // decimated block of a large pass, before its DMA copy to the host
+    void *ran_[2];                   // recorded behind the pass that filled out_[k]
+    bool out_used_[2];               // a copy out of out_[k] (recorded in done_[k] on the copy stream) may be in flight
+    CopyPool pool_;
     PinnedBuffer stage_[2];
     Slot slot_[2];
-    void *done_[2];                  // recorded behind each slot's pass
+    void *done_[2];                  // recorded behind each slot's pass (its DMA copy, for a large one)
     void *direct_done_;
     int64_t next_;
     int cur_;
@@ -417,9 +560,15 @@ private:
 
 class TxChain {
 public:
-    static constexpr size_t kSlotFrames = 1u << 15;    // stream samples per channel and pinned slot
+    static constexpr size_t kMinSlotFrames = 1u << 15; // stream samples per channel and pinned slot: to begin with,
+    static constexpr size_t kMaxSlotBytes = size_t(4) << 20;   // ... and grown for large writes up to this many bytes over all channels
     static constexpr size_t kFlushFrames = 4096;       // small writes are gathered up to this before a GPU pass
     static constexpr int kSlots = 4;
+    // A pass whose input is at least this large crosses PCIe as DMA-engine copies into HBM before the kernels run
+    // (57 GB/s on the boxes measured, and the interpolator and the keying count both read HBM); smaller ones are
+    // read in place from the pinned slot by the kernels themselves (nothing to queue, lowest latency).
+    static constexpr size_t kH2dFromBytes = size_t(1) << 20;
+    static constexpr size_t kDirectFrom = 1u << 15;    // writes at least this long are taken straight from page-locked caller memory
 
     // wire_s32: the DAC-rate sink holds S32_LE I2S words with the transmitter-keying bits
     // (convert_tx_buffer, SoapySX.cpp:116-137, fused into the interpolator's store).
@@ -427,8 +576,12 @@ public:
         : gpu_(gpu), interp_(interp), ntaps_(interp * taps_per_phase), nchan_(nchan), plan_(nullptr),
           ring_len_(ring_frames * (size_t)interp), next_(0), accepted_(0), written_(0), slot_(0), pend_(0)
     {
+        slot_frames_ = kMinSlotFrames;
+        max_slot_frames_ = kMinSlotFrames;
+        while (2 * max_slot_frames_ * 8 * (size_t)nchan_ <= kMaxSlotBytes) max_slot_frames_ *= 2;
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
         stream_.reset(new GpuStream());
+        copy_.reset(new GpuStream());
         std::vector<float> taps((size_t)ntaps_);
         // gain = interp: unity pass-band gain after zero stuffing
         gpu_check(sxfir_design_lowpass(ntaps_, interp_, 8.0, (double)interp_, taps.data()), "sxfir_design_lowpass");
@@ -436,7 +589,7 @@ public:
                                wire_s32 ? SXFIR_S32 : SXFIR_CF32, gpu_),
                   "sxfir_create(tx)");
         ring_.reserve(8 * ring_len_ * (size_t)nchan_);
-        stage_.reserve(8 * kSlotFrames * (size_t)nchan_ * kSlots);
+        stage_.reserve(8 * slot_frames_ * (size_t)nchan_ * kSlots);
         keyed_.reserve(64);
         zero_keyed();
         for (int k = 0; k < kSlots; ++k) {
@@ -444,11 +597,25 @@ public:
             done_[k] = nullptr;
             gpu_check(sxfir_event_create(&done_[k]), "sxfir_event_create");
         }
+        direct_done_ = nullptr;
+        gpu_check(sxfir_event_create(&direct_done_), "sxfir_event_create");
+        for (int j = 0; j < 2; ++j) {
+            copied_[j] = used_[j] = nullptr;
+            in_used_[j] = false;
+            gpu_check(sxfir_event_create(&copied_[j]), "sxfir_event_create");
+            gpu_check(sxfir_event_create(&used_[j]), "sxfir_event_create");
+        }
     }
     ~TxChain()
     {
         sxfir_stream_sync(stream_->get());
+        sxfir_stream_sync(copy_->get());
         for (int k = 0; k < kSlots; ++k) sxfir_event_destroy(done_[k]);
+        sxfir_event_destroy(direct_done_);
+        for (int j = 0; j < 2; ++j) {
+            sxfir_event_destroy(copied_[j]);
+            sxfir_event_destroy(used_[j]);
+        }
         sxfir_destroy(plan_);
     }
     TxChain(const TxChain &) = delete;
@@ -457,6 +624,8 @@ public:
     int interp() const { return interp_; }
     int channels() const { return nchan_; }
     int64_t written() const { return written_; }
+    int64_t direct_samples() const { return direct_samples_; }
+    size_t slot_frames() const { return slot_frames_; }
     void set_threshold2(float thr2)
     {
         thr2_ = thr2;
@@ -496,7 +665,8 @@ public:
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
         if (pos < accepted_) throw std::runtime_error("tx chain: position moved backwards");
         feed(nullptr, (size_t)(pos - accepted_));
-        feed(srcs, n);
+        if (n >= kDirectFrom && device_visible(srcs, n)) direct(srcs, n);
+        else feed(srcs, n);
         written_ += (int64_t)n;
     }
 
@@ -525,16 +695,23 @@ public:
 private:
     void drain()
     {
+        copy_->sync();
         stream_->sync();
         for (int k = 0; k < kSlots; ++k) busy_[k] = false;
     }
 
     // n stream samples per channel (srcs == nullptr: silence) are appended to the current pinned slot
-    // (channel c at c*kSlotFrames); the GPU pass over a slot is issued once kFlushFrames have gathered
+    // (channel c at c*slot_frames_); the GPU pass over a slot is issued once kFlushFrames have gathered
     // or the slot is full, and is never waited for here (write-behind: the sink is only observable
     // through capture(), which flushes).
     void feed(const float *const *srcs, size_t n)
     {
+        if (srcs && n >= 2 * slot_frames_ && slot_frames_ < max_slot_frames_) {
+            // large writes: larger slots, so that a write is a few multi-threaded copies and a few GPU passes
+            size_t f = slot_frames_;
+            while (f < max_slot_frames_ && 2 * f <= n) f *= 2;
+            resize_slots(f);
+        }
         size_t done = 0;
         while (done < n) {
             if (pend_ == 0 && busy_[slot_]) {
@@ -542,11 +719,11 @@ private:
                 gpu_check(sxfir_event_sync(done_[slot_]), "sxfir_event_sync");
                 busy_[slot_] = false;
             }
-            const size_t m = std::min(kSlotFrames - pend_, n - done);
-            float *host = stage_.floats() + 2 * kSlotFrames * (size_t)nchan_ * (size_t)slot_;
+            const size_t m = std::min(slot_frames_ - pend_, n - done);
+            float *host = stage_.floats() + 2 * slot_frames_ * (size_t)nchan_ * (size_t)slot_;
             for (int c = 0; c < nchan_; ++c) {
-                float *dst = host + 2 * ((size_t)c * kSlotFrames + pend_);
-                if (srcs) block_copy(dst, srcs[c] + 2 * done, 8 * m);
+                float *dst = host + 2 * ((size_t)c * slot_frames_ + pend_);
+                if (srcs) pool_.copy(dst, srcs[c] + 2 * done, 8 * m);
                 else std::memset(dst, 0, 8 * m);
             }
             if (srcs) {
@@ -561,34 +738,129 @@ private:
         }
     }
 
-    // pass the gathered samples of the current slot through the interpolator into the sink ring at ring
-    // position next_*interp (in two passes where the ring wraps), asynchronously
+    // pass the gathered samples of the current slot through the interpolator into the sink ring, asynchronously
     void flush()
     {
         if (pend_ == 0) return;
         void *st = stream_->get();
-        const size_t slot_off = kSlotFrames * (size_t)nchan_ * (size_t)slot_;
-        // the interpolator reads its input straight from the pinned slot (device-visible host memory): the
-        // input is 1/interp of the traffic and crosses PCIe as the kernel fetches it, no separate H2D copy
+        const size_t slot_off = slot_frames_ * (size_t)nchan_ * (size_t)slot_;
         const char *host = reinterpret_cast<const char *>(stage_.floats() + 2 * slot_off);
+        if (8 * pend_ * (size_t)nchan_ >= kH2dFromBytes) {
+            // large pass: DMA-engine copies into HBM on the copy stream, beside the kernels of the pass before; the
+            // slot is free again as soon as they are through
+            void *cst = begin_copy();
+            for (int c = 0; c < nchan_; ++c)
+                gpu_check(sxfir_memcpy_h2d(in_dev_[cur_in_].at(8 * (size_t)c * max_slot_frames_),
+                                           host + 8 * (size_t)c * slot_frames_, 8 * pend_, cst),
+                          "sxfir_memcpy_h2d");
+            gpu_check(sxfir_event_record(done_[slot_], cst), "sxfir_event_record");
+            pass_copied(pend_, st);
+        } else {
+            // the interpolator reads its input straight from the pinned slot (device-visible host memory): the
+            // input is 1/interp of the traffic and crosses PCIe as the kernel fetches it, no separate H2D copy
+            pass(host, slot_frames_, pend_, st);
+            gpu_check(sxfir_event_record(done_[slot_], st), "sxfir_event_record");
+        }
+        busy_[slot_] = true;
+        slot_ = (slot_ + 1) % kSlots;
+        pend_ = 0;
+    }
+
+    // `frames` stream samples per channel at `base` (device-visible, channel stride `stride` samples) -> the
+    // interpolator -> sink ring at ring position next_*interp (in two passes where the ring wraps); the ranges of
+    // data_ (application data, relative to base) take part in the keying count
+    void pass(const char *base, size_t stride, size_t frames, void *st)
+    {
         size_t done = 0;
-        while (done < pend_) {
+        while (done < frames) {
             const size_t off = (size_t)((next_ * interp_) % (int64_t)ring_len_);
-            const size_t m = std::min(pend_ - done, (ring_len_ - off) / (size_t)interp_);
+            const size_t m = std::min(frames - done, (ring_len_ - off) / (size_t)interp_);
             size_t n_out = 0;
-            gpu_check(sxfir_interpolate(plan_, host + 8 * done, m, kSlotFrames, ring_.at(8 * off), ring_len_, &n_out, st),
+            gpu_check(sxfir_interpolate(plan_, base + 8 * done, m, stride, ring_.at(8 * off), ring_len_, &n_out, st),
                       "sxfir_interpolate");
             next_ += (int64_t)m;
             done += m;
         }
         for (const auto &r : data_)
-            gpu_check(sxfir_count_keyed(reinterpret_cast<const float *>(host + 8 * r.first), r.second, thr2_, keyed_counter(), st),
+            gpu_check(sxfir_count_keyed(reinterpret_cast<const float *>(base + 8 * r.first), r.second, thr2_, keyed_counter(), st),
                       "sxfir_count_keyed");
         data_.clear();
-        gpu_check(sxfir_event_record(done_[slot_], st), "sxfir_event_record");
-        busy_[slot_] = true;
-        slot_ = (slot_ + 1) % kSlots;
-        pend_ = 0;
+    }
+
+    // Are the caller's blocks page-locked (pinned / registered with sxfir_host_register)?  Then the DMA engines
+    // can take them as they are.
+    bool device_visible(const float *const *srcs, size_t n) const
+    {
+        for (int c = 0; c < nchan_; ++c) {
+            void *d = nullptr;
+            if (sxfir_host_device_pointer(srcs[c], 8 * n, &d) != SXFIR_OK) return false;
+        }
+        return true;
+    }
+
+    // A large write from page-locked caller memory: no staging copy.  The blocks go to HBM by DMA and through the
+    // kernels from there; the call returns when the last copy has read the caller's memory (the kernels run on).
+    void direct(const float *const *srcs, size_t n)
+    {
+        flush();                                           // what was gathered before comes first
+        void *st = stream_->get();
+        size_t done = 0;
+        while (done < n) {
+            const size_t m = std::min(n - done, max_slot_frames_);
+            void *cst = begin_copy();
+            for (int c = 0; c < nchan_; ++c)
+                gpu_check(sxfir_memcpy_h2d(in_dev_[cur_in_].at(8 * (size_t)c * max_slot_frames_), srcs[c] + 2 * done, 8 * m, cst),
+                          "sxfir_memcpy_h2d");
+            if (done + m == n) gpu_check(sxfir_event_record(direct_done_, cst), "sxfir_event_record");
+            data_.emplace_back(0, m);
+            pass_copied(m, st);
+            done += m;
+        }
+        gpu_check(sxfir_event_sync(direct_done_), "sxfir_event_sync");
+        accepted_ += (int64_t)n;
+        direct_samples_ += (int64_t)n;
+    }
+
+    // The next input block in HBM (two alternate): it may be filled once the kernels that read its last contents
+    // are through.  Returns the copy stream.
+    void *begin_copy()
+    {
+        grow(in_dev_[cur_in_], 8 * max_slot_frames_ * (size_t)nchan_);
+        // (the HOST waits here, not the copy stream: the application thread is then never more than two passes
+        // ahead of the GPU.  With the wait queued on the copy stream instead, a caller that runs ahead makes
+        // hipMemcpyAsync itself block for 7-8 ms now and then on ROCm 7.2 -- measured, tools/devpath_probe.py.)
+        if (in_used_[cur_in_]) gpu_check(sxfir_event_sync(used_[cur_in_]), "sxfir_event_sync");
+        return copy_->get();
+    }
+
+    // ... and the kernels over it, once the copies queued since begin_copy() are through
+    void pass_copied(size_t frames, void *st)
+    {
+        gpu_check(sxfir_event_record(copied_[cur_in_], copy_->get()), "sxfir_event_record");
+        gpu_check(sxfir_stream_wait_event(st, copied_[cur_in_]), "sxfir_stream_wait_event");
+        pass(in_dev_[cur_in_].at(0), max_slot_frames_, frames, st);
+        gpu_check(sxfir_event_record(used_[cur_in_], st), "sxfir_event_record");
+        in_used_[cur_in_] = true;
+        cur_in_ ^= 1;
+    }
+
+    void resize_slots(size_t frames)
+    {
+        flush();
+        drain();
+        slot_frames_ = frames;
+        stage_.reserve(8 * slot_frames_ * (size_t)nchan_ * kSlots);
+        slot_ = 0;
+    }
+
+    // a buffer is replaced by a larger one only when nothing queued on the chain's stream can still use it
+    template <class Buffer>
+    void grow(Buffer &b, size_t bytes)
+    {
+        if (b.fits(bytes)) return;
+        copy_->sync();
+        stream_->sync();
+        b.reserve(bytes);
     }
 
     unsigned long long *keyed_counter() const { return static_cast<unsigned long long *>(keyed_.get()); }
@@ -605,6 +877,15 @@ private:
     std::unique_ptr<GpuStream> stream_;
     DeviceBuffer ring_;
     PinnedBuffer stage_;
+    std::unique_ptr<GpuStream> copy_;                     // DMA copies of large passes, beside the kernels on stream_
+    DeviceBuffer in_dev_[2];                              // input blocks of large passes (DMA-copied from the slot or the caller)
+    void *copied_[2], *used_[2];                          // in_dev_[j] filled (copy stream) / read by its kernels (stream_)
+    bool in_used_[2];
+    int cur_in_ = 0;
+    CopyPool pool_;
+    size_t slot_frames_, max_slot_frames_;
+    void *direct_done_;
+    int64_t direct_samples_ = 0;                          // samples taken straight from page-locked caller memory
     DeviceBuffer keyed_;                                  // the keying counter (device memory, read back on demand)
     float thr2_ = 1.0e-6f;
     std::vector<std::pair<size_t, size_t>> data_;         // (offset, length) of application data in the current slot

@@ -108,7 +108,11 @@ private:
         }
         if (tx) {
             tx_chain.reset();
-            tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, 65536, nchan, wire_s32));
+            // the synthetic sink retains the last ring_frames stream samples per channel at the DAC rate: 2^20 where
+            // that stays within 256 MiB of HBM (a large write then is one or two passes, not one per ring wrap)
+            size_t ring_frames = size_t(1) << 20;
+            while (ring_frames > 65536 && 8 * ring_frames * (size_t)interp * (size_t)nchan > (size_t(256) << 20)) ring_frames /= 2;
+            tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, ring_frames, nchan, wire_s32));
             tx_chain->set_threshold2(tx_threshold2);
         }
     }
@@ -589,6 +593,7 @@ public:
             return std::to_string(tx_chain->keyed_samples());
         }
         if (key == "RX_DIRECT_SAMPLES") return std::to_string(rx_chain->direct_samples());
+        if (key == "TX_DIRECT_SAMPLES") return std::to_string(tx_chain->direct_samples());
         if (key == "RX_DECIM") return std::to_string(decim);
         if (key == "TX_INTERP") return std::to_string(interp);
         if (key == "RX_NTAPS") return std::to_string(rx_chain->ntaps());

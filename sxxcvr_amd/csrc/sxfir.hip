@@ -1349,4 +1349,11 @@ int sxfir_event_sync(void *event)
     return SXFIR_OK;
 }
 
+int sxfir_stream_wait_event(void *stream, void *event)
+{
+    if (!event) return fail(SXFIR_EINVAL, "NULL event");
+    HIPCHECK(hipStreamWaitEvent(S(stream), (hipEvent_t)event, 0));
+    return SXFIR_OK;
+}
+
 }  // extern "C"

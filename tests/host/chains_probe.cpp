@@ -92,6 +92,87 @@ static void rx_test()
     }
 }
 
+// Passes of a megabyte and more: the decimated block lands in HBM and is DMA-copied to the host (staged batches
+// and stores into page-locked caller memory alike); the copies to pageable memory are split over the copy pool.
+static void rx_large_test()
+{
+    const int D = 4, NT = 128;
+    const uint64_t seed = 0x51255;
+    const size_t total = 2600000;
+    std::vector<float> taps(NT);
+    sxo_design_lowpass(NT, D, 8.0, 1.0, taps.data());
+    std::vector<float> ref(2 * total);
+    {
+        std::vector<float> x(2 * total * D);
+        sxo_synth_iq(seed, 0, 0, total * D, x.data());
+        sxo_decim_f32(taps.data(), NT, D, 2, 4, x.data(), total * D, 0, total, ref.data());
+    }
+    sx::RxChain chain(0, D, 32, seed, 0, 1, false);
+    int64_t pos = 0;
+    std::vector<float> buf;
+    for (size_t n : {(size_t)300000, (size_t)300000, (size_t)256, (size_t)524288}) {
+        buf.assign(2 * n, -1.0f);
+        float *dsts[1] = {buf.data()};
+        chain.produce(pos, n, dsts);
+        check("rx_large_read", buf.data(), ref.data() + 2 * pos, 2 * n);
+        pos += (int64_t)n;
+    }
+    void *blk = nullptr;
+    const size_t n = 200000;
+    sxfir_host_alloc(&blk, 8 * n);
+    float *dsts[1] = {static_cast<float *>(blk)};
+    pos += 1000;                                           // a jump: nothing of this read is staged
+    std::memset(blk, 0xff, 8 * n);
+    chain.produce(pos, n, dsts);
+    check("rx_large_direct", dsts[0], ref.data() + 2 * pos, 2 * n);
+    std::printf("rx_large_direct_samples %lld\n", (long long)chain.direct_samples());
+    sxfir_host_free(blk);
+}
+
+// Large writes: the slots grow, their samples reach HBM by DMA copies; page-locked caller memory is taken as it is.
+static void tx_large_test()
+{
+    const int L = 8, NT = 256;
+    const size_t ring_frames = 1 << 16;
+    std::vector<float> taps(NT);
+    sxo_design_lowpass(NT, L, 8.0, (double)L, taps.data());
+    sx::TxChain chain(0, L, 32, ring_frames, 1, false);
+    chain.set_threshold2(0.5f);
+    const size_t total = 900000;
+    std::vector<float> stream(2 * total, 0.0f);
+    sxo_synth_iq(123, 3, 0, total, stream.data());
+    // a gap of silence in the middle (a timed write further on)
+    std::memset(stream.data() + 2 * 600100, 0, 8 * 900);
+    long long want_keyed = 0;
+    auto count = [&](size_t from, size_t n) {
+        for (size_t i = from; i < from + n; ++i)
+            want_keyed += (stream[2 * i] * stream[2 * i] + stream[2 * i + 1] * stream[2 * i + 1] >= 0.5f) ? 1 : 0;
+    };
+    const float *srcs[1];
+    srcs[0] = stream.data();               chain.consume(0, 300, srcs);          count(0, 300);
+    srcs[0] = stream.data() + 2 * 300;     chain.consume(300, 299800, srcs);     count(300, 299800);      // pageable, large
+    std::printf("tx_large_slot_frames %zu\n", chain.slot_frames());
+    srcs[0] = stream.data() + 2 * 300100;  chain.consume(300100, 300000, srcs);  count(300100, 300000);
+    void *blk = nullptr;
+    const size_t nd = 150000;
+    sxfir_host_alloc(&blk, 8 * nd);
+    std::memcpy(blk, stream.data() + 2 * 601000, 8 * nd);
+    srcs[0] = static_cast<const float *>(blk);
+    chain.consume(601000, nd, srcs);                                              // after the gap, from page-locked memory
+    count(601000, nd);
+    std::memset(blk, 0x55, 8 * nd);                        // the call has returned: the memory is the caller's again
+    std::printf("tx_large_direct_samples %lld\n", (long long)chain.direct_samples());
+    srcs[0] = stream.data() + 2 * 751000;  chain.consume(751000, 149000, srcs);  count(751000, 149000);
+    std::printf("tx_large_keyed %lld want %lld\n", (long long)chain.keyed_samples(), want_keyed);
+    bad += chain.keyed_samples() != want_keyed;
+    std::vector<float> want(2 * total * L), got(2 * ring_frames * L);
+    sxo_interp_f32(taps.data(), NT, L, 2, stream.data(), total, 0, total * L, want.data());
+    const int64_t from = (int64_t)total - (int64_t)ring_frames;
+    chain.capture(from * L, ring_frames * L, got.data(), 0);
+    check("tx_large_sink", got.data(), want.data() + 2 * from * L, 2 * ring_frames * L);
+    sxfir_host_free(blk);
+}
+
 static void tx_test()
 {
     const int L = 8, NT = 256, NCH = 2;
@@ -171,6 +252,8 @@ int main()
 {
     rx_test();
     tx_test();
+    rx_large_test();
+    tx_large_test();
     std::printf("bad %d\n", bad);
     return bad ? 1 : 0;
 }

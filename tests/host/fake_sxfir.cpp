@@ -70,6 +70,7 @@ int sxfir_event_create(void **event) { *event = (void *)0x2; return SXFIR_OK; }
 int sxfir_event_destroy(void *) { return SXFIR_OK; }
 int sxfir_event_record(void *, void *) { return SXFIR_OK; }
 int sxfir_event_sync(void *) { return SXFIR_OK; }
+int sxfir_stream_wait_event(void *, void *) { return SXFIR_OK; }
 int sxfir_memcpy_h2d(void *dst, const void *src, size_t bytes, void *) { std::memcpy(dst, src, bytes); return SXFIR_OK; }
 int sxfir_memcpy_d2h(void *dst, const void *src, size_t bytes, void *) { std::memcpy(dst, src, bytes); return SXFIR_OK; }
 

@@ -633,6 +633,61 @@ def test_large_reads_into_registered_memory_skip_the_staging_copy(oracle):
     dev.closeStream(rx)
 
 
+def test_megabyte_blocks_cross_pcie_as_dma_copies_beside_the_kernels(oracle):
+    """Reads and writes of 2^19 samples (4 MiB): the decimated block lands in HBM and a DMA-engine copy on a second
+    stream takes it to the host while the next pass runs (RX: staged batches and page-locked caller memory alike);
+    a written block is copied into grown pinned slots by the copy pool, or taken from page-locked memory as it
+    is, and reaches HBM by DMA copies before the interpolator and the keying count read it.  Every sample is
+    compared with the oracle, on both sides, with small calls in between."""
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536"})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536", "threshold": "0.5"})
+    dev.activateStream(rx)
+    n = 1 << 19
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    total = 4 * n + 1300
+    ref = oracle.decim_f32(h, 4, oracle.synth_iq_mt(SEED, 0, 0, 4 * total, 8), 2, 4, threads=8)
+    pinned = sxxcvr_amd.pin_array(np.zeros(n, dtype=np.complex64))
+    try:
+        pos = 0
+        for what, m in (("small", 1000), ("registered", n), ("pageable", n), ("pageable", n), ("small", 300), ("registered", n)):
+            buf = pinned if what == "registered" else np.zeros(m, dtype=np.complex64)
+            buf[:] = 0
+            assert dev.readStream(rx, [buf], m).ret == m
+            assert_bit_exact(buf[:m], ref[pos:pos + m], "%s read of %d at %d" % (what, m, pos))
+            pos += m
+        assert int(dev.readSetting("RX_DIRECT_SAMPLES")) >= n
+        dev.deactivateStream(rx)
+
+        dev.activateStream(tx)
+        rng = np.random.default_rng(11)
+        stream = np.zeros(4 * n, dtype=np.complex64)
+        keyed = 0
+        end = 0
+        for what, m in (("small", 700), ("pageable", n), ("registered", n), ("small", 256), ("pageable", n // 2)):
+            x = (rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(np.complex64)
+            f = x.view(np.float32).reshape(-1, 2)
+            keyed += int(np.count_nonzero(f[:, 0] * f[:, 0] + f[:, 1] * f[:, 1] >= np.float32(0.25)))
+            src = x
+            if what == "registered":
+                pinned[:m] = x
+                src = pinned
+            assert dev.writeStream(tx, [src], m).ret == m
+            if what == "registered":
+                pinned[:m] = 0                               # the call has returned: the memory is the caller's again
+            end = int(dev.readSetting("TX_POSITION"))
+            stream[end - m:end] = x
+        assert int(dev.readSetting("TX_DIRECT_SAMPLES")) == n
+        assert int(dev.readSetting("TX_PTT_SAMPLES")) == keyed and keyed > 0
+        L = int(dev.readSetting("TX_INTERP"))
+        want = tx_reference(oracle, L, stream[:end])
+        tail = 1 << 19                                        # stream samples of the sink's tail to compare
+        got = dev.txCapture((end - tail) * L, tail * L)
+        assert_bit_exact(got, want[(end - tail) * L:], "dac stream tail")
+    finally:
+        sxxcvr_amd.unpin_array(pinned)
+
+
 def test_keying_count_on_the_gpu_matches_the_reference_rule(oracle):
     """TX_PTT_SAMPLES: the number of written samples whose squared magnitude reaches threshold^2 (the PTT bit of
     convert_tx_buffer, SX.cpp:126-135), counted by the GPU as the staged blocks pass; silence from timed gaps
