@@ -57,7 +57,6 @@ inline void gpu_check(int rc, const char *what)
 class CopyPool {
 public:
     static constexpr size_t kParallelFrom = size_t(1) << 20;   // smaller blocks: plain memcpy on the calling thread
-    static constexpr size_t kMinPiece = size_t(256) << 10;
 
     explicit CopyPool(unsigned max_threads = 4) : stop_(false), remaining_(0)
     {
@@ -68,6 +67,10 @@ public:
             if (v >= 1 && v <= 64) max_threads = (unsigned)v;
         }
         nthreads_ = n < 2 ? 1 : (n > max_threads ? max_threads : n);
+        if (const char *e = std::getenv("SX_COPY_PARALLEL_FROM")) {
+            const long long v = std::strtoll(e, nullptr, 10);
+            if (v >= 65536) parallel_from_ = (size_t)v;
+        }
     }
     ~CopyPool()
     {
@@ -86,11 +89,11 @@ public:
 
     void copy(void *dst, const void *src, size_t bytes)
     {
-        if (bytes < kParallelFrom || nthreads_ < 2) {
+        if (bytes < parallel_from_ || nthreads_ < 2) {
             std::memcpy(dst, src, bytes);
             return;
         }
-        size_t parts = std::min<size_t>(nthreads_, bytes / kMinPiece);
+        const size_t parts = std::min<size_t>(nthreads_, bytes / (parallel_from_ / 4));
         const size_t piece = ((bytes / parts) + 4095) & ~size_t(4095);
         if (workers_.empty()) {
             jobs_.resize(nthreads_ - 1);
@@ -137,6 +140,7 @@ private:
     }
 
     unsigned nthreads_;
+    size_t parallel_from_ = kParallelFrom;
     std::mutex m_;
     std::condition_variable work_, done_;
     std::vector<std::thread> workers_;

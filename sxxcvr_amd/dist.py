@@ -41,14 +41,16 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
-def gather_channels(local, n_channels, dst=0, group=None):
+def gather_channels(local, n_channels, dst=0, group=None, always_collective=False):
     """Gather every rank's [local_channels, n] block into a [n_channels, n]
     tensor on `dst` (channel-major, in global channel order); other ranks get
     None.  Shards may differ in size by one channel; blocks are padded to the
-    largest shard for the collective and trimmed on the root."""
+    largest shard for the collective and trimmed on the root.  A world of one
+    rank returns `local` itself unless always_collective is set (which runs the
+    collective anyway: a 1-GPU box can then exercise the RCCL call)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

@@ -1,0 +1,88 @@
+"""The collectives of the multi-GPU layout through RCCL itself (torch.distributed backend "nccl") on the GPUs this
+box has.  With one GPU the world is one rank: communicator set-up, the gather of the decimated channels in the
+wire layout bench.py uses, the MAX all-reduce of the timing and the barrier all run through librccl -- what a
+1-GPU box can prove about the N > 1 path beyond the gloo tests.  With two or more GPUs the same script runs one
+rank per GPU over xGMI."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+import sxxcvr_amd
+from sxxcvr_amd import dist as sxdist
+from sxxcvr_amd.resampler import DECIMATE
+
+rank, local_rank, world = sxdist.env_rank()
+torch.cuda.set_device(local_rank)
+dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+assert dist.get_backend() == "nccl"
+per, n_in = 8, 1 << 16
+lo, hi = sxdist.shard_channels(per * world, world, rank)
+taps = sxxcvr_amd.design_lowpass(128, 4)
+plan = sxxcvr_amd.Resampler(DECIMATE, taps, 4, nchan=per, device=local_rank)
+x = torch.empty((per, n_in), dtype=torch.complex64, device="cuda")
+sxxcvr_amd.synth_fill(x, 0x51255, first_channel=lo, start=0)
+y = plan.process(x)
+torch.cuda.synchronize()
+full = sxdist.gather_channels(y, per * world, dst=0, always_collective=True)
+t = torch.tensor([1.0 + rank], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t.item()) == float(world)
+if rank == 0:
+    assert full.shape == (per * world, n_in // 4) and full.dtype == torch.complex64
+    assert torch.equal(full[:per], y)
+    # every rank's block is what this rank computes for those channels
+    for r in range(1, world):
+        sxxcvr_amd.synth_fill(x, 0x51255, first_channel=per * r, start=0)
+        plan.reset()
+        want = plan.process(x)
+        torch.cuda.synchronize()
+        assert torch.equal(full[per * r:per * (r + 1)], want), r
+    print("rccl ok world", world)
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gather_allreduce_barrier_through_rccl(tmp_path):
+    import torch
+    world = min(max(torch.cuda.device_count(), 1), 2)
+    script = tmp_path / "rccl_probe.py"
+    script.write_text(SCRIPT % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    assert "rccl ok world %d" % world in outs[0]
