@@ -50,6 +50,7 @@
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
 #include "sxfir_decim_pair.hip.h"
+#include "sxfir_decim_wide.hip.h"
 #ifdef SXFIR_PROFILING
 #include "sxfir_decim_sgpr.hip.h"
 #include "../../include/sxfir_prof.h"
@@ -107,6 +108,9 @@ struct sxfir_plan {
     bool pair;             // decim4_pair_kernel: the two tap halves on the two waves of a workgroup
     bool pair_xsep;        // ... with a separate exchange buffer (two barriers per tile instead of four)
     int occ_pair;          // its resident workgroups per CU
+    bool wide;             // decim4_wide_kernel: 8 outputs per lane, 512-output tiles (symmetric 128-tap plans)
+    int wide_nb;           // (profiling) its LDS read-ahead depth: 0 = default
+    int occ_wide;
     int compute_units;
     float *taps_dev;
     float *taps_scaled_dev;   // taps * 2^-31 (exact): scalar-tap kernel on S32 wire words
@@ -248,6 +252,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->pair = false;
     p->pair_xsep = false;
     p->occ_pair = 8;
+    p->wide = false;
+    p->wide_nb = 0;
+    p->occ_wide = 8;
     p->occ_multi = 2;
     // generations of workgroups per launch, measured (tools/kbench.py): the multi-column kernel's prologue
     // (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16; the
@@ -311,6 +318,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (ntaps == 128) {
             const void *kp = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_pair_kernel<0, true> : (const void *)sxfir::decim4_pair_kernel<0, false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 128, 0) == hipSuccess && nb > 0) p->occ_pair = nb;
+            const void *kw = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_wide_kernel<0, true> : (const void *)sxfir::decim4_wide_kernel<0, false>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
         }
 #ifdef SXFIR_PROFILING
         const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
@@ -326,6 +335,11 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                                : (const void *)sxfir::decim4_sgpr_kernel<4>;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, 0) == hipSuccess && nb > 0)
                     p->occ_sb = nb;
+            }
+            // "wide": decim4_wide_kernel (sxfir_decim_wide.hip.h), symmetric taps only
+            if (strncmp(v, "wide", 4) == 0 && ntaps == 128 && p->symmetric) {
+                p->wide = true;
+                p->wide_nb = atoi(v + 4);
             }
             // "pair": decim4_pair_kernel (sxfir_decim_pair.hip.h)
             if (strncmp(v, "pair", 4) == 0 && ntaps == 128) {
@@ -615,10 +629,11 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.sched = p->sched;
         a.stamps = nullptr;
-        if (p->pair && p->ntaps == 128) {
-            // decim4_pair_kernel: tiles of 512 outputs, one 2-wave workgroup each, strided XCD-blocked passes
+        if ((p->pair || p->wide) && p->ntaps == 128) {
+            // decim4_pair_kernel / decim4_wide_kernel: tiles of 512 outputs, one workgroup (2 waves / 1 wave) each,
+            // strided XCD-blocked passes
             const long long n_tiles2 = (n_out + 511) / 512;
-            long long G = ((long long)p->compute_units * p->occ_pair * p->oversub) / p->nchan;
+            long long G = ((long long)p->compute_units * (p->wide ? p->occ_wide : p->occ_pair) * p->oversub) / p->nchan;
             if (G < 1) G = 1;
             if (G > n_tiles2) G = n_tiles2;
             a.n_tiles = (int)n_tiles2;
@@ -634,14 +649,26 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
 #ifdef SXFIR_PROFILING
             abl = p->ablate;
             if (abl == 5) {
-                const size_t need = (size_t)G * p->nchan * 2;
+                const size_t need = (size_t)G * p->nchan * (p->wide ? 1 : 2);
                 if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
                 if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
                 p->stamps_n = need;
                 a.stamps = (unsigned long long *)p->stamps_dev;
             }
 #endif
-            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, true>), grid, dim3(128), 0, st, a);
+            if (p->wide) {
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
+#ifdef SXFIR_PROFILING
+                else if (abl == 0 && p->wide_nb == 2) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 2>), grid, dim3(64), 0, st, a);
+                else if (abl == 0 && p->wide_nb == 4) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 4>), grid, dim3(64), 0, st, a);
+                else if (abl == 0 && p->wide_nb == 12) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 12>), grid, dim3(64), 0, st, a);
+                else if (abl == 0 && p->wide_nb == 16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 16>), grid, dim3(64), 0, st, a);
+                else if (abl == 1) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<1, false>), grid, dim3(64), 0, st, a);
+                else if (abl == 5) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<5, false>), grid, dim3(64), 0, st, a);
+#endif
+                else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
+            }
+            else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, true>), grid, dim3(128), 0, st, a);
 #ifdef SXFIR_PROFILING
             else if (p->pair_xsep && abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false, true>), grid, dim3(128), 0, st, a);
             else if (p->pair_xsep) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false, true>), grid, dim3(128), 0, st, a);

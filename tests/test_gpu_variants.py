@@ -28,6 +28,9 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_TILE_VARIANT": "sg4"},
     {"SXFIR_TILE_VARIANT": "pair"},
     {"SXFIR_TILE_VARIANT": "pair", "SXFIR_OVERSUB": "3"},
+    {"SXFIR_TILE_VARIANT": "wide"},
+    {"SXFIR_TILE_VARIANT": "wide", "SXFIR_OVERSUB": "3"},
+    {"SXFIR_TILE_VARIANT": "wide", "SXFIR_OVERSUB": "64", "SXFIR_SCHED": "2"},
     {"SXFIR_TILE_VARIANT": "pairx"},
     {"SXFIR_TILE_VARIANT": "pairx", "SXFIR_OVERSUB": "5"},
     {"SXFIR_TILE_VARIANT": "pair", "SXFIR_OVERSUB": "64", "SXFIR_SCHED": "2"},
