@@ -247,7 +247,6 @@ public:
         while (max_batch_ < kMaxBatchCap && 2 * max_batch_ * (size_t)decim_ * (size_t)nchan_ <= kMaxSource) max_batch_ *= 2;
         for (int k = 0; k < 2; ++k) {
             done_[k] = ran_[k] = nullptr;
-            out_used_[k] = false;
             gpu_check(sxfir_event_create(&done_[k]), "sxfir_event_create");
             gpu_check(sxfir_event_create(&ran_[k]), "sxfir_event_create");
         }
@@ -289,8 +288,11 @@ public:
         // it, no staging and no host copy.  Everything else goes through the pinned staging slots.
         float *direct = nullptr;
         size_t direct_stride = 0;
-        const bool go_direct = n >= kDirectFrom && (pos != next_ || n > staged_from(pos)) &&
-                               direct_target(dsts, n, &direct, &direct_stride);
+        dst_locked_ = n >= kDirectFrom && direct_target(dsts, n, &direct, &direct_stride);
+        // a reader of megabyte blocks into page-locked memory: the batches read ahead for it stay in HBM and are
+        // DMA-copied into ITS buffer when it asks (no staging hop, no host copy)
+        if (8 * n * (size_t)nchan_ >= kSdmaFromBytes) prefer_hbm_ = dst_locked_;
+        const bool go_direct = dst_locked_ && (pos != next_ || n > staged_from(pos));
         if (pos != next_) {
             // a jump (overrun skip, restart): whatever was read ahead is for the wrong positions
             slot_[0].n = slot_[1].n = 0;
@@ -305,23 +307,15 @@ public:
         if (go_direct) {
             // what the read-ahead already holds is handed out first: the filter has moved past it
             done = drain_slots(pos, n, dsts);
+            const size_t from_slots = done;
             int64_t p = pos + (int64_t)done;
             void *st = stream_->get();
-            // passes of a quarter of the read (a megabyte at least): the DMA copy of one runs beside the kernels of the next
-            size_t chunk = max_batch_;
-            while (chunk / 2 >= (n + 3) / 4 && 8 * (chunk / 2) * (size_t)nchan_ >= kSdmaFromBytes) chunk /= 2;
-            int k = 0;
-            bool copies[2] = {false, false};
             while (done < n) {
-                const size_t m = std::min(n - done, chunk);
+                const size_t m = std::min(n - done, max_batch_);
                 if (8 * m * (size_t)nchan_ >= kSdmaFromBytes) {
-                    run_to_hbm(k, p, m, st);
+                    run_to_hbm(0, p, m, st);
                     for (int c = 0; c < nchan_; ++c)
-                        gpu_check(sxfir_memcpy_d2h(dsts[c] + 2 * done, out_[k].at(8 * (size_t)c * m), 8 * m, copy_->get()),
-                                  "sxfir_memcpy_d2h");
-                    gpu_check(sxfir_event_record(done_[k], copy_->get()), "sxfir_event_record");
-                    copies[k] = true;
-                    k ^= 1;
+                        gpu_check(sxfir_memcpy_d2h(dsts[c] + 2 * done, out_[0].at(8 * (size_t)c * m), 8 * m, st), "sxfir_memcpy_d2h");
                 } else {
                     run(p, m, direct + 2 * done, direct_stride, st);
                 }
@@ -330,9 +324,7 @@ public:
             }
             gpu_check(sxfir_event_record(direct_done_, st), "sxfir_event_record");
             gpu_check(sxfir_event_sync(direct_done_), "sxfir_event_sync");
-            for (int q = 0; q < 2; ++q)
-                if (copies[q]) gpu_check(sxfir_event_sync(done_[q]), "sxfir_event_sync");
-            direct_samples_ += (int64_t)n;
+            direct_samples_ += (int64_t)(n - from_slots);
             next_ = pos + (int64_t)n;
             // keep the next batches in flight for whoever reads next
             batch_ = pick_batch(n);
@@ -354,11 +346,9 @@ public:
                 launch(cur_ ^ 1, slot_[cur_].pos + (int64_t)slot_[cur_].n, batch_);
                 continue;
             }
-            wait(cur_);
             const size_t off = (size_t)(p - s.pos);
             const size_t m = std::min(n - done, s.n - off);
-            for (int c = 0; c < nchan_; ++c)
-                pool_.copy(dsts[c] + 2 * done, stage_[cur_].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+            hand_out(cur_, off, m, dsts, done);
             done += m;
         }
         next_ = pos + (int64_t)n;
@@ -369,7 +359,40 @@ private:
         int64_t pos = 0;
         size_t n = 0;         // 0 = nothing launched into this slot
         bool ready = false;   // the host may read the staged samples
+        bool in_hbm = false;  // the batch is in out_[k] only: no copy to the host has been queued yet
     };
+
+    // samples [off, off+m) of slot k -> dsts[c] + 2*done
+    void hand_out(int k, size_t off, size_t m, float *const *dsts, size_t done)
+    {
+        Slot &s = slot_[k];
+        if (s.in_hbm) {
+            if (dst_locked_) {
+                // The batch's kernels are long through (the host checks, it does not queue a wait: a DMA copy
+                // queued behind a cross-stream wait makes hipMemcpyAsync itself block for milliseconds now and then
+                // on ROCm 7.2); the copy runs on the copy stream, beside the kernels of the batches read ahead.
+                void *cst = copy_->get();
+                gpu_check(sxfir_event_sync(ran_[k]), "sxfir_event_sync");
+                for (int c = 0; c < nchan_; ++c)
+                    gpu_check(sxfir_memcpy_d2h(dsts[c] + 2 * done, out_[k].at(8 * ((size_t)c * s.n + off)), 8 * m, cst),
+                              "sxfir_memcpy_d2h");
+                gpu_check(sxfir_event_record(done_[k], cst), "sxfir_event_record");
+                gpu_check(sxfir_event_sync(done_[k]), "sxfir_event_sync");
+                direct_samples_ += (int64_t)m;
+                return;
+            }
+            // an ordinary destination after all: the batch takes the staging hop now
+            void *st = stream_->get();
+            grow(stage_[k], 8 * s.n * (size_t)nchan_);
+            gpu_check(sxfir_memcpy_d2h(stage_[k].floats(), out_[k].get(), 8 * s.n * (size_t)nchan_, st), "sxfir_memcpy_d2h");
+            gpu_check(sxfir_event_record(done_[k], st), "sxfir_event_record");
+            s.in_hbm = false;
+            s.ready = false;
+        }
+        wait(k);
+        for (int c = 0; c < nchan_; ++c)
+            pool_.copy(dsts[c] + 2 * done, stage_[k].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+    }
 
     size_t pick_batch(size_t request) const
     {
@@ -409,11 +432,9 @@ private:
             const int64_t p = pos + (int64_t)done;
             if (s.n == 0) continue;
             if (p >= s.pos && p < s.pos + (int64_t)s.n && done < n) {
-                wait(k);
                 const size_t off = (size_t)(p - s.pos);
                 const size_t m = std::min(n - done, s.n - off);
-                for (int c = 0; c < nchan_; ++c)
-                    pool_.copy(dsts[c] + 2 * done, stage_[k].floats() + 2 * ((size_t)c * s.n + off), 8 * m);
+                hand_out(k, off, m, dsts, done);
                 done += m;
             }
         }
@@ -443,43 +464,35 @@ private:
         if (n_out != m) throw std::runtime_error("rx chain: decimator produced an unexpected block size");
     }
 
-    // a DMA copy queued for buffer pair k (possibly of a batch that a jump dropped) comes before anything new
-    // that writes out_[k] or stage_[k]: ordered on the GPU, the host does not wait
-    void settle_copy(int k, void *st)
-    {
-        if (!out_used_[k]) return;
-        gpu_check(sxfir_stream_wait_event(st, done_[k]), "sxfir_stream_wait_event");
-        out_used_[k] = false;
-    }
-
-    // stream samples [pos, pos+m) of all channels -> out_[k] in HBM (channel stride m); the copy stream then waits
-    // for that pass, so that the caller can queue the block's DMA copies on it
+    // stream samples [pos, pos+m) of all channels -> out_[k] in HBM (channel stride m); ran_[k] fires behind the pass
     void run_to_hbm(int k, int64_t pos, size_t m, void *st)
     {
         grow(out_[k], 8 * m * (size_t)nchan_);
-        settle_copy(k, st);
         run(pos, m, static_cast<float *>(out_[k].get()), m, st);
         gpu_check(sxfir_event_record(ran_[k], st), "sxfir_event_record");
-        gpu_check(sxfir_stream_wait_event(copy_->get(), ran_[k]), "sxfir_stream_wait_event");
-        out_used_[k] = true;
     }
 
-    // stream samples [pos, pos+m) of all channels -> staging slot k, asynchronously on the chain's streams
+    // stream samples [pos, pos+m) of all channels -> staging slot k, asynchronously on the chain's stream
     void launch(int k, int64_t pos, size_t m)
     {
         void *st = stream_->get();
-        grow(stage_[k], 8 * m * (size_t)nchan_);
         const size_t bytes = 8 * m * (size_t)nchan_;
-        if (bytes >= kSdmaFromBytes) {
-            // large batch: HBM, then one DMA-engine copy into the pinned staging buffer on the copy stream, beside
-            // the kernels of the batch after it
+        slot_[k].in_hbm = false;
+        if (bytes >= kSdmaFromBytes && prefer_hbm_) {
+            // large batch for a reader with page-locked buffers: it stays in HBM until that reader names its buffer
             run_to_hbm(k, pos, m, st);
-            gpu_check(sxfir_memcpy_d2h(stage_[k].floats(), out_[k].get(), bytes, copy_->get()), "sxfir_memcpy_d2h");
-            gpu_check(sxfir_event_record(done_[k], copy_->get()), "sxfir_event_record");
+            slot_[k].in_hbm = true;
+        } else if (bytes >= kSdmaFromBytes) {
+            // large batch: HBM, then one DMA-engine copy into the pinned staging buffer, queued behind the kernels
+            // on the same stream
+            grow(stage_[k], bytes);
+            run_to_hbm(k, pos, m, st);
+            gpu_check(sxfir_memcpy_d2h(stage_[k].floats(), out_[k].get(), bytes, st), "sxfir_memcpy_d2h");
+            gpu_check(sxfir_event_record(done_[k], st), "sxfir_event_record");
         } else {
+            grow(stage_[k], bytes);
             // the decimator stores straight into the pinned staging buffer (device-visible host memory): the
             // outputs are 1/decim of the traffic and cross PCIe as they are produced, no separate D2H copy
-            settle_copy(k, st);
             run(pos, m, stage_[k].floats(), m, st);
             gpu_check(sxfir_event_record(done_[k], st), "sxfir_event_record");
         }
@@ -516,7 +529,7 @@ private:
     // wait for THIS slot's pass only: the batch read ahead behind it stays in flight
     void wait(int k)
     {
-        if (slot_[k].ready) return;
+        if (slot_[k].ready || slot_[k].in_hbm) return;     // (in HBM: ordered on the GPU, hand_out queues the copy)
         gpu_check(sxfir_event_sync(done_[k]), "sxfir_event_sync");
         slot_[k].ready = true;
     }
@@ -547,10 +560,9 @@ private:
     sxfir_plan *plan_;
     std::unique_ptr<GpuStream> stream_;
     DeviceBuffer in_, scratch_;      // wideband source block; outputs of the priming pass (discarded)
-    std::unique_ptr<GpuStream> copy_;   // DMA copies of large passes, beside the kernels on stream_
+    std::unique_ptr<GpuStream> copy_;   // DMA copies out of HBM into page-locked caller memory, beside the kernels on stream_
     DeviceBuffer out_[2];            // decimated block of a large pass, before its DMA copy to the host
     void *ran_[2];                   // recorded behind the pass that filled out_[k]
-    bool out_used_[2];               // a copy out of out_[k] (recorded in done_[k] on the copy stream) may be in flight
     CopyPool pool_;
     PinnedBuffer stage_[2];
     Slot slot_[2];
@@ -559,7 +571,9 @@ private:
     int64_t next_;
     int cur_;
     size_t batch_, max_batch_;
-    int64_t direct_samples_ = 0;     // samples delivered by passes that stored into caller memory
+    int64_t direct_samples_ = 0;     // samples that reached page-locked caller memory without a host copy
+    bool dst_locked_ = false;        // this call's destination is page-locked (and laid out for direct stores)
+    bool prefer_hbm_ = false;        // the last megabyte-sized read went to page-locked memory
 };
 
 class TxChain {

@@ -126,6 +126,23 @@ static void rx_large_test()
     chain.produce(pos, n, dsts);
     check("rx_large_direct", dsts[0], ref.data() + 2 * pos, 2 * n);
     std::printf("rx_large_direct_samples %lld\n", (long long)chain.direct_samples());
+    // the reader of page-locked megabyte blocks goes on: its read-ahead stays in HBM and is DMA-copied into its buffer
+    pos += (int64_t)n;
+    for (int rep = 0; rep < 3; ++rep) {
+        std::memset(blk, 0xff, 8 * n);
+        chain.produce(pos, n, dsts);
+        check("rx_large_from_hbm", dsts[0], ref.data() + 2 * pos, 2 * n);
+        pos += (int64_t)n;
+    }
+    std::printf("rx_large_hbm_samples %lld\n", (long long)chain.direct_samples());
+    // ... and an ordinary buffer after all: the batch in HBM takes the staging hop
+    buf.assign(2 * 300000, -1.0f);
+    float *pd[1] = {buf.data()};
+    chain.produce(pos, 300000, pd);
+    check("rx_large_fallback", buf.data(), ref.data() + 2 * pos, 2 * 300000);
+    pos += 300000;
+    chain.produce(pos, 1000, pd);
+    check("rx_large_small_after", buf.data(), ref.data() + 2 * pos, 2 * 1000);
     sxfir_host_free(blk);
 }
 

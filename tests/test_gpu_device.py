@@ -656,7 +656,9 @@ def test_megabyte_blocks_cross_pcie_as_dma_copies_beside_the_kernels(oracle):
             assert dev.readStream(rx, [buf], m).ret == m
             assert_bit_exact(buf[:m], ref[pos:pos + m], "%s read of %d at %d" % (what, m, pos))
             pos += m
-        assert int(dev.readSetting("RX_DIRECT_SAMPLES")) >= n
+        # the first registered read reached the caller's memory without a host copy (bar what the small read before
+        # it had left in the pinned staging slots: at most two batches of 4096)
+        assert int(dev.readSetting("RX_DIRECT_SAMPLES")) >= n - 8192
         dev.deactivateStream(rx)
 
         dev.activateStream(tx)
