@@ -190,6 +190,107 @@ static void tx_large_test()
     sxfir_host_free(blk);
 }
 
+// Random call sequences: block sizes from one sample to megabytes, ordinary and page-locked buffers, jumps forwards
+// and backwards, in any order -- every path change of the chains (staged / in HBM / direct, zero-copy / DMA, slot
+// growth) must keep the stream intact.
+static uint64_t rnd_state = 0x9e3779b97f4a7c15ull;
+static uint64_t rnd()
+{
+    rnd_state ^= rnd_state << 13;
+    rnd_state ^= rnd_state >> 7;
+    rnd_state ^= rnd_state << 17;
+    return rnd_state;
+}
+
+static size_t random_block()
+{
+    switch (rnd() % 6) {
+    case 0: return 1 + rnd() % 300;
+    case 1: return 256 * (1 + rnd() % 16);
+    case 2: return 30000 + rnd() % 10000;
+    case 3: return 131072 + rnd() % 70000;
+    case 4: return 262144 + rnd() % 300000;
+    default: return 1 + rnd() % 5000;
+    }
+}
+
+static void rx_random_test()
+{
+    const int D = 4, NT = 128;
+    const uint64_t seed = 77;
+    const size_t total = 6000000;
+    std::vector<float> taps(NT);
+    sxo_design_lowpass(NT, D, 8.0, 1.0, taps.data());
+    std::vector<float> ref(2 * total);
+    {
+        std::vector<float> x(2 * total * D);
+        sxo_synth_iq(seed, 2, 0, total * D, x.data());
+        sxo_decim_f32(taps.data(), NT, D, 2, 4, x.data(), total * D, 0, total, ref.data());
+    }
+    sx::RxChain chain(0, D, 32, seed, 2, 1, false);
+    void *blk = nullptr;
+    sxfir_host_alloc(&blk, 8 * 600000);
+    std::vector<float> plain(2 * 600000);
+    int64_t pos = 0;
+    size_t bad_reads = 0, reads = 0;
+    for (int op = 0; op < 90; ++op) {
+        const size_t n = random_block();
+        if (rnd() % 7 == 0) pos = (int64_t)(rnd() % (total - 700000));     // a jump, either way
+        if (pos + (int64_t)n > (int64_t)total) pos = 0;
+        const bool locked = rnd() % 2 == 0;
+        float *dst = locked ? static_cast<float *>(blk) : plain.data();
+        std::memset(dst, 0xff, 8 * n);
+        float *dsts[1] = {dst};
+        chain.produce(pos, n, dsts);
+        bad_reads += std::memcmp(dst, ref.data() + 2 * pos, 8 * n) != 0;
+        ++reads;
+        pos += (int64_t)n;
+    }
+    std::printf("rx_random %zu mismatches of %zu reads\n", bad_reads, reads);
+    bad += bad_reads != 0;
+    sxfir_host_free(blk);
+}
+
+static void tx_random_test()
+{
+    const int L = 4, NT = 128;
+    const size_t ring_frames = 1 << 20;
+    std::vector<float> taps(NT);
+    sxo_design_lowpass(NT, L, 8.0, (double)L, taps.data());
+    sx::TxChain chain(0, L, 32, ring_frames, 1, false);
+    chain.set_threshold2(0.3f);
+    const size_t cap = 9000000;
+    std::vector<float> stream(2 * cap, 0.0f);
+    void *blk = nullptr;
+    sxfir_host_alloc(&blk, 8 * 600000);
+    std::vector<float> plain(2 * 600000);
+    int64_t pos = 0;
+    long long want_keyed = 0;
+    for (int op = 0; op < 70; ++op) {
+        const size_t n = random_block();
+        if (rnd() % 5 == 0) pos += (int64_t)(rnd() % 3000);               // a gap: silence
+        if (pos + (int64_t)n > (int64_t)cap) break;
+        const bool locked = rnd() % 2 == 0;
+        float *src = locked ? static_cast<float *>(blk) : plain.data();
+        sxo_synth_iq(5, 9, pos, n, src);
+        std::memcpy(stream.data() + 2 * pos, src, 8 * n);
+        for (size_t i = 0; i < n; ++i) want_keyed += (src[2 * i] * src[2 * i] + src[2 * i + 1] * src[2 * i + 1] >= 0.3f) ? 1 : 0;
+        const float *srcs[1] = {src};
+        chain.consume(pos, n, srcs);
+        std::memset(src, 0x33, 8 * n);                     // the call has returned: the memory is the caller's again
+        pos += (int64_t)n;
+    }
+    const size_t total = (size_t)pos;
+    std::printf("tx_random_keyed %lld want %lld\n", (long long)chain.keyed_samples(), want_keyed);
+    bad += chain.keyed_samples() != want_keyed;
+    const size_t tail = std::min(total, ring_frames);
+    std::vector<float> want(2 * total * L), got(2 * tail * L);
+    sxo_interp_f32(taps.data(), NT, L, 2, stream.data(), total, 0, total * L, want.data());
+    chain.capture((int64_t)(total - tail) * L, tail * L, got.data(), 0);
+    check("tx_random_sink", got.data(), want.data() + 2 * (total - tail) * L, 2 * tail * L);
+    sxfir_host_free(blk);
+}
+
 static void tx_test()
 {
     const int L = 8, NT = 256, NCH = 2;
@@ -271,6 +372,8 @@ int main()
     tx_test();
     rx_large_test();
     tx_large_test();
+    rx_random_test();
+    tx_random_test();
     std::printf("bad %d\n", bad);
     return bad ? 1 : 0;
 }

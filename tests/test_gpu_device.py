@@ -690,6 +690,65 @@ def test_megabyte_blocks_cross_pcie_as_dma_copies_beside_the_kernels(oracle):
         sxxcvr_amd.unpin_array(pinned)
 
 
+def test_random_call_sequences_keep_the_stream_intact(oracle):
+    """Forty reads and thirty writes of random sizes (one sample … 4 MiB), into ordinary and page-locked buffers in
+    any order: every change of path inside the chains (staged / in HBM / direct, zero-copy / DMA copy, slot growth)
+    must hand over the same stream the oracle computes."""
+    rng = np.random.default_rng(2026)
+
+    def block():
+        kind = rng.integers(0, 6)
+        return int([rng.integers(1, 300), 256 * rng.integers(1, 17), rng.integers(30000, 40000),
+                    rng.integers(131072, 200000), rng.integers(262144, 524288), rng.integers(1, 5000)][kind])
+
+    dev = make()
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536"})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536", "threshold": "0.5"})
+    pinned = sxxcvr_amd.pin_array(np.zeros(1 << 19, dtype=np.complex64))
+    try:
+        sizes = [block() for _ in range(40)]
+        total = sum(sizes)
+        h = sxxcvr_amd.design_lowpass(128, 4)
+        ref = oracle.decim_f32(h, 4, oracle.synth_iq_mt(SEED, 0, 0, 4 * total, 8), 2, 4, threads=8)
+        dev.activateStream(rx)
+        pos = 0
+        for i, m in enumerate(sizes):
+            locked = bool(rng.integers(0, 2))
+            buf = pinned if locked else np.zeros(m, dtype=np.complex64)
+            buf[:m] = 0
+            assert dev.readStream(rx, [buf], m).ret == m
+            assert_bit_exact(buf[:m], ref[pos:pos + m], "read %d: %d samples at %d, %s" % (i, m, pos, "page-locked" if locked else "pageable"))
+            pos += m
+        dev.deactivateStream(rx)
+
+        dev.activateStream(tx)
+        sizes = [block() for _ in range(30)]
+        stream = np.zeros(sum(sizes) + 70000 * 30, dtype=np.complex64)
+        keyed, end = 0, 0
+        for i, m in enumerate(sizes):
+            x = (rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(np.complex64)
+            f = x.view(np.float32).reshape(-1, 2)
+            keyed += int(np.count_nonzero(f[:, 0] * f[:, 0] + f[:, 1] * f[:, 1] >= np.float32(0.25)))
+            locked = bool(rng.integers(0, 2))
+            src = x
+            if locked:
+                pinned[:m] = x
+                src = pinned
+            assert dev.writeStream(tx, [src], m).ret == m
+            if locked:
+                pinned[:m] = 0
+            end = int(dev.readSetting("TX_POSITION"))
+            stream[end - m:end] = x
+        assert int(dev.readSetting("TX_PTT_SAMPLES")) == keyed
+        L = int(dev.readSetting("TX_INTERP"))
+        tail = min(end, 1 << 20)
+        want = tx_reference(oracle, L, stream[:end])
+        got = dev.txCapture((end - tail) * L, tail * L)
+        assert_bit_exact(got, want[(end - tail) * L:], "dac stream tail")
+    finally:
+        sxxcvr_amd.unpin_array(pinned)
+
+
 def test_keying_count_on_the_gpu_matches_the_reference_rule(oracle):
     """TX_PTT_SAMPLES: the number of written samples whose squared magnitude reaches threshold^2 (the PTT bit of
     convert_tx_buffer, SX.cpp:126-135), counted by the GPU as the staged blocks pass; silence from timed gaps

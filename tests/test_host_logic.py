@@ -118,6 +118,9 @@ def test_gpu_chains_over_fake_backend(oracle, tmp_path):
     assert "rx_direct_samples 40000" in lines and "rx_direct_unchanged 1" in lines
     # passes of a megabyte and more (DMA copies beside the kernels), grown TX slots, page-locked memory on both sides
     assert "rx_large_direct_samples 200000" in lines and "tx_large_direct_samples 150000" in lines
+    assert any(l.startswith("rx_random 0 mismatches of 90 reads") for l in lines)
+    rk = [l for l in lines if l.startswith("tx_random_keyed ")][0].split()
+    assert rk[1] == rk[3] and int(rk[1]) > 0
     assert "rx_large_hbm_samples 800000" in lines            # three more reads of 200000, none through a host copy
     assert "tx_large_slot_frames 262144" in lines
     big = [l for l in lines if l.startswith("tx_large_keyed ")][0].split()
