@@ -66,6 +66,30 @@ def test_bench_starts_its_own_ranks_gloo_stand_in():
     assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
 
 
+def test_bench_under_the_drivers_launcher_gloo_stand_in():
+    """The driver's own N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...; exactly one JSON line must come out (rank 0's).
+    On a 1-GPU box the two ranks share the GPU and the collectives run over gloo."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    e = dict(os.environ, SXFIR_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["scaling"] == "weak"
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["channels_per_gpu"] == 8
+    assert line["gather"]["gathered_shape"][0] == 16
+
+
 def test_bench_two_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
