@@ -168,7 +168,29 @@ class Oracle:
         return self._run(self.lib.sxo_interp_f32_mt, h, L, x, n0, n_out, groups=groups, threads=threads)
 
     def max_threads(self):
-        return int(self.lib.sxo_max_threads())
+        """Threads worth starting: OpenMP's own figure, capped by the CPUs this process may use (affinity mask)
+        and by the cgroup CPU quota (a container with cpu.max = 16 CPUs on a 256-thread host runs 16 threads well
+        and 128 threads badly)."""
+        n = int(self.lib.sxo_max_threads())
+        try:
+            n = min(n, len(os.sched_getaffinity(0)))
+        except (AttributeError, OSError):
+            pass
+        for path in ("/sys/fs/cgroup/cpu.max",):
+            try:
+                quota, period = open(path).read().split()[:2]
+                if quota != "max":
+                    n = min(n, max(1, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+        return max(1, n)
 
     # -- half ---------------------------------------------------------------
     def f32_to_f16(self, a):
