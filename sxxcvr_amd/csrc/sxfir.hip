@@ -49,8 +49,10 @@
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
-#include "sxfir_decim_pair.hip.h"
+#ifdef SXFIR_PROFILING
+#include "sxfir_decim_pair.hip.h"   // measured variants, not shipped
 #include "sxfir_decim_wide.hip.h"
+#endif
 #ifdef SXFIR_PROFILING
 #include "sxfir_decim_sgpr.hip.h"
 #include "../../include/sxfir_prof.h"
@@ -315,13 +317,13 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                               : (ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
                                               : (const void *)sxfir::decim4_tile_kernel<64, false>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
+#ifdef SXFIR_PROFILING
         if (ntaps == 128) {
             const void *kp = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_pair_kernel<0, true> : (const void *)sxfir::decim4_pair_kernel<0, false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 128, 0) == hipSuccess && nb > 0) p->occ_pair = nb;
             const void *kw = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_wide_kernel<0, true> : (const void *)sxfir::decim4_wide_kernel<0, false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
         }
-#ifdef SXFIR_PROFILING
         const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
                                        : (const void *)sxfir::decim4_tile_kernel<64, true>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kdb, 64, 0) == hipSuccess && nb > 0) p->occ_db = nb;
@@ -629,6 +631,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.sched = p->sched;
         a.stamps = nullptr;
+#ifdef SXFIR_PROFILING
         if ((p->pair || p->wide) && p->ntaps == 128) {
             // decim4_pair_kernel / decim4_wide_kernel: tiles of 512 outputs, one workgroup (2 waves / 1 wave) each,
             // strided XCD-blocked passes
@@ -645,9 +648,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
             }
             dim3 grid((unsigned)G, (unsigned)p->nchan);
-            int abl = 0;
-#ifdef SXFIR_PROFILING
-            abl = p->ablate;
+            const int abl = p->ablate;
             if (abl == 5) {
                 const size_t need = (size_t)G * p->nchan * (p->wide ? 1 : 2);
                 if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
@@ -655,31 +656,25 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 p->stamps_n = need;
                 a.stamps = (unsigned long long *)p->stamps_dev;
             }
-#endif
             if (p->wide) {
                 if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
-#ifdef SXFIR_PROFILING
                 else if (abl == 0 && p->wide_nb == 2) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 2>), grid, dim3(64), 0, st, a);
                 else if (abl == 0 && p->wide_nb == 4) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 4>), grid, dim3(64), 0, st, a);
                 else if (abl == 0 && p->wide_nb == 12) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 12>), grid, dim3(64), 0, st, a);
                 else if (abl == 0 && p->wide_nb == 16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 16>), grid, dim3(64), 0, st, a);
                 else if (abl == 1) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<1, false>), grid, dim3(64), 0, st, a);
                 else if (abl == 5) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<5, false>), grid, dim3(64), 0, st, a);
-#endif
                 else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
             }
             else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, true>), grid, dim3(128), 0, st, a);
-#ifdef SXFIR_PROFILING
             else if (p->pair_xsep && abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false, true>), grid, dim3(128), 0, st, a);
             else if (p->pair_xsep) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false, true>), grid, dim3(128), 0, st, a);
             else if (abl == 1) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<1, false>), grid, dim3(128), 0, st, a);
             else if (abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false>), grid, dim3(128), 0, st, a);
-#endif
             else hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false>), grid, dim3(128), 0, st, a);
             HIPCHECK(hipGetLastError());
             return SXFIR_OK;
         }
-#ifdef SXFIR_PROFILING
         if (p->t2_wpg) {
             // decim4_tile2_kernel: G workgroups of t2_wpg waves per channel, wave ww of workgroup b takes tiles
             // (S(b) + i*G)*wpg + ww
