@@ -49,7 +49,8 @@
 
 namespace sxfir {
 
-enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64, T2_CUQ = 128 };
+enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64, T2_CUQ = 128,
+       T2_MASKPAD = 256 };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -62,7 +63,17 @@ __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chun
 // HBM -> LDS for the slots [Q0, Q0 + 64*(NI-1) + LASTL) of one tile's image: DMA instruction j fills the slots
 // Q0 + 64j + lane from the per-lane byte offsets off[j] (tile-invariant, see slot_source_offset).  The last
 // instruction is issued for LASTL lanes.
-template <int NT, int Q0, int NI, int LASTL>
+// lanes of the DMA instruction that starts at slot q0 whose slot is a pad slot (never read)
+constexpr unsigned long long pad_lanes(int q0)
+{
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if ((q0 + l + 1) % 17 == 0) m |= 1ull << l;
+    return m;
+}
+
+// MASKPAD: the lanes whose slot is a pad slot sit the DMA out (6 % of the L2 -> LDS bytes)
+template <int NT, int Q0, int NI, int LASTL, bool MASKPAD = false>
 __device__ __forceinline__ void stage_range(const DecimTileCtx<NT> &c, int tile, f32x4 *buf, const unsigned (&off)[NI])
 {
     using C = DecimTile4<NT>;
@@ -75,7 +86,9 @@ __device__ __forceinline__ void stage_range(const DecimTileCtx<NT> &c, int tile,
         for (int j = 0; j < NI; ++j) {
             unsigned b = off[j];
             asm volatile("" : "+v"(b));                  // 32-bit offset next to its use (see stage_tile)
-            if (j < NI - 1 || LASTL >= 64 || c.lane < LASTL) glds16(src + b, buf + Q0 + 64 * j);
+            bool on = j < NI - 1 || LASTL >= 64 || c.lane < LASTL;
+            if constexpr (MASKPAD) on = on && !((pad_lanes(Q0 + 64 * j) >> c.lane) & 1ull);
+            if (on) glds16(src + b, buf + Q0 + 64 * j);
         }
     } else {
 #pragma unroll
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             stage_range<NT, 0, NIA, LASTA>(c, t, buf, aoff);
             stage_range<NT, HS, NIB, LASTB>(c, t, buf, boff);
         } else {
-            stage_range<NT, 0, NIF, LASTF>(c, t, buf, boff);
+            stage_range<NT, 0, NIF, LASTF, (OPT & T2_MASKPAD) != 0>(c, t, buf, boff);
         }
     };
 
