@@ -40,7 +40,7 @@
     X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
-    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320)
+    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576)
 // variants that also exist with phase stamps (ABL 5)
 #define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
@@ -116,6 +116,7 @@ struct sxfir_plan {
     int compute_units;
     float *taps_dev;
     float *taps_scaled_dev;   // taps * 2^-31 (exact): scalar-tap kernel on S32 wire words
+    float taps_k[64];         // the first 64 taps (times 2^-31 for S32 plans) for kernels that take them by value
     bool symmetric;           // taps[k] == taps[ntaps-1-k] bit for bit (every linear-phase design)
     void *hist_dev;        // current history: nchan * hist_len samples
     void *hist_alt;        // the tile kernel writes the next history here, then the two swap
@@ -381,6 +382,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     hipError_t e = hipMalloc((void **)&p->taps_dev, sizeof(float) * (size_t)ntaps);
     if (e == hipSuccess) e = hipMalloc((void **)&p->taps_scaled_dev, sizeof(float) * (size_t)ntaps);
 
+    for (int k = 0; k < 64; ++k) p->taps_k[k] = k < ntaps ? (fmt == SXFIR_S32 ? taps[k] * 4.656612873077393e-10f : taps[k]) : 0.0f;
     if (e == hipSuccess) {
         std::vector<float> scaled(taps, taps + ntaps);
         for (float &t : scaled) t *= 4.656612873077393e-10f;      // 2^-31: exact
@@ -617,6 +619,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         *history_done = true;      // caller swaps hist_dev / hist_alt when it commits the call
         a.taps = p->taps_dev;
         a.taps_scaled = p->taps_scaled_dev;
+        memcpy(a.taps_k, p->taps_k, sizeof(a.taps_k));
         a.n_in = (long long)n_in;
         a.n_out = n_out;
         a.in_stride = (long long)in_stride;

@@ -58,6 +58,9 @@ struct DecimTileArgs {
     int run_base, run_extra;    // n_tiles / n_waves, n_tiles % n_waves (sched 1)
     int hist_wave;          // the wave whose tiles include the last one: it carries the history over
     unsigned long long *stamps;   // diagnostic builds only (ABL 11/12): per-wave {shader cycles, 100 MHz ticks}
+    // the first 64 taps by value (scaled by 2^-31 for S32 wire-word plans): a scalar-tap kernel loads them from the
+    // kernel-argument segment together with everything else, one scalar-load round trip instead of two
+    float taps_k[64];
 };
 
 template <int NT>

@@ -50,7 +50,7 @@
 namespace sxfir {
 
 enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64, T2_CUQ = 128,
-       T2_MASKPAD = 256 };
+       T2_MASKPAD = 256, T2_KARG = 512 };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -63,6 +63,24 @@ __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chun
 // HBM -> LDS for the slots [Q0, Q0 + 64*(NI-1) + LASTL) of one tile's image: DMA instruction j fills the slots
 // Q0 + 64j + lane from the per-lane byte offsets off[j] (tile-invariant, see slot_source_offset).  The last
 // instruction is issued for LASTL lanes.
+// output group r of lanes 8k..8k+7 of a half-wave, 5 bits each (see the kernel: conflict-free ds_read_b128 groups)
+constexpr unsigned long long rgrp_word(int k)
+{
+    unsigned long long w = 0;
+    for (int i = 0; i < 8; ++i) {
+        const int l5 = 8 * k + i;
+        const bool first = l5 < 4 || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+        const int idx = first ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
+        w |= (unsigned long long)(2 * idx + (first ? 0 : 1)) << (5 * i);
+    }
+    return w;
+}
+__device__ __forceinline__ unsigned long long rgrp_table(int k)
+{
+    constexpr unsigned long long W0 = rgrp_word(0), W1 = rgrp_word(1), W2 = rgrp_word(2), W3 = rgrp_word(3);
+    return k == 0 ? W0 : (k == 1 ? W1 : (k == 2 ? W2 : W3));
+}
+
 // lanes of the DMA instruction that starts at slot q0 whose slot is a pad slot (never read)
 constexpr unsigned long long pad_lanes(int q0)
 {
@@ -242,7 +260,8 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
     using C = DecimTile4<NT>;
     constexpr bool DEFER = (OPT & T2_DEFER) != 0, TAPSEP = (OPT & T2_TAPSEP) != 0, DBUF = (OPT & T2_DBUF) != 0;
     constexpr bool PLAINST = (OPT & T2_PLAINST) != 0, HCARRY = (OPT & T2_HCARRY) != 0, PRIO = (OPT & T2_PRIO) != 0;
-    constexpr bool SCALAR = (OPT & T2_SCALAR) != 0, CUQ = (OPT & T2_CUQ) != 0;
+    constexpr bool SCALAR = (OPT & T2_SCALAR) != 0, CUQ = (OPT & T2_CUQ) != 0, KARG = (OPT & T2_KARG) != 0;
+    static_assert(!KARG || (SCALAR && WPG == 1 && !CUQ && !HCARRY), "taps by value: the plain scalar-tap kernel");
     static_assert(!CUQ || (!DBUF && !HCARRY && !TAPSEP && (WPG & (WPG - 1)) == 0), "the LDS tile queue drives the single-buffered loop");
     __shared__ unsigned cuq_next;                        // CUQ: tiles of this workgroup's share handed out so far
     static_assert(!(HCARRY && DBUF), "halo carry-over is for the single-buffered loop");
@@ -320,7 +339,10 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         if (threadIdx.x == 0) cuq_next = 0u;
         __syncthreads();
     } else {
-        if (tile >= tile_end) return;
+        // (KARG: the host launches no more waves than tiles, so no wave leaves here -- and nothing stands between
+        // the scalar loads of the arguments, which then go out as one batch)
+        if constexpr (KARG) __builtin_assume(tile < tile_end);
+        else if (tile >= tile_end) return;
         if (b * WPG + ww == a.hist_wave) write_history<NT>(c, a.hist_out + 2 * a.hist_stride * ch, a.n_in);
     }
 
@@ -342,7 +364,11 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
-    if constexpr (SCALAR) {
+    if constexpr (SCALAR && KARG) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) hs[m] = (f32x2){a.taps_k[2 * m], a.taps_k[2 * m + 1]};
+        hp[0] = (f32x2){0.0f, 0.0f};
+    } else if constexpr (SCALAR) {
         const __attribute__((address_space(4))) f32x2 *tq =
             (const __attribute__((address_space(4))) f32x2 *)(S32IN ? a.taps_scaled : a.taps);
 #pragma unroll
@@ -367,10 +393,10 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
     // the second the odd r, m = 0..15 in both (SQ_LDS_BANK_CONFLICT: 160 -> 32 cycles per tile and wave).
     int rgrp = c.lane;
     if constexpr (SCALAR) {
+        // r of lane l5 (5 bits per lane, branch free): first group {0-3,12-15,20-27} -> 0,2,..,30 in lane order,
+        // second group {4-11,16-19,28-31} -> 1,3,..,31
         const int l5 = c.lane & 31;
-        const bool first = l5 < 4 || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
-        const int idx = first ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
-        rgrp = 2 * idx + (first ? 0 : 1) + (c.lane & 32);
+        rgrp = (int)((rgrp_table(l5 >> 3) >> (5 * (l5 & 7))) & 31u) + (c.lane & 32);
     }
     // this lane's first window chunk: tap halves on lane pairs -> 16g + (1 - p) * NT/4 (a multiple of 16);
     // scalar taps -> 8r, with a second base one slot on for an odd r's differently placed pads

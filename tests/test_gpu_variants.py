@@ -29,6 +29,8 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_TILE_VARIANT": "pair"},
     {"SXFIR_TILE_VARIANT": "pair", "SXFIR_OVERSUB": "3"},
     {"SXFIR_TILE_VARIANT": "t2:1:320"},
+    {"SXFIR_TILE_VARIANT": "t2:1:576"},
+    {"SXFIR_TILE_VARIANT": "t2:1:576", "SXFIR_OVERSUB": "64"},
     {"SXFIR_TILE_VARIANT": "wide"},
     {"SXFIR_TILE_VARIANT": "wide", "SXFIR_OVERSUB": "3"},
     {"SXFIR_TILE_VARIANT": "wide", "SXFIR_OVERSUB": "64", "SXFIR_SCHED": "2"},
