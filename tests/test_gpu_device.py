@@ -455,6 +455,61 @@ def test_rx_and_tx_threads(oracle):
     assert int(dev.readSetting("TX_WRITTEN")) == nblk * blk
 
 
+def test_rx_and_tx_threads_with_megabyte_blocks(oracle):
+    """The same two threads with blocks of 2^18 samples (2 MiB) at 600 kS/s on the wall clock (0.44 s a block), ordinary
+    and page-locked buffers alternating: both chains run their DMA-copy paths, copy pools and second streams at the
+    same time.  The RX stream must be the oracle's, contiguous from position 0; the TX side must have taken every
+    sample and counted the keyed ones."""
+    import threading
+    dev = SoapySDR.Device({"driver": "sx", "clock": "wall"})
+    rate = 600000.0
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, rate)
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_TX, 0, rate)
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536"})
+    tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"period": "65536", "threshold": "0.5"})
+    nblk, blk = 6, 1 << 18
+    rng = np.random.default_rng(5)
+    sent = (rng.uniform(-1, 1, blk) + 1j * rng.uniform(-1, 1, blk)).astype(np.complex64)
+    f = sent.view(np.float32).reshape(-1, 2)
+    keyed_per_block = int(np.count_nonzero(f[:, 0] * f[:, 0] + f[:, 1] * f[:, 1] >= np.float32(0.25)))
+    pin_rx = sxxcvr_amd.pin_array(np.zeros(blk, dtype=np.complex64))
+    pin_tx = sxxcvr_amd.pin_array(sent.copy())
+    errors = []
+    try:
+        dev.activateStream(rx)
+        dev.activateStream(tx)
+
+        def tx_loop():
+            for i in range(nblk):
+                r = dev.writeStream(tx, [pin_tx if i % 2 else sent], blk)
+                if r.ret != blk:
+                    errors.append(("tx", i, r.ret))
+
+        t = threading.Thread(target=tx_loop)
+        t.start()
+        got = np.zeros(nblk * blk, dtype=np.complex64)
+        plain = np.zeros(blk, dtype=np.complex64)
+        times = []
+        for i in range(nblk):
+            buf = pin_rx if i % 2 else plain
+            r = dev.readStream(rx, [buf], blk)
+            if r.ret != blk:
+                errors.append(("rx", i, r.ret))
+            times.append(r.timeNs)
+            got[i * blk:(i + 1) * blk] = buf
+        t.join()
+        assert not errors, errors
+        assert times == [oracle.ticks_to_time_ns(i * blk, rate) for i in range(nblk)]
+        h = sxxcvr_amd.design_lowpass(128, 4)
+        ref = oracle.decim_f32(h, 4, oracle.synth_iq_mt(SEED, 0, 0, 4 * nblk * blk, 8), 2, 4, threads=8)
+        assert_bit_exact(got, ref, "threaded rx stream, megabyte blocks")
+        assert int(dev.readSetting("TX_WRITTEN")) == nblk * blk
+        assert int(dev.readSetting("TX_PTT_SAMPLES")) == nblk * keyed_per_block
+    finally:
+        sxxcvr_amd.unpin_array(pin_rx)
+        sxxcvr_amd.unpin_array(pin_tx)
+
+
 def test_multi_channel_device(oracle):
     """Device argument channels=N (the reference has one channel, SX.cpp:1591-1595; BASELINE config 4 puts
     8 on a GPU): one stream carries all N channels, buffs[c] = channel c of the synthetic source, and the TX
