@@ -31,6 +31,7 @@
 #include <sxfir.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -276,6 +277,7 @@ public:
     {
         next_ = -1;
         slot_[0].n = slot_[1].n = 0;
+        grown_ = 0;
     }
 
     // Deliver decimated stream samples [pos, pos+n) of every channel (stream rate) to host memory as
@@ -340,9 +342,14 @@ public:
                 const int64_t following = s.n ? s.pos + (int64_t)s.n : p;
                 cur_ ^= 1;
                 if (slot_[cur_].n == 0) launch(cur_, following, batch_);
+                else if (waited(cur_) && grown_ < max_batch_) {
+                    // the reader caught up with the batch in flight: a caller faster than one GPU round trip per
+                    // batch (no sample clock holding it back) gets batches twice as long from here on
+                    grown_ = std::max(grown_, batch_) * 2;
+                }
                 wait(cur_);
                 // ... and the batch after it goes in flight while the host hands this one out
-                batch_ = pick_batch(n);
+                batch_ = std::min(max_batch_, std::max(pick_batch(n), grown_));
                 launch(cur_ ^ 1, slot_[cur_].pos + (int64_t)slot_[cur_].n, batch_);
                 continue;
             }
@@ -526,6 +533,15 @@ private:
         return have;
     }
 
+    // wait for THIS slot's pass; true when the host really had to wait for it (more than a few microseconds)
+    bool waited(int k)
+    {
+        if (slot_[k].ready || slot_[k].in_hbm) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        wait(k);
+        return std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(3);
+    }
+
     // wait for THIS slot's pass only: the batch read ahead behind it stays in flight
     void wait(int k)
     {
@@ -572,6 +588,7 @@ private:
     int cur_;
     size_t batch_, max_batch_;
     int64_t direct_samples_ = 0;     // samples that reached page-locked caller memory without a host copy
+    size_t grown_ = 0;               // batch length a reader that outran the read-ahead has earned (0 = none)
     bool dst_locked_ = false;        // this call's destination is page-locked (and laid out for direct stores)
     bool prefer_hbm_ = false;        // the last megabyte-sized read went to page-locked memory
 };
@@ -674,6 +691,7 @@ public:
         written_ = 0;
         zero_keyed();
         data_.clear();
+        flush_frames_ = kFlushFrames;
     }
 
     // Stream samples [pos, pos+n) of every channel from host memory (srcs[c]).  Positions the
@@ -734,8 +752,13 @@ private:
         while (done < n) {
             if (pend_ == 0 && busy_[slot_]) {
                 // the slot's last H2D may still be reading it: wait for THAT pass only, not for the newer ones
+                const auto t0 = std::chrono::steady_clock::now();
                 gpu_check(sxfir_event_sync(done_[slot_]), "sxfir_event_sync");
                 busy_[slot_] = false;
+                // a writer that comes round to a slot still in use is faster than one GPU pass per kFlushFrames
+                // samples (no sample clock holding it back): gather twice as much per pass from here on
+                if (flush_frames_ < slot_frames_ && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(3))
+                    flush_frames_ *= 2;
             }
             const size_t m = std::min(slot_frames_ - pend_, n - done);
             float *host = stage_.floats() + 2 * slot_frames_ * (size_t)nchan_ * (size_t)slot_;
@@ -752,7 +775,7 @@ private:
             pend_ += m;
             accepted_ += (int64_t)m;
             done += m;
-            if (pend_ >= kFlushFrames) flush();
+            if (pend_ >= flush_frames_) flush();
         }
     }
 
@@ -902,6 +925,7 @@ private:
     int cur_in_ = 0;
     CopyPool pool_;
     size_t slot_frames_, max_slot_frames_;
+    size_t flush_frames_ = kFlushFrames;                  // samples gathered before a GPU pass; grows for writers that outrun the passes
     void *direct_done_;
     int64_t direct_samples_ = 0;                          // samples taken straight from page-locked caller memory
     DeviceBuffer keyed_;                                  // the keying counter (device memory, read back on demand)
