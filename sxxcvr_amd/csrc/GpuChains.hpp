@@ -43,53 +43,11 @@
 #include <thread>
 #include <vector>
 
-#if defined(__x86_64__) || defined(__i386__)
-#include <emmintrin.h>
-#define SX_HAVE_SSE2_STREAM 1
-#endif
-
 namespace sx {
 
 inline void gpu_check(int rc, const char *what)
 {
     if (rc != SXFIR_OK) throw std::runtime_error(std::string(what) + ": " + sxfir_last_error());
-}
-
-// Copy into pinned staging that the GPU will read next and the CPU will not: non-temporal stores, so that the
-// destination lines are neither fetched for ownership first nor left in the cache (a plain memcpy of 32 KiB ...
-// 4 MiB into the TX slots ran at 10 GB/s on one core for that reason).  Small blocks: plain memcpy.
-inline void copy_streaming(void *dst, const void *src, size_t bytes)
-{
-#ifdef SX_HAVE_SSE2_STREAM
-    if (bytes >= (size_t(16) << 10)) {
-        char *d = static_cast<char *>(dst);
-        const char *s = static_cast<const char *>(src);
-        const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
-        if (head) {
-            std::memcpy(d, s, head);
-            d += head;
-            s += head;
-            bytes -= head;
-        }
-        size_t n64 = bytes / 64;
-        while (n64--) {
-            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s));
-            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + 16));
-            const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + 32));
-            const __m128i e = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + 48));
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d), a);
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + 16), b);
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + 32), c);
-            _mm_stream_si128(reinterpret_cast<__m128i *>(d + 48), e);
-            s += 64;
-            d += 64;
-        }
-        _mm_sfence();
-        if (bytes % 64) std::memcpy(d, s, bytes % 64);
-        return;
-    }
-#endif
-    std::memcpy(dst, src, bytes);
 }
 
 // memcpy of large blocks by a few PERSISTENT threads: one core moves ~10 GB/s between pageable caller memory and
@@ -130,12 +88,10 @@ public:
     unsigned threads() const { return nthreads_; }
     size_t parallel_copies() const { return parallel_copies_; }
 
-    // streaming: the destination is pinned staging for the GPU (copy_streaming)
-    void copy(void *dst, const void *src, size_t bytes, bool streaming = false)
+    void copy(void *dst, const void *src, size_t bytes)
     {
         if (bytes < parallel_from_ || nthreads_ < 2) {
-            if (streaming) copy_streaming(dst, src, bytes);
-            else std::memcpy(dst, src, bytes);
+            std::memcpy(dst, src, bytes);
             return;
         }
         const size_t parts = std::min<size_t>(nthreads_, bytes / (parallel_from_ / 4));
@@ -150,13 +106,12 @@ public:
                 const size_t off = piece * i;
                 if (off >= bytes) break;
                 jobs_[i - 1] = Job{static_cast<char *>(dst) + off, static_cast<const char *>(src) + off,
-                                   std::min(piece, bytes - off), true, streaming};
+                                   std::min(piece, bytes - off), true};
                 ++remaining_;
             }
         }
         work_.notify_all();
-        if (streaming) copy_streaming(dst, src, std::min(piece, bytes));      // the caller takes the first piece
-        else std::memcpy(dst, src, std::min(piece, bytes));
+        std::memcpy(dst, src, std::min(piece, bytes));      // the caller takes the first piece
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [this] { return remaining_ == 0; });
         ++parallel_copies_;
@@ -168,7 +123,6 @@ private:
         const char *src = nullptr;
         size_t bytes = 0;
         bool pending = false;
-        bool streaming = false;
     };
 
     void serve(unsigned i)
@@ -180,8 +134,7 @@ private:
             const Job j = jobs_[i];
             jobs_[i].pending = false;
             lk.unlock();
-            if (j.streaming) copy_streaming(j.dst, j.src, j.bytes);
-            else std::memcpy(j.dst, j.src, j.bytes);
+            std::memcpy(j.dst, j.src, j.bytes);
             lk.lock();
             if (--remaining_ == 0) done_.notify_one();
         }
@@ -648,8 +601,10 @@ public:
     static constexpr int kSlots = 4;
     // A pass whose input is at least this large crosses PCIe as DMA-engine copies into HBM before the kernels run
     // (57 GB/s on the boxes measured, and the interpolator and the keying count both read HBM); smaller ones are
-    // read in place from the pinned slot by the kernels themselves (nothing to queue, lowest latency; a threshold of
-    // 128 KiB was measured: mid-size writes halve their rate, the host then waits for the input blocks).
+    // read in place from the pinned slot by the kernels themselves (nothing to queue, lowest latency).  Measured
+    // alternatives for the blocks in between (32 KiB ... 512 KiB, 1.25 GS/s = two PCIe reads of the slot per pass,
+    // interpolator and keying count): a DMA threshold of 128 KiB halves their rate (the host then waits for the
+    // input blocks), non-temporal stores into the slot change nothing (the copy is not what limits them).
     static constexpr size_t kH2dFromBytes = size_t(1) << 20;
     static constexpr size_t kDirectFrom = 1u << 15;    // writes at least this long are taken straight from page-locked caller memory
 
@@ -812,7 +767,7 @@ private:
             float *host = stage_.floats() + 2 * slot_frames_ * (size_t)nchan_ * (size_t)slot_;
             for (int c = 0; c < nchan_; ++c) {
                 float *dst = host + 2 * ((size_t)c * slot_frames_ + pend_);
-                if (srcs) pool_.copy(dst, srcs[c] + 2 * done, 8 * m, true);
+                if (srcs) pool_.copy(dst, srcs[c] + 2 * done, 8 * m);
                 else std::memset(dst, 0, 8 * m);
             }
             if (srcs) {
