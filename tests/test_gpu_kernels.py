@@ -234,3 +234,48 @@ def test_s32_wire_words_through_the_multi_column_kernel(oracle, D, n_in):
         y1 = to_cpu(plan.process(wg[:n_in].clone()))
         y2 = to_cpu(plan.process(wg[n_in:].clone()))
         assert_bit_exact(np.concatenate([y1, y2]), ref, "S32 /%d kernel %d" % (D, kern))
+
+
+@pytest.mark.parametrize("name,mode,ntaps,ratio,fmt", [
+    ("config 2", "decim", 128, 4, "CF32"), ("config 3 RX", "decim", 256, 8, "CF32"), ("config 3 TX", "interp", 256, 8, "CF32"),
+    ("config 5", "decim", 1024, 32, "CF32"), ("config 5 CF16", "decim", 1024, 32, "CF16"), ("÷16", "decim", 512, 16, "CF32"),
+])
+def test_every_configuration_against_scipy_fp64(name, mode, ntaps, ratio, fmt):
+    """An anchor that does not pass through the repo's oracle: scipy.signal.upfirdn in float64 on random input
+    computed on the spot, against the GPU path.  Tolerance 2e-6 * sum|h| for fp32 storage (round-off of a 1024-term
+    fp32 sum in the kernels' order stays an order of magnitude below it), half-precision storage adds the rounding
+    of the stored samples (2^-11 relative, input and output)."""
+    import torch
+    from scipy.signal import upfirdn
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE
+    rng = np.random.default_rng(1234 + ntaps + ratio)
+    decim = mode == "decim"
+    n_in = (1 << 16) + 37 * ratio if decim else (1 << 13) + 5
+    x = (rng.uniform(-1, 1, n_in) + 1j * rng.uniform(-1, 1, n_in)).astype(np.complex64)
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, 1.0 if decim else float(ratio))
+    plan = sxxcvr_amd.Resampler(DECIMATE if decim else INTERPOLATE, h, ratio, fmt=fmt)
+    if fmt == "CF16":
+        x16 = x.view(np.float32).astype(np.float16)
+        xt = torch.from_numpy(x16.view(np.int32).copy()).cuda()
+        x_used = x16.astype(np.float32).view(np.complex64)      # what the kernel filters: the stored halves, exactly
+    else:
+        xt = torch.from_numpy(x).cuda()
+        x_used = x
+    y = plan.process(xt)
+    torch.cuda.synchronize()
+    if fmt == "CF16":
+        got = y.cpu().numpy().view(np.float16).astype(np.float64)
+        got = got[0::2] + 1j * got[1::2]
+    else:
+        got = y.cpu().numpy().astype(np.complex128)
+    h64 = h.astype(np.float64)
+    if decim:
+        want = upfirdn(h64, x_used.astype(np.complex128), up=1, down=ratio)[: len(got)]
+    else:
+        want = upfirdn(h64, x_used.astype(np.complex128), up=ratio, down=1)[: len(got)]
+    assert len(got) == (n_in + ratio - 1) // ratio if decim else len(got) == n_in * ratio
+    tol = 2.0e-6 * float(np.abs(h64).sum())
+    if fmt == "CF16":
+        tol += 2.0 ** -11 * float(np.abs(want).max())             # the one rounding of each output to half
+    err = float(np.abs(got - want).max())
+    assert err <= tol, "%s: max |GPU - scipy fp64| = %.3g > %.3g" % (name, err, tol)
