@@ -89,6 +89,32 @@ def test_whole_stream_decimators_cf32(fast_oracle, name, ntaps, ratio):
     print("%s: %d outputs compared bit for bit" % (name, compared))
 
 
+def test_whole_stream_config4_slice_eight_channels(fast_oracle):
+    """BASELINE config 4 as one GPU sees it: 8 independent channels x 2^25 samples in one launch (blockIdx.y =
+    channel), the slice every rank of `bench.py --gpus N` runs.  Every output of every channel is compared; the
+    channels are those of rank 3 (24..31) so that the channel index is not confused with the row index."""
+    import torch
+    _enough_memory(8)
+    orc = fast_oracle
+    nchan, first = 8, 24
+    n = 1 << (LOG2N - 3)
+    threads = orc.max_threads()
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    x = torch.empty((nchan, n), dtype=torch.complex64, device="cuda")
+    sxxcvr_amd.synth_fill(x, SEED, first, 0)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, nchan=nchan)
+    y = plan.process(x)
+    torch.cuda.synchronize()
+    del x
+    compared = 0
+    for c in range(nchan):
+        xs = orc.synth_iq_mt(SEED, first + c, 0, n, threads)
+        ref = orc.decim_f32(h, 4, xs, *plan.contract, threads=threads).view(np.uint64)
+        compared += _compare_blocks(y[c].cpu().numpy().view(np.uint64), ref, "config 4 slice, channel %d" % (first + c))
+    assert compared == nchan * (n // 4)
+    print("config 4 slice: %d outputs compared bit for bit" % compared)
+
+
 def test_whole_stream_interpolator_config3_tx(fast_oracle):
     import torch
     _enough_memory(8)
