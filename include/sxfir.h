@@ -46,7 +46,9 @@
 extern "C" {
 #endif
 
-#define SXFIR_ABI_VERSION 1
+/* 2: sxfir_stream_wait_event, timing events, clock probe, host registration and the keying count were added
+ * (round 2); nothing was removed or changed, a caller built against 1 keeps working. */
+#define SXFIR_ABI_VERSION 2
 
 enum {
     SXFIR_OK = 0,
