@@ -7,6 +7,6 @@ libraries and mirrors the reference's Python-facing call pattern; there is no
 CPU implementation and nothing here imports the oracle.
 """
 from ._native import NativeError, load_sxfir  # noqa: F401
-from .resampler import Resampler, design_lowpass, pin_array, synth_fill, unpin_array  # noqa: F401
+from .resampler import PipelinedResampler, Resampler, design_lowpass, pin_array, synth_fill, unpin_array  # noqa: F401
 
-__all__ = ["NativeError", "load_sxfir", "Resampler", "design_lowpass", "synth_fill", "pin_array", "unpin_array"]
+__all__ = ["NativeError", "load_sxfir", "Resampler", "PipelinedResampler", "design_lowpass", "synth_fill", "pin_array", "unpin_array"]

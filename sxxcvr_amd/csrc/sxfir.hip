@@ -424,6 +424,19 @@ int sxfir_reset(sxfir_plan *p, void *stream)
     return SXFIR_OK;
 }
 
+int sxfir_set_history(sxfir_plan *p, const void *src_dev, size_t n, size_t stride, void *stream)
+{
+    if (!p || !src_dev) return fail(SXFIR_EINVAL, "NULL argument");
+    if (n < (size_t)p->hist_len) return fail(SXFIR_EINVAL, "history needs %d samples per channel, %zu given", p->hist_len, n);
+    if (p->nchan > 1 && stride < n) return fail(SXFIR_EINVAL, "channel stride %zu shorter than the block (%zu)", stride, n);
+    const size_t sb = sample_bytes(p->fmt);
+    // the LAST hist_len samples of the block, channel by channel
+    const char *src = static_cast<const char *>(src_dev) + sb * (n - (size_t)p->hist_len);
+    HIPCHECK(hipMemcpy2DAsync(p->hist_dev, sb * (size_t)p->hist_len, src, sb * stride, sb * (size_t)p->hist_len, (size_t)p->nchan,
+                              hipMemcpyDeviceToDevice, S(stream)));
+    return SXFIR_OK;
+}
+
 int sxfir_set_kernel(sxfir_plan *p, int kernel)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");

@@ -152,6 +152,11 @@ class Resampler:
     def reset(self, stream=None):
         self._ck(self._lib.sxfir_reset(self._plan, C.c_void_p(stream or 0)))
 
+    def set_history_ptr(self, src_ptr, n, stride, stream=0):
+        """The filter state becomes the last samples of the device block [src_ptr, src_ptr + n) of every channel
+        (sxfir_set_history): as if that block had just been processed."""
+        self._ck(self._lib.sxfir_set_history(self._plan, C.c_void_p(src_ptr), n, stride, C.c_void_p(stream)))
+
     # -- raw pointers ---------------------------------------------------------
     def process_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, stream=0):
         n_out = C.c_size_t()
@@ -237,3 +242,46 @@ class Resampler:
             lib.sxfir_free(din)
             lib.sxfir_free(dout)
         return y[0] if squeeze else y
+
+
+class PipelinedResampler:
+    """Consecutive blocks of ONE stream on `depth` plans and `depth` HIP streams in turn, so that their passes
+    overlap on the GPU.  Block k+1 needs nothing of block k but the tail of its INPUT, which is in device memory
+    before either pass runs: each plan's filter state is seeded from there (sxfir_set_history) and the passes are
+    independent launches.  The ramp-up and the tail of a launch cost ~7 % of a 2^28-sample pass of the /4 kernel;
+    several passes in flight hide them.  The outputs are those of one plan fed block by block.
+
+    The caller keeps every input block unchanged until the pass over the NEXT block has run (join() waits for all)."""
+
+    def __init__(self, mode, taps, ratio, nchan=1, fmt="CF32", device=-1, depth=4):
+        import torch
+        self.depth = int(depth)
+        self.plans = [Resampler(mode, taps, ratio, nchan=nchan, fmt=fmt, device=device) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=None if device < 0 else device) for _ in range(self.depth)]
+        self._k = 0
+        self._prev = None                                   # (ptr, n, stride) of the previous input block
+
+    @property
+    def contract(self):
+        return self.plans[0].contract
+
+    def restart(self):
+        """The next block is the first of a new stream (zero history)."""
+        self._prev = None
+
+    def process_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride):
+        """Queue the pass over one block; returns its output count.  Asynchronous: join() before using outputs."""
+        k = self._k % self.depth
+        plan, st = self.plans[k], self.streams[k].cuda_stream
+        if self._prev is None:
+            plan.reset(st)
+        else:
+            plan.set_history_ptr(self._prev[0], self._prev[1], self._prev[2], st)
+        n_out = plan.process_ptr(in_ptr, n_in, in_stride, out_ptr, out_stride, st)
+        self._prev = (in_ptr, n_in, in_stride)
+        self._k += 1
+        return n_out
+
+    def join(self):
+        for s in self.streams:
+            s.synchronize()

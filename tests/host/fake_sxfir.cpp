@@ -95,6 +95,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
 
 int sxfir_destroy(sxfir_plan *p) { delete p; return SXFIR_OK; }
 int sxfir_reset(sxfir_plan *p, void *) { std::fill(p->hist.begin(), p->hist.end(), 0.0f); return SXFIR_OK; }
+int sxfir_set_history(sxfir_plan *, const void *, size_t, size_t, void *) { g_err = "not in the fake"; return SXFIR_EUNSUPPORTED; }
 int sxfir_set_tx_threshold(sxfir_plan *p, float t) { p->thr2 = t; return SXFIR_OK; }
 
 int sxfir_synth_fill(void *out_dev, size_t n, size_t stride, int nchan, uint64_t seed, uint32_t first_channel,

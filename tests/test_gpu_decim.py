@@ -310,3 +310,52 @@ def test_history_longer_than_2048_samples(oracle, mode):
     got = np.concatenate(outs, axis=1)
     for c in range(2):
         assert_bit_exact(got[c], refs[c], "%s, long history, channel %d" % (mode, c))
+
+
+@pytest.mark.parametrize("mode,ntaps,ratio,fmt", [("decim", 128, 4, "CF32"), ("decim", 256, 8, "CF32"), ("interp", 256, 8, "CF32"),
+                                                   ("decim", 1024, 32, "CF16"), ("decim", 128, 4, "S32")])
+def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ratio, fmt):
+    """sxfir_set_history seeds a plan from the tail of the previous INPUT block, so consecutive blocks of one stream
+    can run on several plans and HIP streams at once (PipelinedResampler).  Seven ragged blocks on three plans:
+    every output equals what ONE plan produces fed block by block (which the other tests pin to the oracle)."""
+    import torch
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE
+    decim = mode == "decim"
+    m = DECIMATE if decim else INTERPOLATE
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, 1.0 if decim else float(ratio))
+    unit = ratio if decim else 1
+    blocks = [unit * b for b in (4096, 1024, 8192 + 8, 520, 4096, 64, 2048)]
+    if not decim:
+        blocks = [b // 4 + 32 for b in blocks]
+    total = sum(blocks)
+    nchan = 2
+    dt = torch.complex64 if fmt == "CF32" else (torch.int32 if fmt == "CF16" else torch.int64)
+    if fmt == "S32":
+        x = torch.randint(-2**31, 2**31 - 1, (nchan, total, 2), dtype=torch.int32, device="cuda").view(torch.int64).reshape(nchan, total)
+    else:
+        x = torch.empty((nchan, total), dtype=dt, device="cuda")
+        sxxcvr_amd.synth_fill(x, 0x51255, 3, 0, fmt=fmt)
+    n_out_total = total // ratio if decim else total * ratio
+    odt = torch.complex64 if fmt in ("CF32", "S32") and decim else dt
+    if fmt == "S32":
+        odt = torch.complex64
+    one = sxxcvr_amd.Resampler(m, h, ratio, nchan=nchan, fmt=fmt)
+    want = torch.empty((nchan, n_out_total), dtype=odt, device="cuda")
+    got = torch.zeros_like(want)
+    pipe = sxxcvr_amd.PipelinedResampler(m, h, ratio, nchan=nchan, fmt=fmt, depth=3)
+    es_in, es_out = x.element_size(), want.element_size()
+    i0 = o0 = 0
+    st = torch.cuda.current_stream().cuda_stream
+    for b in blocks:
+        ob = b // ratio if decim else b * ratio
+        a = one.process_ptr(x.data_ptr() + es_in * i0, b, total, want.data_ptr() + es_out * o0, n_out_total, st)
+        c = pipe.process_ptr(x.data_ptr() + es_in * i0, b, total, got.data_ptr() + es_out * o0, n_out_total)
+        assert a == c == ob
+        i0 += b
+        o0 += ob
+    torch.cuda.synchronize()
+    pipe.join()
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+    # a plan refuses a block shorter than its history
+    with pytest.raises(Exception):
+        one.set_history_ptr(x.data_ptr(), 3, total, st)
