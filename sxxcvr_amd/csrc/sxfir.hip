@@ -625,6 +625,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                     "an output boundary");
     if (tiled) {
         sxfir::DecimTileArgs a;
+        a.long_waves = a.long_tiles = a.long_w8 = a.short_w8 = 0;
         a.in = (const float *)in_dev;
         a.hist = (const float *)p->hist_dev;
         a.hist_out = (float *)p->hist_alt;
@@ -758,6 +759,25 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
             }
         }
+#ifdef SXFIR_PROFILING
+        if (p->sched == 3 && p->ntaps == 128 && p->symmetric) {
+            // short tail: the last generation of long waves (one CU-filling set) is replaced by as many one-tile
+            // waves as it had tiles
+            const long long W = per_chan, passes = n_tiles / W;
+            const long long resident = (long long)p->compute_units * p->occ_sb / p->nchan;
+            if (passes >= 2 && n_tiles % W == 0 && W > resident && resident % 8 == 0) {
+                const long long glong = W - resident, gshort = resident * passes;
+                a.long_waves = (int)glong;
+                a.long_tiles = (int)(glong * passes);
+                a.long_w8 = (glong % 8 == 0) ? (int)(glong / 8) : 0;
+                a.short_w8 = (gshort % 8 == 0) ? (int)(gshort / 8) : 0;
+                per_chan = glong + gshort;
+                a.n_waves = (int)per_chan;
+                const int t = (int)(gshort - 1);                       // the last tile's place among the short waves
+                a.hist_wave = (int)glong + (a.short_w8 ? (t % a.short_w8) * 8 + t / a.short_w8 : t);
+            }
+        }
+#endif
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
 #ifdef SXFIR_PROFILING
         if (p->ablate == 11 || p->ablate == 12) {

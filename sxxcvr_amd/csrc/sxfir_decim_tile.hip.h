@@ -57,6 +57,9 @@ struct DecimTileArgs {
     int w8;                 // n_waves / 8 when n_waves is a multiple of 8, else 0 (sched 0)
     int run_base, run_extra;    // n_tiles / n_waves, n_tiles % n_waves (sched 1)
     int hist_wave;          // the wave whose tiles include the last one: it carries the history over
+    // short tail (scalar-tap kernel): waves [0, long_waves) make strided passes over the first long_tiles tiles,
+    // waves [long_waves, n_waves) take ONE tile each of the rest; long_waves == 0: every wave makes strided passes
+    int long_waves, long_tiles, long_w8, short_w8;
     unsigned long long *stamps;   // diagnostic builds only (ABL 11/12): per-wave {shader cycles, 100 MHz ticks}
     // the first 64 taps by value (scaled by 2^-31 for S32 wire-word plans): a scalar-tap kernel loads them from the
     // kernel-argument segment together with everything else, one scalar-load round trip instead of two

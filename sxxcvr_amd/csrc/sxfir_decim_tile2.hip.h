@@ -330,10 +330,26 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         tile_end = tile + a.run_base < a.n_tiles ? tile + a.run_base : a.n_tiles;
         tile_step = 1;
     } else {
-        const int S = (a.sched == 0 && a.w8) ? (b & 7) * a.w8 + (b >> 3) : b;
-        tile = S * WPG + ww;
-        tile_end = a.n_tiles;
-        tile_step = G * WPG;
+        if (WPG == 1 && a.long_waves > 0) {
+            // Short tail: the launch ends with one-tile waves, so that the CUs run empty over the life of a short
+            // wave instead of a long one; the long waves stride over the tiles before them.
+            if (b < a.long_waves) {
+                const int S = a.long_w8 ? (b & 7) * a.long_w8 + (b >> 3) : b;
+                tile = S;
+                tile_end = a.long_tiles;
+                tile_step = a.long_waves;
+            } else {
+                const int bs = b - a.long_waves;
+                tile = a.long_tiles + (a.short_w8 ? (bs & 7) * a.short_w8 + (bs >> 3) : bs);
+                tile_end = tile + 1 < a.n_tiles ? tile + 1 : a.n_tiles;
+                tile_step = 1;
+            }
+        } else {
+            const int S = (a.sched == 0 && a.w8) ? (b & 7) * a.w8 + (b >> 3) : b;
+            tile = S * WPG + ww;
+            tile_end = a.n_tiles;
+            tile_step = G * WPG;
+        }
     }
     if constexpr (CUQ) {
         if (threadIdx.x == 0) cuq_next = 0u;

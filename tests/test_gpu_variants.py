@@ -65,6 +65,27 @@ def test_variant_matches_oracle(oracle, monkeypatch, env):
 
 
 @pytest.mark.gpu
+def test_short_tail_schedule_matches_oracle(oracle, monkeypatch):
+    """SXFIR_SCHED=3: the launch ends with one-tile waves (the last CU-filling set of long waves is replaced by as
+    many short ones as it had tiles).  2^24 samples = 16384 tiles with two generations of waves, so that the split
+    applies; two calls, so that the short wave that owns the last tile carries the history over."""
+    import torch
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_SCHED", "3")
+    monkeypatch.setenv("SXFIR_OVERSUB", "2")
+    h = sxxcvr_amd.design_lowpass(128, 4)
+    n = 1 << 24
+    x = oracle.synth_iq_mt(0x51255, 9, 0, 2 * n, 8)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    y1 = to_cpu(plan.process(to_gpu(x[:n])))
+    y2 = to_cpu(plan.process(to_gpu(x[n:])))
+    ref = oracle.decim_f32(h, 4, x, 2, 4, threads=8)
+    assert_bit_exact(np.concatenate([y1, y2]), ref, "short-tail schedule")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,n_in", [(4, 70000), (8, 1 << 16), (16, 50000), (32, 4096 * 5 + 32 * 3)])
 def test_quarter_row_split_variant(oracle, monkeypatch, D, n_in):
     """SXFIR_MULTI_PS=4: the multi-column decimator with the 32 tap rows split over four lanes.  The plan
