@@ -347,9 +347,6 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=28, help="wideband-side samples per GPU (log2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-through-device", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=8,
-                    help="depth of the extra pipelined-passes measurement (consecutive blocks on several plans and "
-                         "HIP streams, reported beside the value; 0 = skip)")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
@@ -476,48 +473,6 @@ def main():
         t = torch.tensor([1.0 if verified else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         verified = bool(t.item() > 0.5)
-    # Extra, after the measurement above and never part of `value`: the same stream of blocks with several passes
-    # in flight (PipelinedResampler: `depth` plans on `depth` HIP streams, each seeded from the tail of the previous
-    # INPUT block, so consecutive passes are independent launches and overlap).  It hides the ramp-up and the tail
-    # of a launch; a kernel's own duration is then no longer the inverse of the throughput, which is why the
-    # roofline block stays with the one-launch-at-a-time figures.
-    pipelined = None
-    if args.pipeline > 1 and world == 1:
-        try:
-            depth = args.pipeline
-            pr = sxxcvr_amd.PipelinedResampler(DECIMATE if decim else INTERPOLATE, taps, ratio, nchan=nchan_local,
-                                               fmt=cfg["fmt"], device=gpu_index, depth=depth)
-            outs = [y] + [torch.empty_like(y) for _ in range(depth - 1)]
-            torch.cuda.synchronize()
-
-            def pstep(i):
-                pr.process_ptr(x.data_ptr(), n_in, xs, outs[i % depth].data_ptr(), ys)
-
-            for i in range(max(60, 2 * depth)):
-                pstep(i)
-            pr.join()
-            npass = max(args.steps, 60)
-            first = max(60, 2 * depth)
-            t0 = time.perf_counter()
-            for i in range(first, first + npass):
-                pstep(i)
-            pr.join()
-            dtp = time.perf_counter() - t0
-            okp, _ = verify(cfg, plan, x, outs[(first + npass - 1) % depth], n_in, lo, True, orc)
-            ms_pass = dtp / npass * 1e3
-            pipelined = {
-                "depth": depth, "passes": npass, "ms_per_pass": round(ms_pass, 4),
-                "MS/s": round(wide_per_gpu / ms_pass / 1e3, 1),
-                "algorithmic_GB/s": round(cfg["bytes"] * wide_per_gpu / (ms_pass * 1e-3) / 1e9, 1),
-                "of_8TB/s_by_throughput": round(cfg["bytes"] * wide_per_gpu / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "verified": bool(okp),
-                "note": "consecutive blocks of the stream on %d plans / HIP streams at once (sxfir_set_history seeds each "
-                        "from the previous input's tail); throughput of overlapping launches, not a kernel duration: "
-                        "not part of value or roofline" % depth,
-            }
-            del outs, pr
-        except Exception as e:                                  # reported, never fatal for the line
-            pipelined = {"error": repr(e)}
     achieved = cfg["bytes"] * wide_per_gpu / (kernel_ms * 1e-3) / 1e9
     tflops = cfg["flop"] * wide_per_gpu / (kernel_ms * 1e-3) / 1e12
 
@@ -595,8 +550,6 @@ def main():
                                         "see roofline.valu")
         if gather is not None:
             line["gather"] = gather
-        if pipelined is not None:
-            line["pipelined_passes"] = pipelined
         if world == 1 and not args.no_through_device:
             try:
                 line["through_device"] = through_device()

@@ -97,9 +97,9 @@ int sxfir_reset(sxfir_plan *plan, void *stream);
 /* Seed the filter state from samples already in device memory: the plan's history becomes the LAST samples of
  * the block [src_dev, src_dev + n) of every channel (channel c at c*stride samples; n >= the plan's history
  * length: ntaps for a decimator, ntaps/ratio for an interpolator), as if that block had just been processed.
- * With it consecutive blocks of one stream can be handed to SEVERAL plans on several HIP streams -- block k+1 needs
- * nothing from block k but the tail of its INPUT, which is in memory before either runs -- so that their passes
- * overlap (the ramp-up and the tail of a launch cost 7 % of a 2^28-sample pass; sxxcvr_amd.PipelinedResampler). */
+ * With it consecutive blocks of one stream can be handed to SEVERAL plans (on several HIP streams or GPUs): block
+ * k+1 needs nothing from block k but the tail of its INPUT, which is in memory before either runs
+ * (sxxcvr_amd.PipelinedResampler).  No speed-up on one GPU: DESIGN.md 7. */
 int sxfir_set_history(sxfir_plan *plan, const void *src_dev, size_t n, size_t stride, void *stream);
 int sxfir_set_kernel(sxfir_plan *plan, int kernel);
 /* Squared-magnitude threshold above which an SXFIR_S32 interpolator sets the two low bits of the I

@@ -248,8 +248,8 @@ class PipelinedResampler:
     """Consecutive blocks of ONE stream on `depth` plans and `depth` HIP streams in turn, so that their passes
     overlap on the GPU.  Block k+1 needs nothing of block k but the tail of its INPUT, which is in device memory
     before either pass runs: each plan's filter state is seeded from there (sxfir_set_history) and the passes are
-    independent launches.  The ramp-up and the tail of a launch cost ~7 % of a 2^28-sample pass of the /4 kernel;
-    several passes in flight hide them.  The outputs are those of one plan fed block by block.
+    independent launches.  The outputs are those of one plan fed block by block.  (On one GPU this buys nothing once
+    every block is new data -- DESIGN.md 7 -- it is the way to split one stream over plans or GPUs.)
 
     The caller keeps every input block unchanged until the pass over the NEXT block has run (join() waits for all)."""
 

@@ -41,9 +41,6 @@ def test_bench_line_every_config(config):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 300.0 < r["shader_mhz"] < 2600.0
     assert line["value"] > 0 and r["kernel_ms"] > 0
-    pp = line["pipelined_passes"]
-    assert "error" not in pp, pp
-    assert pp["verified"] is True and pp["depth"] == 8 and pp["ms_per_pass"] > 0
 
 
 def test_bench_reports_device_and_cpu_figures():

@@ -11,7 +11,9 @@ from sxxcvr_amd.resampler import DECIMATE
 
 n = 1 << 28
 h = sxxcvr_amd.design_lowpass(128, 4)
+DISTINCT = os.environ.get("OP_DISTINCT", "0") == "1"     # every stream reads its own copy of the input (no cache sharing between passes)
 x = torch.empty(n, dtype=torch.complex64, device="cuda"); sxxcvr_amd.synth_fill(x, 0x51255, 0, 0)
+xs = [x] + [x.clone() if DISTINCT else x for _ in range(7)]
 ys = [torch.empty(n // 4, dtype=torch.complex64, device="cuda") for _ in range(8)]
 plans = [sxxcvr_amd.Resampler(DECIMATE, h, 4) for _ in range(8)]
 streams = [torch.cuda.Stream() for _ in range(8)]
@@ -20,7 +22,7 @@ streams = [torch.cuda.Stream() for _ in range(8)]
 def run(nstreams, steps):
     for i in range(steps):
         k = i % nstreams
-        plans[k].process_ptr(x.data_ptr(), n, n, ys[k].data_ptr(), n // 4, streams[k].cuda_stream)
+        plans[k].process_ptr(xs[k].data_ptr(), n, n, ys[k].data_ptr(), n // 4, streams[k].cuda_stream)
 
 
 def timed(nstreams, steps=60):
@@ -32,6 +34,7 @@ def timed(nstreams, steps=60):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+print("distinct input buffers per stream:", DISTINCT)
 for rep in range(2):
     for ns in (1, 2, 3, 4, 6, 8):
         ms = timed(ns)
