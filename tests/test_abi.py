@@ -79,3 +79,25 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIBDIR", str(tmp_path))
     with pytest.raises(ImportError):
         _native.load_sxfir()
+
+
+def test_header_version_is_the_library_version():
+    """One number, written once (include/sxfir.h): the library and the entry point both follow it."""
+    import __graft_entry__ as entry
+    text = open(os.path.join(ROOT, "include", "sxfir.h")).read()
+    want = int(re.search(r"^#define\s+SXFIR_ABI_VERSION\s+(\d+)", text, re.M).group(1))
+    assert entry.header_abi_version() == want
+    assert sxxcvr_amd.load_sxfir().sxfir_abi_version() == want
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert not re.search(r"sxfir_abi_version\(\)\s*==\s*\d", src), "a literal ABI number in the entry point"
+
+
+def test_build_entry_point_runs():
+    """__graft_entry__.build() end to end in a fresh interpreter: product libraries, the oracle, CMake."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for name in ("libsxfir.so", "libSXSupport.so"):
+        assert os.path.exists(os.path.join(ROOT, "sxxcvr_amd", "lib", name))
