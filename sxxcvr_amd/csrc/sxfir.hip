@@ -47,6 +47,7 @@
 #define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
 #endif
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
+#include "sxfir_decim_dense.hip.h"
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
 #ifdef SXFIR_PROFILING
@@ -94,6 +95,7 @@ struct sxfir_plan {
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
+    bool dense32;          // decim32_dense_kernel (ratio 32, 1024 taps, CF32 / S32): the linear-image form
     int multi_waves;       // waves per workgroup of the multi kernel
     int multi_ps;          // lanes that share the 32 tap rows of one output (2 or 4) in the multi kernel
     int occ_multi;         // resident workgroups per CU of the multi kernel
@@ -251,6 +253,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // halo stays a small part of the staging
     p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
+    // ratio 32 (1024 taps) on CF32 / S32 words: the linear-image form (sxfir_decim_dense.hip.h), four workgroups
+    // per CU instead of three
+    p->dense32 = p->multi_capable && ratio == 32 && fmt != SXFIR_CF16;
     p->t2_wpg = p->t2_opt = 0;
     p->pair = false;
     p->pair_xsep = false;
@@ -273,7 +278,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             p->oversub = 8;
         }
     }
-    if (p->multi_capable && fmt != SXFIR_S32) {
+    if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
+    if (p->multi_capable && fmt != SXFIR_S32 && !p->dense32) {
         if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
         if (p->multi_ps == 4) p->multi_waves = ratio <= 4 ? 2 : (ratio == 8 ? 4 : 8);
         if (const char *v = getenv("SXFIR_MULTI_W")) p->multi_waves = atoi(v);
@@ -291,7 +297,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const int W = p->multi_waves;
         int nb = 0;
         const void *k = nullptr;
-        if (fmt == SXFIR_S32) {          // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
+        if (p->dense32) {
+            k = fmt == SXFIR_S32 ? (const void *)sxfir::decim32_dense_kernel<0, true>
+                                 : (const void *)sxfir::decim32_dense_kernel<0, false>;
+        } else if (fmt == SXFIR_S32) {   // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
             k = ratio == 8    ? (const void *)sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>
                 : ratio == 16 ? (const void *)sxfir::decim_multi_kernel<16, 4, false, 0, 2, true>
                               : (const void *)sxfir::decim_multi_kernel<32, 4, false, 0, 2, true>;
@@ -568,6 +577,26 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         a.stamps = nullptr;
+        if (p->dense32) {
+#ifdef SXFIR_PROFILING
+            if (p->ablate == 3) {
+                const size_t need = (size_t)groups * p->nchan * W;
+                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
+                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 40 * need));
+                p->stamps_n = need;
+                a.stamps = (unsigned long long *)p->stamps_dev;
+            }
+            if (p->fmt != SXFIR_S32 && p->ablate == 1) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<1, false>), grid, dim3(256), 0, st, a);
+            else if (p->fmt != SXFIR_S32 && p->ablate == 2) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<2, false>), grid, dim3(256), 0, st, a);
+            else if (p->fmt != SXFIR_S32 && p->ablate == 3) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<3, false>), grid, dim3(256), 0, st, a);
+            else
+#endif
+            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<0, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sxfir::decim32_dense_kernel<0, false>), grid, dim3(256), 0, st, a);
+            HIPCHECK(hipGetLastError());
+            *history_done = true;
+            return SXFIR_OK;
+        }
         if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 8: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;

@@ -1,0 +1,39 @@
+#!/bin/bash
+# One script for the GPU calls of a round (replaces the per-call run logs of round 2):
+#     gpurun --timeout 900 -- 'bash tools/gpu_steps.sh <tag> <step> [<step> ...]'
+# Each step appends to gpurun_out/<tag>/<step>.txt; what is worth keeping is copied to profiles/ by hand.
+# Steps (arguments after ':' are passed on, ',' separated):
+#   tests[:expr]        pytest -m gpu (optionally -k expr)
+#   bench[:config]      bench.py --config C (default 2) without the CPU legs
+#   benchfull           bench.py with everything (the driver's call)
+#   kb32 | kb32h | kb8 | kb16   kbench A/B of the /32 (CF32, CF16), /8, /16 kernels incl. ablations and stamps
+#   kb4                 the /4 production kernel + its memory side
+#   ib8                 interpolator x8 (tiled)
+#   pmc:D[,fmt]         LDS / VALU counters of one decimator shape (tools/pmc_pass.sh)
+#   profile:config      tools/profile_round.sh for one bench configuration
+#   power               board power / clock while the /4 kernel runs (tools/gpu_power.sh)
+set -u
+TAG=${1:?tag}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp KB_ROUNDS=${KB_ROUNDS:-5} KB_ITERS=${KB_ITERS:-20}
+for S in "$@"; do
+  NAME=${S%%:*}; ARG=""; [ "$S" != "$NAME" ] && ARG=${S#*:}
+  LOG=$OUT/$(echo $S | tr ':,/ ' '____').txt
+  echo "=== $S" | tee -a $LOG
+  case $NAME in
+    tests)    if [ -n "$ARG" ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q -k "$ARG" >> $LOG 2>&1; else timeout 2400 python3 -m pytest tests -m gpu -x -q >> $LOG 2>&1; fi; tail -5 $LOG ;;
+    bench)    timeout 600 python3 bench.py --config ${ARG:-2} --no-cpu-baseline --no-through-device >> $LOG 2>&1; tail -1 $LOG | cut -c1-1500 ;;
+    benchfull) timeout 900 python3 bench.py >> $LOG 2>&1; tail -1 $LOG | cut -c1-3000 ;;
+    kb32)     KB_D=32 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 dense:2:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -40 ;;
+    kb32h)    KB_D=32 KB_FMT=CF16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    kb8)      KB_D=8 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    kb16)     KB_D=16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    kb4)      KB_D=4 timeout 600 python3 tools/kbench.py x:16:0:0:0 t2.1.64:16:0:5:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    ib8)      KB_L=8 timeout 600 python3 tools/ibench.py >> $LOG 2>&1; tail -8 $LOG ;;
+    pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; tail -2 $LOG ;;
+    profile)  bash tools/profile_round.sh $TAG ${ARG:-2} >> $LOG 2>&1; tail -3 $LOG ;;
+    power)    bash tools/gpu_power.sh >> $LOG 2>&1; tail -20 $LOG ;;
+    *)        echo "unknown step $S" | tee -a $LOG ;;
+  esac
+done
