@@ -50,7 +50,7 @@ CONFIGS = {
                 kernel="sxfir::interp_tile_kernel<8>",
                 name="256-tap polyphase interp-by-8 TX, 1 ch CF32 streaming (BASELINE config 3, TX half)"),
     "5": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF32", bytes=8 + 8 / 32, flop=128, gain=1.0,
-              kernel="sxfir::decim_multi_kernel<32, 4>",
+              kernel="sxfir::decim32_dense_kernel",
               name="1024-tap decim-by-32, 1 ch CF32 streaming (BASELINE config 5, CF32 leg)"),
     "5h": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF16", bytes=4 + 4 / 32, flop=128, gain=1.0,
                kernel="sxfir::decim_multi_kernel<32, 4, CF16>",
@@ -95,6 +95,97 @@ def spawn_ranks(n):
             rc = rc or 1
         time.sleep(0.05)
     return rc
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Board telemetry beside the kernel: socket power, its cap, the GFX clock the SMU reports
+# ----------------------------------------------------------------------------------------------------------
+class BoardSampler:
+    """Side thread that reads the GPU's socket power and GFX clock every `period_s` while kernels run (amdsmi:
+    the library behind `amd-smi metric --power --clock`; falls back to the hwmon files).  What it supplies is the
+    driver-run evidence for DESIGN.md's "the package power cap sets the clock": power at the cap and a GFX clock
+    far under the 2.4 GHz the chip runs unloaded.  Never raises: a box without telemetry yields {"error": ...}."""
+
+    def __init__(self, gpu_index=0, period_s=0.02):
+        import threading
+        self.gpu_index, self.period = gpu_index, period_s
+        self.samples, self.cap_w, self.source, self.error = [], None, None, None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _open(self):
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[self.gpu_index]
+            try:
+                cap = amdsmi.amdsmi_get_power_cap_info(h)["power_cap"]
+                self.cap_w = cap / 1e6 if cap > 100000 else float(cap)
+            except Exception:
+                pass
+
+            def read():
+                pw = amdsmi.amdsmi_get_power_info(h)
+                w = pw.get("current_socket_power")
+                if not isinstance(w, (int, float)) or w <= 0:
+                    w = pw.get("socket_power")
+                if not isinstance(w, (int, float)) or w <= 0:
+                    w = pw.get("average_socket_power")
+                mhz = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"]
+                return float(w), float(mhz)
+
+            read()
+            self.source = "amdsmi"
+            return read
+        except Exception as e:
+            first = "%s: %s" % (type(e).__name__, e)
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+        if not cards:
+            self.error = "no telemetry (amdsmi: %s; no hwmon power1_average)" % first
+            return None
+        d = os.path.dirname(cards[min(self.gpu_index, len(cards) - 1)])
+        try:
+            self.cap_w = int(open(os.path.join(d, "power1_cap")).read()) / 1e6
+        except Exception:
+            pass
+
+        def read():
+            w = int(open(os.path.join(d, "power1_average")).read()) / 1e6
+            try:
+                mhz = int(open(os.path.join(d, "freq1_input")).read()) / 1e6
+            except Exception:
+                mhz = float("nan")
+            return w, mhz
+
+        self.source = "hwmon"
+        return read
+
+    def _run(self):
+        read = self._open()
+        if read is None:
+            return
+        while not self._stop.is_set():
+            try:
+                self.samples.append(read())
+            except Exception as e:
+                self.error = "%s: %s" % (type(e).__name__, e)
+                return
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(5.0)
+        if not self.samples:
+            return {"error": self.error or "no samples"}
+        w = sorted(s[0] for s in self.samples)
+        f = sorted(s[1] for s in self.samples)
+        return {"source": self.source, "samples": len(w), "power_w": round(w[len(w) // 2], 1),
+                "power_w_min": round(w[0], 1), "power_w_max": round(w[-1], 1), "power_cap_w": self.cap_w,
+                "gfx_mhz_smi": round(f[len(f) // 2], 0), "gfx_mhz_smi_min": round(f[0], 0), "gfx_mhz_smi_max": round(f[-1], 0)}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -420,6 +511,12 @@ def main():
     # Setup, untimed and independent of --warmup: let the chip's power management settle on this kernel (its
     # time swings 0.49 -> 0.84 -> 0.60 ms over the first ~20 launches); same launches
     # as a step, then the stream restarts at position 0.
+    # The first 20 launches on a chip that has been idle (what a bursty readStream caller sees, the pattern of
+    # example/linear_repeater.py:57-69): reported as roofline.kernel_ms_first_20, never part of `value`.
+    time.sleep(0.5)
+    kernel_ms_first_20 = plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, 20, stream)
+    plan.reset()
+    torch.cuda.synchronize()
     if args.settle > 0:
         plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, args.settle, stream)
         plan.reset()
@@ -462,6 +559,17 @@ def main():
     torch.cuda.synchronize()
     iters = min(max(args.steps, 40), 200)
     kernel_ms_loop = plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, iters, stream)
+    # ... for about a second more with the board's telemetry sampled beside it (socket power, its cap, the GFX
+    # clock the SMU reports: >= 10 samples) ...
+    board, kernel_ms_telemetry = {"error": "not sampled (rank > 0)"}, None
+    if rank == 0:
+        sampler = BoardSampler(gpu_index, 0.02)
+        sampler.start()
+        t_tel, tel_ms = time.perf_counter(), []
+        while time.perf_counter() - t_tel < 1.0:
+            tel_ms.append(plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, 100, stream))
+        board = sampler.stop()
+        kernel_ms_telemetry = sum(tel_ms) / len(tel_ms)
     # ... and once more with the in-kernel shader clock read beside it (a few probe waves on a second stream;
     # their presence costs the kernel a few per cent, so this pass only supplies the clock)
     probe = ClockProbe(gpu_index, 8000)
@@ -538,12 +646,19 @@ def main():
                 "shader_mhz": round(shader_mhz, 0),
                 "kernel_ms_how": "HIP events on the launch stream around the K timed steps (one launch per step) / K",
                 "kernel_ms_back_to_back_loop": round(kernel_ms_loop, 4),
+                "kernel_ms_first_20": round(kernel_ms_first_20, 4),
+                "kernel_ms_first_20_how": "the first 20 launches after 0.5 s of idle, before the settle launches: the "
+                                          "clock transient a bursty caller sees; not part of value",
+                "board": dict(board, kernel_ms_while_sampled=(round(kernel_ms_telemetry, 4)
+                                                              if kernel_ms_telemetry else None)),
                 "kernel_ms_beside_clock_probe": round(kernel_ms_probed, 4),
                 "valu": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs_at_2400MHz": VALU_PEAK_TFLOPS,
                          "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
                          "frac_at_measured_clock": round(tflops / (VALU_PEAK_TFLOPS * shader_mhz / 2400.0), 4)},
             },
         }
+        for k in ("power_w", "power_cap_w", "gfx_mhz_smi"):      # the board's own figures beside shader_mhz
+            line["roofline"][k] = board.get(k)
         if args.config == "5h":
             line["roofline"]["note"] = ("CF16 storage halves the bytes but not the 128 flop per sample: this leg is "
                                         "bound by fp32 VALU throughput at the clock the power management allows; "

@@ -6,9 +6,11 @@
 //
 // One wave = one workgroup; a tile is KT sub-tiles of QT = 128/NPH input samples
 // (512 outputs each), staged by one LDS-DMA round trip and computed one after
-// the other.  Lane = (p, c, g): tap-row half p (lane bit 5: j in
-// [16p, 16p+16)), phase group c (phases 4c..4c+3; lane bits below p), input
-// group g (4 consecutive inputs).  A lane holds its 64 taps in VGPRs and 32
+// the other.  Lane = (p, g, c): tap-row half p (lane bit 5: j in
+// [16p, 16p+16)), input group g (4 consecutive inputs), phase group c (phases
+// 4c..4c+3) in the LOWEST lane bits: the lanes of one g read the same window, so
+// each 16-lane service group of a ds_read_b128 touches few distinct addresses,
+// all in different banks (no conflicts from x8 up; tools/lds_bank_model.py).  A lane holds its 64 taps in VGPRs and 32
 // accumulators (4 inputs x 4 phases x I/Q); its window is 10 ds_read_b128
 // (the tile is tiny: <= 2.3 KiB of LDS, staged by LDS-DMA) for 256 v_pk_fma_f32.
 // The two row-half partials are exchanged with v_permlane32_swap and added
@@ -50,7 +52,19 @@ struct InterpTile {
     static constexpr int HIST = 32;
     static constexpr int CHUNKS = (TILE_IN + 32) / 2;     // staged: samples [q0 - 32, q0 + TILE_IN)
     static constexpr int NLOAD = (CHUNKS + 63) / 64;
+    static constexpr int CB = NPH == 8 ? 3 : (NPH == 4 ? 2 : (NPH == 2 ? 1 : 0));   // lane bits of c
     static_assert(L % 4 == 0 && (NPH & (NPH - 1)) == 0 && NPH <= 8, "L must be 4, 8, 16 or 32");
+    // Output transposition buffer: 256 chunks (512 outputs), chunk oc kept at slot oc ^ (some of its own higher
+    // bits), chosen so that the 8 consecutive lanes a ds_write_b128 is served with hit 8 different slots mod 8
+    // and the linear read-back stays conflict free: no pad slots.  Chunk index bits: bit 0 = which of a lane's
+    // two pieces, then c, the input of the pair, p, g.
+    static __device__ __forceinline__ int swz(int oc)
+    {
+        if (L == 4) return oc ^ ((oc >> 3) & 7);
+        if (L == 8) return oc ^ (((oc >> 4) & 1) | (((oc >> 5) & 1) << 2));
+        if (L == 16) return oc ^ ((oc >> 5) & 1);
+        return oc ^ ((oc >> 3) & 1);
+    }
 };
 
 // S32OUT: outputs leave as S32_LE I2S wire words with the keying bits (convert_tx_buffer, SoapySX.cpp:116-137)
@@ -58,17 +72,14 @@ template <int L, bool S32OUT = false>
 __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 {
     using C = InterpTile<L>;
-    // input image, then a 512-output (4 KiB) transpose buffer with one pad chunk after every 16
-    __shared__ __attribute__((aligned(16))) f32x4 lds[C::NLOAD * 64 + 256 + 16];
+    // input image, then the 512-output (4 KiB) transposition buffer
+    __shared__ __attribute__((aligned(16))) f32x4 lds[C::NLOAD * 64 + 256];
     f32x4 *obuf = lds + C::NLOAD * 64;
 
     const int lane = threadIdx.x;
     const int p = lane >> 5;
-    int c = 0;                                             // phase group: lane bits just below p
-    if (C::NPH >= 2) c |= (lane >> 4) & 1;
-    if (C::NPH >= 4) c |= ((lane >> 3) & 1) << 1;
-    if (C::NPH >= 8) c |= ((lane >> 2) & 1) << 2;
-    const int g = lane & (C::GW - 1);
+    const int c = lane & (C::NPH - 1);                     // phase group: the lowest lane bits
+    const int g = (lane >> C::CB) & (C::GW - 1);
     const int ch = blockIdx.y;
 
     const float *in = a.in + 2 * a.in_stride * ch;
@@ -172,15 +183,15 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int oc = ((4 * g + 2 * p + qi) * L + 4 * c) >> 1;          // chunk index inside the sub-tile
-            obuf[oc + (oc >> 4)] = (f32x4){oi[qi][0], oq[qi][0], oi[qi][1], oq[qi][1]};
-            obuf[oc + 1 + ((oc + 1) >> 4)] = (f32x4){oi[qi][2], oq[qi][2], oi[qi][3], oq[qi][3]};
+            obuf[C::swz(oc)] = (f32x4){oi[qi][0], oq[qi][0], oi[qi][1], oq[qi][1]};
+            obuf[C::swz(oc) ^ 1] = (f32x4){oi[qi][2], oq[qi][2], oi[qi][3], oq[qi][3]};
         }
         const long long o0 = (q0 + kt * C::QT) * L;                          // first output of the sub-tile
         const long long o_end = a.n_in * L;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int oc = 64 * k + lane;
-            f32x4 v = obuf[oc + (oc >> 4)];
+            f32x4 v = obuf[C::swz(oc)];
             if constexpr (S32OUT) {
                 const int2 w0 = tx_words(v.x, v.y, a.thr2), w1 = tx_words(v.z, v.w, a.thr2);
                 v = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};

@@ -11,6 +11,9 @@
 #   ib8                 interpolator x8 (tiled)
 #   pmc:D[,fmt]         LDS / VALU counters of one decimator shape (tools/pmc_pass.sh)
 #   profile:config      tools/profile_round.sh for one bench configuration
+#   clocks              tools/clock_calib.hip: shader clock by instruction count vs s_memtime / s_memrealtime
+#   pprobe[:D]          tools/power_probe.py: board power, caps and clocks, random vs all-zero input
+#   grbm                GRBM_GUI_ACTIVE-derived clock on a 0.5 ms and a 33 ms dispatch of the /4 kernel
 #   power               board power / clock while the /4 kernel runs (tools/gpu_power.sh)
 set -u
 TAG=${1:?tag}; shift
@@ -33,6 +36,10 @@ for S in "$@"; do
     ib8)      KB_L=8 timeout 600 python3 tools/ibench.py >> $LOG 2>&1; tail -8 $LOG ;;
     pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; tail -2 $LOG ;;
     profile)  bash tools/profile_round.sh $TAG ${ARG:-2} >> $LOG 2>&1; tail -3 $LOG ;;
+    clocks)   hipcc --offload-arch=gfx950 -O3 tools/clock_calib.hip -o /tmp/clock_calib >> $LOG 2>&1 && timeout 120 /tmp/clock_calib >> $LOG 2>&1; tail -9 $LOG ;;
+    pprobe)   timeout 300 python3 tools/power_probe.py ${ARG:-4} >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -6 ;;
+    grbm)     # GRBM_GUI_ACTIVE on a short (2^28) and a long (2^34 samples, ~33 ms) dispatch of the same kernel
+              for L in 28 34; do timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/grbm_$L -- python3 tools/onekernel.py 4 CF32 $L > /dev/null 2>&1; python3 tools/grbm_clock.py $OUT/grbm_$L $L >> $LOG 2>&1; done; find $OUT -name "*.csv" -size +1M -delete; tail -4 $LOG ;;
     power)    bash tools/gpu_power.sh >> $LOG 2>&1; tail -20 $LOG ;;
     *)        echo "unknown step $S" | tee -a $LOG ;;
   esac

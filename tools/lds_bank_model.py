@@ -7,6 +7,7 @@ pad slot after every PADROWS rows; chunk 14 - 2c + h of a row holds half h of co
 
     python tools/lds_bank_model.py            # the shipped lane map: extra LDS cycles per tile (expect 0)
     python tools/lds_bank_model.py search     # every assignment of (c0, c1, c2, p, g1, g0) to the lane bits
+    python tools/lds_bank_model.py interp     # interp_tile_kernel<L>: window reads, transposition writes, read-back
 """
 import itertools
 import sys
@@ -40,8 +41,46 @@ def extra_cycles(bits, padrows=16):
     return total
 
 
+WRITE_GROUPS = [list(range(8 * i, 8 * i + 8)) for i in range(8)]       # ds_write_b128: 8 x 8 contiguous lanes, 128 B wide
+
+
+def interp_swz(L, oc):
+    if L == 4: return oc ^ ((oc >> 3) & 7)
+    if L == 8: return oc ^ (((oc >> 4) & 1) | (((oc >> 5) & 1) << 2))
+    if L == 16: return oc ^ ((oc >> 5) & 1)
+    return oc ^ ((oc >> 3) & 1)
+
+
+def group_conflicts(groups, addr, mod):
+    total = 0
+    for grp in groups:
+        banks = {}
+        for lane in grp:
+            a = addr(lane)
+            banks.setdefault(a % mod, set()).add(a)
+        total += max(len(x) for x in banks.values()) - 1
+    return total
+
+
+def interp_model():
+    """sxfir_interp_tile.hip.h: lane = (p, g, c) with c in the lowest bits, XOR-swizzled transposition buffer."""
+    for L in (4, 8, 16, 32):
+        nph = L // 4
+        gw, cb = 32 // nph, nph.bit_length() - 1
+        dec = lambda l: (l >> 5, l & (nph - 1), (l >> cb) & (gw - 1))      # p, c, g
+        rd = sum(group_conflicts(GROUPS, lambda l: 2 * dec(l)[2] - 8 * dec(l)[0] + 8 + t, 16) for t in range(10))
+        wr = sum(group_conflicts(WRITE_GROUPS,
+                                 lambda l: interp_swz(L, ((4 * dec(l)[2] + 2 * dec(l)[0] + qi) * L + 4 * dec(l)[1]) // 2 + e), 8)
+                 for qi in (0, 1) for e in (0, 1))
+        rb = sum(group_conflicts(GROUPS, lambda l: interp_swz(L, 64 * k + l), 16) for k in range(4))
+        assert sorted(interp_swz(L, o) for o in range(256)) == list(range(256))
+        print("x%-2d extra LDS cycles per sub-tile: window reads %d, transposition writes %d, read-back %d" % (L, rd, wr, rb))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "search":
+    if len(sys.argv) > 1 and sys.argv[1] == "interp":
+        interp_model()
+    elif len(sys.argv) > 1 and sys.argv[1] == "search":
         for padrows in (8, 16, 32):
             free = [b for b in itertools.permutations(NAMES) if extra_cycles(b, padrows) == 0]
             print("pad after every %2d rows: %d conflict-free lane maps" % (padrows, len(free)))
