@@ -47,8 +47,11 @@ extern "C" {
 #endif
 
 /* 2: sxfir_stream_wait_event, sxfir_set_history, timing events, clock probe, host registration and the keying count were added
- * (round 2); nothing was removed or changed, a caller built against 1 keeps working. */
-#define SXFIR_ABI_VERSION 2
+ *    (round 2).  Two diagnostic entry points of version 1, sxfir_debug_clock and sxfir_debug_stamps, moved out of
+ *    libsxfir.so into the profiling build (libsxfir_prof.so, include/sxfir_prof.h): a version-1 client that referenced
+ *    them no longer links against the production library; every other version-1 entry point is unchanged.
+ * 3: sxfir_set_position added (round 3); nothing removed or changed. */
+#define SXFIR_ABI_VERSION 3
 
 enum {
     SXFIR_OK = 0,
@@ -101,6 +104,12 @@ int sxfir_reset(sxfir_plan *plan, void *stream);
  * k+1 needs nothing from block k but the tail of its INPUT, which is in memory before either runs
  * (sxxcvr_amd.PipelinedResampler).  No speed-up on one GPU: DESIGN.md 7. */
 int sxfir_set_history(sxfir_plan *plan, const void *src_dev, size_t n, size_t stride, void *stream);
+/* Place the plan at sample `consumed` of its input stream (the count sxfir_position reports as consumed; the
+ * outputs produced so far follow from it: ceil(consumed / D) for a decimator, consumed * L for an interpolator).
+ * A decimator's phase -- which input of the next call yields the next output, SX.cpp:950's position arithmetic --
+ * depends on it, so a plan that takes over a stream in the middle (sxfir_set_history) must be told where it is
+ * unless the blocks are multiples of the ratio. */
+int sxfir_set_position(sxfir_plan *plan, int64_t consumed);
 int sxfir_set_kernel(sxfir_plan *plan, int kernel);
 /* Squared-magnitude threshold above which an SXFIR_S32 interpolator sets the two low bits of the I
  * word (tx_threshold2 of SX.cpp:540-542, :132-133).  Default 1e-6 (threshold 1e-3, SX.cpp:767). */

@@ -57,6 +57,7 @@ def load_sxfir(profiling=False):
         "sxfir_destroy": (ci, [vp]),
         "sxfir_reset": (ci, [vp, vp]),
         "sxfir_set_history": (ci, [vp, vp, sz, sz, vp]),
+        "sxfir_set_position": (ci, [vp, i64]),
         "sxfir_set_kernel": (ci, [vp, ci]),
         "sxfir_set_tx_threshold": (ci, [vp, C.c_float]),
         "sxfir_contract": (ci, [vp, P(ci), P(ci)]),

@@ -592,8 +592,14 @@ public:
             std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
             return std::to_string(tx_chain->keyed_samples());
         }
-        if (key == "RX_DIRECT_SAMPLES") return std::to_string(rx_chain->direct_samples());
-        if (key == "TX_DIRECT_SAMPLES") return std::to_string(tx_chain->direct_samples());
+        if (key == "RX_DIRECT_SAMPLES") {
+            std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_rx).mutex);
+            return std::to_string(rx_chain->direct_samples());
+        }
+        if (key == "TX_DIRECT_SAMPLES") {
+            std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
+            return std::to_string(tx_chain->direct_samples());
+        }
         if (key == "RX_DECIM") return std::to_string(decim);
         if (key == "TX_INTERP") return std::to_string(interp);
         if (key == "RX_NTAPS") return std::to_string(rx_chain->ntaps());

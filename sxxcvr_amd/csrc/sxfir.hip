@@ -446,6 +446,16 @@ int sxfir_set_history(sxfir_plan *p, const void *src_dev, size_t n, size_t strid
     return SXFIR_OK;
 }
 
+int sxfir_set_position(sxfir_plan *p, int64_t consumed)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (consumed < 0) return fail(SXFIR_EINVAL, "negative stream position");
+    p->consumed = (long long)consumed;
+    p->produced = p->mode == SXFIR_DECIMATE ? ((long long)consumed + p->ratio - 1) / p->ratio
+                                            : (long long)consumed * p->ratio;
+    return SXFIR_OK;
+}
+
 int sxfir_set_kernel(sxfir_plan *p, int kernel)
 {
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
@@ -1364,6 +1374,25 @@ int sxfir_host_device_pointer(const void *host, size_t bytes, void **dev)
     if (e != hipSuccess || !d) {
         (void)hipGetLastError();
         return SXFIR_EUNSUPPORTED;
+    }
+    // ... and to the same registration: inside one page-locked allocation the device view is linear, so the last
+    // byte's device pointer is d + bytes - 1; a range that spans two registrations (or a pageable hole between
+    // them) maps elsewhere and is refused -- kernels and DMA copies write through d across the whole range
+    if (bytes > 1) {
+        void *dl = nullptr;
+        e = hipHostGetDevicePointer(&dl, const_cast<char *>((const char *)host + bytes - 1), 0);
+        if (e != hipSuccess || dl != (char *)d + bytes - 1) {
+            (void)hipGetLastError();
+            return SXFIR_EUNSUPPORTED;
+        }
+        // and, where the runtime reports the allocation the device pointer belongs to, the range ends inside it
+        void *base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)d) == hipSuccess && base && size) {
+            if ((char *)d + bytes > (char *)base + size) return SXFIR_EUNSUPPORTED;
+        } else {
+            (void)hipGetLastError();
+        }
     }
     *dev = d;
     return SXFIR_OK;

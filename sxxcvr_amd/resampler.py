@@ -157,6 +157,11 @@ class Resampler:
         (sxfir_set_history): as if that block had just been processed."""
         self._ck(self._lib.sxfir_set_history(self._plan, C.c_void_p(src_ptr), n, stride, C.c_void_p(stream)))
 
+    def set_position(self, consumed):
+        """Place the plan at input sample `consumed` of its stream (sxfir_set_position): a decimator's output phase
+        and output count of the next call follow from it."""
+        self._ck(self._lib.sxfir_set_position(self._plan, int(consumed)))
+
     # -- raw pointers ---------------------------------------------------------
     def process_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, stream=0):
         n_out = C.c_size_t()
@@ -248,10 +253,14 @@ class PipelinedResampler:
     """Consecutive blocks of ONE stream on `depth` plans and `depth` HIP streams in turn, so that their passes
     overlap on the GPU.  Block k+1 needs nothing of block k but the tail of its INPUT, which is in device memory
     before either pass runs: each plan's filter state is seeded from there (sxfir_set_history) and the passes are
-    independent launches.  The outputs are those of one plan fed block by block.  (On one GPU this buys nothing once
-    every block is new data -- DESIGN.md 7 -- it is the way to split one stream over plans or GPUs.)
+    independent launches.  Each plan is also told where in the stream its block starts (sxfir_set_position), so
+    blocks need not be multiples of the ratio: the outputs, their count and their positions are those of one plan
+    fed block by block.  (On one GPU this buys nothing once every block is new data -- DESIGN.md 7 -- it is the way
+    to split one stream over plans or GPUs.)
 
-    The caller keeps every input block unchanged until the pass over the NEXT block has run (join() waits for all)."""
+    Ordering: every pass waits (on the GPU) for the work the CALLER's current torch stream had queued when
+    process_ptr was called -- the kernels that produced the block -- and nothing else.  The caller keeps every input
+    block unchanged until the pass over the NEXT block has run (join() waits for all)."""
 
     def __init__(self, mode, taps, ratio, nchan=1, fmt="CF32", device=-1, depth=4):
         import torch
@@ -260,25 +269,33 @@ class PipelinedResampler:
         self.streams = [torch.cuda.Stream(device=None if device < 0 else device) for _ in range(self.depth)]
         self._k = 0
         self._prev = None                                   # (ptr, n, stride) of the previous input block
+        self._consumed = 0                                  # input samples of the stream before the next block
 
     @property
     def contract(self):
         return self.plans[0].contract
 
     def restart(self):
-        """The next block is the first of a new stream (zero history)."""
+        """The next block is the first of a new stream (zero history, position 0)."""
         self._prev = None
+        self._consumed = 0
 
     def process_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride):
         """Queue the pass over one block; returns its output count.  Asynchronous: join() before using outputs."""
+        import torch
         k = self._k % self.depth
         plan, st = self.plans[k], self.streams[k].cuda_stream
+        # the block (and the previous one, whose tail is the history) was produced on the caller's stream
+        self.streams[k].wait_stream(torch.cuda.current_stream(self.streams[k].device))
         if self._prev is None:
             plan.reset(st)
         else:
+            # (a previous block shorter than the filter history is refused by sxfir_set_history: SXFIR_EINVAL)
             plan.set_history_ptr(self._prev[0], self._prev[1], self._prev[2], st)
+        plan.set_position(self._consumed)
         n_out = plan.process_ptr(in_ptr, n_in, in_stride, out_ptr, out_stride, st)
         self._prev = (in_ptr, n_in, in_stride)
+        self._consumed += n_in
         self._k += 1
         return n_out
 

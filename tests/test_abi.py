@@ -27,7 +27,7 @@ def test_sxfir_exports_every_declared_symbol():
         assert hasattr(lib, n), "libsxfir.so does not export " + n
     # and the python binding declares a prototype for each of them
     assert set(names) <= set(lib._sx_signatures), set(names) - set(lib._sx_signatures)
-    assert lib.sxfir_abi_version() == 2
+    assert lib.sxfir_abi_version() == 3
 
 
 def test_time_arithmetic_matches_oracle(oracle):

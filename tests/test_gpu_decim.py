@@ -313,11 +313,15 @@ def test_history_longer_than_2048_samples(oracle, mode):
 
 
 @pytest.mark.parametrize("mode,ntaps,ratio,fmt", [("decim", 128, 4, "CF32"), ("decim", 256, 8, "CF32"), ("interp", 256, 8, "CF32"),
-                                                   ("decim", 1024, 32, "CF16"), ("decim", 128, 4, "S32")])
-def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ratio, fmt):
+                                                   ("decim", 1024, 32, "CF16"), ("decim", 128, 4, "S32"),
+                                                   ("decim", 1024, 32, "CF32")])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ratio, fmt, ragged):
     """sxfir_set_history seeds a plan from the tail of the previous INPUT block, so consecutive blocks of one stream
-    can run on several plans and HIP streams at once (PipelinedResampler).  Seven ragged blocks on three plans:
-    every output equals what ONE plan produces fed block by block (which the other tests pin to the oracle)."""
+    can run on several plans and HIP streams at once (PipelinedResampler).  Seven blocks of uneven length on three
+    plans -- with `ragged` not even multiples of the ratio, so the decimation phase differs from block to block
+    (sxfir_set_position) -- and every output equals what ONE plan produces fed block by block (which the other
+    tests pin to the oracle)."""
     import torch
     from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE
     decim = mode == "decim"
@@ -327,6 +331,10 @@ def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ra
     blocks = [unit * b for b in (4096, 1024, 8192 + 8, 520, 4096, 64, 2048)]
     if not decim:
         blocks = [b // 4 + 32 for b in blocks]
+    if ragged:
+        # blocks that are NOT multiples of the ratio: every plan must be told the stream position
+        # (sxfir_set_position), or its decimation phase and output count are those of position 0
+        blocks = [b + d for b, d in zip(blocks, (1, 3, 0, 5, 2, 7, 1))]
     total = sum(blocks)
     nchan = 2
     dt = torch.complex64 if fmt == "CF32" else (torch.int32 if fmt == "CF16" else torch.int64)
@@ -335,7 +343,7 @@ def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ra
     else:
         x = torch.empty((nchan, total), dtype=dt, device="cuda")
         sxxcvr_amd.synth_fill(x, 0x51255, 3, 0, fmt=fmt)
-    n_out_total = total // ratio if decim else total * ratio
+    n_out_total = (total + ratio - 1) // ratio if decim else total * ratio
     odt = torch.complex64 if fmt in ("CF32", "S32") and decim else dt
     if fmt == "S32":
         odt = torch.complex64
@@ -347,7 +355,8 @@ def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ra
     i0 = o0 = 0
     st = torch.cuda.current_stream().cuda_stream
     for b in blocks:
-        ob = b // ratio if decim else b * ratio
+        # outputs of a decimator block: the multiples of `ratio` inside [i0, i0 + b)
+        ob = ((i0 + b + ratio - 1) // ratio - (i0 + ratio - 1) // ratio) if decim else b * ratio
         a = one.process_ptr(x.data_ptr() + es_in * i0, b, total, want.data_ptr() + es_out * o0, n_out_total, st)
         c = pipe.process_ptr(x.data_ptr() + es_in * i0, b, total, got.data_ptr() + es_out * o0, n_out_total)
         assert a == c == ob
