@@ -36,6 +36,7 @@ SEED = 0x51255
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                            # measured float4 copy ceiling (same guide)
 VALU_PEAK_TFLOPS = 157.3                         # fp32 vector peak at 2.4 GHz (same guide)
+XGMI_LINK_GBS = 153.0                            # one xGMI link, per direction (7 links per GPU, point to point)
 
 # algorithmic bytes and flops per WIDEBAND-side sample (input of a decimator, output
 # of the interpolator); halo and tap re-reads excluded.
@@ -65,6 +66,11 @@ def spawn_ranks(n):
     """Start n fresh child processes (one per GPU) running this script as torch.distributed ranks and wait for
     them.  Called before the parent has imported torch or made any GPU call; nothing is exec'ed over a process
     that has touched a GPU."""
+    # the checker is built once, here, before the ranks exist (they would all find it stale at the same moment
+    # after a fresh checkout; oracle_lib.build() also serialises itself with an flock).  CPU only: no GPU call.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.build()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -387,7 +393,8 @@ def through_device():
     return res
 
 
-def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps):
+def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps, step_into,
+                   world_pipe_steps=None):
     """Exchange step of BASELINE config 4: RCCL gather of every rank's decimated output to rank 0 over xGMI,
     timed after (and outside) the timed region; rank 0 checks that the gathered tensor holds every rank's
     channels in global channel order."""
@@ -424,6 +431,48 @@ def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gp
         local = y.shape[0]
         out["root_holds_own_channels"] = bool(torch.equal(full[:local].to(y.device), y))
         out["gathered_shape"] = list(full.shape)
+    del full
+
+    # The same exchange in steady state: each step's output is gathered in chunks of whole channels
+    # behind the kernel that produced it and beside the kernels of the following steps (two output buffers in turn).
+    # The throughput of that pipeline is max(kernel, gather) per step instead of their sum.
+    depth, psteps = 2, (6 if world_pipe_steps is None else world_pipe_steps)
+    ybuf = [y, torch.empty_like(y)]
+    pipe = sxdist.GatherPipeline(total_channels, tuple(y.shape), y.dtype, y.device, dst=0, chunks=4, depth=depth)
+
+    def run(nsteps):
+        for s in range(nsteps):
+            k = s % depth
+            pipe.reuse(k)
+            step_into(ybuf[k])
+            pipe.submit(k, ybuf[k])
+        pipe.drain()
+
+    run(depth)                                                   # warm-up: communicators, staging buffers
+    torch.cuda.synchronize()
+    dist.barrier()
+    p0 = time.perf_counter()
+    run(psteps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    tp = time.perf_counter() - p0
+    t = torch.tensor([tp], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tp = float(t.item())
+    per_link = peer_bytes * psteps / tp / 1e9
+    out["overlapped_value"] = round(world * wide_per_gpu * psteps / tp / 1e6, 1)
+    out["link_bound_frac"] = round(per_link / XGMI_LINK_GBS, 4)
+    out["overlapped"] = {
+        "steps": psteps, "ms_per_step": round(tp / psteps * 1e3, 3), "chunks_per_step": pipe.chunks,
+        "GB/s_per_link": round(per_link, 2), "link_peak_GB/s": XGMI_LINK_GBS,
+        "how": "each step's output gathered in %d chunks (whole channels) behind its kernel and beside the next "
+               "steps' kernels, two output buffers in turn; value = whole-job MS/s of that pipeline" % pipe.chunks,
+    }
+    if dist.get_rank() == 0:
+        last = (psteps - 1) % depth
+        out["overlapped"]["root_holds_own_channels"] = bool(
+            torch.equal(pipe.slot(last)[: y.shape[0]].to(y.device), ybuf[last]))
+        out["overlapped"]["gathered_shape"] = list(pipe.slot(last).shape)
     return out
 
 
@@ -689,7 +738,8 @@ def main():
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps)
+            gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps,
+                                    lambda out: plan.process(x, out=out))
         except Exception as e:
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
         finished.set()

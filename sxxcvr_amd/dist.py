@@ -84,3 +84,125 @@ def gather_channels(local, n_channels, dst=0, group=None, always_collective=Fals
             parts.append(bufs[r][: rhi - rlo])
         out = torch.cat(parts, dim=0)
     return torch.view_as_complex(out) if is_complex else out
+
+
+class GatherPipeline:
+    """The exchange step in steady state ("chunk and overlap with the next tile's compute"):
+    every step's decimated output is gathered to `dst` in `chunks` sub-collectives (groups of whole channels, so
+    each send buffer is contiguous) that run BEHIND the kernel that produced the block and BESIDE the kernels of the
+    next steps.  The caller alternates between `depth` output buffers:
+
+        for s in range(steps):
+            pipe.reuse(s % depth)            # the gather that last read buffer s % depth is done (GPU-side wait)
+            plan.process(x, out=y[s % depth])
+            pipe.submit(s % depth, y[s % depth])
+        pipe.drain()
+
+    backend nccl (= RCCL over xGMI): dist.gather(async_op=True) per chunk; the collective is ordered behind the
+    current stream's work by ProcessGroupNCCL and runs on its own stream; reuse() makes the current stream wait for
+    it, the host never blocks.  Any other backend (gloo: host tensors; the dry-run stand-in for a 1-GPU box and the
+    CPU tests): the block is staged to the host behind the kernel and its collectives are issued one step late, when
+    the staging copy has certainly been queued; same results, same order.
+
+    On `dst`, slot(k) is the [n_channels, ...] tensor that buffer k's last gather filled (global channel order);
+    the reference is single-channel (SoapySX.cpp:1591-1595), this layout is the build's."""
+
+    def __init__(self, n_channels, local_shape, dtype, device, dst=0, chunks=2, depth=2, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_channels, self.depth = n_channels, depth
+        if n_channels % self.world:
+            raise ValueError("the pipelined gather takes equal shards (%d channels over %d ranks)" % (n_channels, self.world))
+        self.local_ch = n_channels // self.world
+        if tuple(local_shape)[0] != self.local_ch:
+            raise ValueError("a rank holds %d channels, expected %d" % (local_shape[0], self.local_ch))
+        chunks = max(1, min(int(chunks), self.local_ch))
+        while self.local_ch % chunks:
+            chunks -= 1
+        self.chunks, self.cpc = chunks, self.local_ch // chunks         # channels per chunk
+        self.host = dist.get_backend(group) != "nccl"
+        self.is_complex = dtype.is_complex
+        wire_dtype = {torch.complex64: torch.float32, torch.complex128: torch.float64}.get(dtype, dtype)
+        tail = tuple(local_shape[1:]) + ((2,) if self.is_complex else ())
+        cdev = torch.device("cpu") if self.host else device
+        self.full = None
+        if self.rank == dst:
+            # [depth][world, local_ch, ...]: rank r's chunk j lands in full[k][r, j*cpc:(j+1)*cpc]
+            self.full = [torch.empty((self.world, self.local_ch) + tail, dtype=wire_dtype, device=cdev) for _ in range(depth)]
+        self.stage = None
+        if self.host:
+            self.stage = [torch.empty((self.local_ch,) + tail, dtype=wire_dtype).pin_memory() if torch.cuda.is_available()
+                          else torch.empty((self.local_ch,) + tail, dtype=wire_dtype) for _ in range(depth)]
+        self.works = [[] for _ in range(depth)]
+        self.pending = []                                               # host mode: (slot, event) not yet issued
+        self.submitted = 0
+
+    def _wire(self, t):
+        return self.torch.view_as_real(t) if self.is_complex else t
+
+    def _issue(self, k, wire):
+        for j in range(self.chunks):
+            send = wire[j * self.cpc:(j + 1) * self.cpc]
+            bufs = None
+            if self.rank == self.dst:
+                bufs = [self.full[k][r, j * self.cpc:(j + 1) * self.cpc] for r in range(self.world)]
+            self.works[k].append(self.dist.gather(send, bufs, dst=self.dst, group=self.group, async_op=True))
+
+    def _pump(self, force=False):
+        while self.pending:
+            k, ev = self.pending[0]
+            if ev is not None:
+                if not force and len(self.pending) < 2 and not ev.query():
+                    return
+                ev.synchronize()
+            self.pending.pop(0)
+            self._issue(k, self.stage[k])
+
+    def reuse(self, k):
+        """Buffer k (and slot k on dst) may be overwritten once this returns (nccl: once the current stream gets
+        there)."""
+        if self.host:
+            self._pump(force=any(p[0] == k for p in self.pending))
+        for w in self.works[k]:
+            w.wait()
+        self.works[k] = []
+
+    def submit(self, k, local):
+        """Queue the gather of `local` (this step's output, produced on the current stream) into slot k."""
+        wire = self._wire(local)
+        if not wire.is_contiguous():
+            raise ValueError("the step's output must be contiguous [channels, samples]")
+        if self.host:
+            ev = None
+            if wire.is_cuda:
+                self.stage[k].copy_(wire, non_blocking=True)
+                ev = self.torch.cuda.Event()
+                ev.record()
+            else:
+                self.stage[k].copy_(wire)
+            self.pending.append((k, ev))
+            self._pump()
+        else:
+            self._issue(k, wire)
+        self.submitted += 1
+
+    def drain(self):
+        if self.host:
+            self._pump(force=True)
+        for k in range(self.depth):
+            for w in self.works[k]:
+                w.wait()
+            self.works[k] = []
+        if not self.host and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+
+    def slot(self, k):
+        """dst only: the gathered [n_channels, ...] block of buffer k's last submit (after reuse(k) / drain())."""
+        if self.full is None:
+            return None
+        t = self.full[k].reshape((self.n_channels,) + tuple(self.full[k].shape[2:]))
+        return self.torch.view_as_complex(t) if self.is_complex else t

@@ -26,15 +26,22 @@ class StreamResult(C.Structure):
 
 
 def build():
-    """Compile the oracle if a library is missing or older than its source."""
+    """Compile the oracle if a library is missing or older than its source.  The check and the `make` are one
+    critical section under an flock: the ranks of `bench.py --gpus N` all come through here at once."""
+    import fcntl
     src = os.path.join(_ODIR, "sx_oracle.c")
     hdr = os.path.join(_ODIR, "sx_oracle.h")
-    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
-    for name in ("libsxoracle.so", "libsxoracle_fast.so"):
-        p = os.path.join(_ODIR, name)
-        if not os.path.exists(p) or os.path.getmtime(p) < newest:
-            subprocess.check_call(["make", "-C", _ODIR, "-s"], stdout=subprocess.DEVNULL)
-            break
+    with open(os.path.join(_ODIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+            for name in ("libsxoracle.so", "libsxoracle_fast.so"):
+                p = os.path.join(_ODIR, name)
+                if not os.path.exists(p) or os.path.getmtime(p) < newest:
+                    subprocess.check_call(["make", "-C", _ODIR, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    break
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def _fp(a):

@@ -88,3 +88,78 @@ def test_gather_two_ranks_gloo(oracle, n_channels):
 def test_single_process_gather_is_identity():
     t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
     assert sxdist.gather_channels(t, 3) is t
+
+
+def _pipe_worker(rank, world, port, n_channels, n, steps, chunks, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        sxdist.init_process_group(backend="gloo")
+        lo, hi = sxdist.shard_channels(n_channels, world, rank)
+
+        def block(step, c0, c1):          # what the rank's decimator would hold after `step`: distinct per (step, channel, sample)
+            ch = torch.arange(c0, c1, dtype=torch.float32).reshape(-1, 1)
+            k = torch.arange(n, dtype=torch.float32).reshape(1, -1)
+            return torch.complex(1000.0 * step + ch + k / 4096.0, -(7.0 * step + ch) - k / 8192.0)
+
+        depth = 2
+        pipe = sxdist.GatherPipeline(n_channels, (hi - lo, n), torch.complex64, torch.device("cpu"), dst=0, chunks=chunks,
+                                     depth=depth)
+        y = [torch.empty((hi - lo, n), dtype=torch.complex64) for _ in range(depth)]
+        bad = []
+        for s in range(steps):
+            k = s % depth
+            pipe.reuse(k)
+            if rank == 0 and s >= depth and not torch.equal(pipe.slot(k), block(s - depth, 0, n_channels)):
+                bad.append(s - depth)
+            y[k].copy_(block(s, lo, hi))          # "the kernel" overwrites the buffer the finished gather read
+            pipe.submit(k, y[k])
+        pipe.drain()
+        if rank == 0:
+            for s in range(max(0, steps - depth), steps):
+                if not torch.equal(pipe.slot(s % depth), block(s, 0, n_channels)):
+                    bad.append(s)
+        q.put(("ok", bad, pipe.chunks, pipe.submitted))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc(), 0, 0))
+
+
+@pytest.mark.parametrize("n_channels,chunks", [(16, 4), (6, 2)])
+def test_pipelined_gather_two_ranks_gloo(n_channels, chunks):
+    """GatherPipeline: each step's block is gathered in chunks behind the step that produced it while the next
+    steps overwrite the other buffer; the root sees every step's block, whole and in global channel order."""
+    world, n, steps = 2, 513, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, n_channels, n, steps, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] == "ok" for r in results), results
+    for _, bad, used_chunks, submitted in results:
+        assert bad == [] and submitted == steps
+        assert (n_channels // world) % used_chunks == 0
+
+
+def test_oracle_build_is_serialised(tmp_path):
+    """Eight ranks of bench.py call oracle_lib.build() at once after a fresh checkout: the check-and-make must be
+    one critical section (flock), or they race `make` over the .so files the others dlopen."""
+    import subprocess
+    code = ("import sys, os; sys.path.insert(0, %r); import oracle_lib; oracle_lib.build(); "
+            "o = oracle_lib.Oracle(); print(o.ticks_to_time_ns(256, 75000.0))" % os.path.join(ROOT, "tests"))
+    so = os.path.join(ROOT, "oracle", "libsxoracle.so")
+    old = os.path.getmtime(so) if os.path.exists(so) else None
+    os.utime(os.path.join(ROOT, "oracle", "sx_oracle.c"))          # "fresh checkout": sources newer than the libraries
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(8)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    assert all(o[0].strip() == "3413333" for o in outs), [o[0] for o in outs]
+    assert old is None or os.path.getmtime(so) > old

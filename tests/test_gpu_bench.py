@@ -66,6 +66,21 @@ def test_bench_starts_its_own_ranks_gloo_stand_in():
     assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
 
 
+def test_bench_eight_ranks_gloo_stand_in():
+    """BASELINE config 4's full layout on the 1-GPU box: --gpus 8 self-spawned, eight ranks share the GPU, 64 channels,
+    collectives over gloo.  Everything but the transport is the code the 8-GPU run executes: sharding, the serial gather
+    and the pipelined (chunked, overlapped) gather, verification on every rank, one JSON line."""
+    line = run_bench(["--gpus", "8"] + SMALL, env={"SXFIR_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert line["n_gpus"] == 8 and line["verified"] is True and line["scaling"] == "weak"
+    assert line["config"]["rccl_ranks"] == 8 and line["config"]["channels_per_gpu"] == 8
+    g = line["gather"]
+    assert "error" not in g, g
+    assert g["gathered_shape"][0] == 64 and g["root_holds_own_channels"] is True
+    o = g["overlapped"]
+    assert o["gathered_shape"][0] == 64 and o["root_holds_own_channels"] is True and o["chunks_per_step"] == 4
+    assert g["overlapped_value"] > 0 and 0 < g["link_bound_frac"]
+
+
 def test_bench_under_the_drivers_launcher_gloo_stand_in():
     """The driver's own N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...; exactly one JSON line must come out (rank 0's).
