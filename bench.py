@@ -390,7 +390,26 @@ def through_device():
         dev.deactivateStream(tx)
         dev.closeStream(rx)
         dev.closeStream(tx)
+    res["c_caller"] = c_caller()
     return res
+
+
+def c_caller():
+    """The same calls from C (sxxcvr_amd/lib/sx_devloop = tools/devloop.c against include/sx_device.h, built by
+    build()): what the plugin costs per readStream / writeStream call with no Python stand-in in the loop, at the
+    reference's block sizes (256 ... 8192, SoapySX.cpp:706-707) on the virtual sample clock.  A child process."""
+    exe = os.path.join(ROOT, "sxxcvr_amd", "lib", "sx_devloop")
+    if not os.path.exists(exe):
+        return {"error": "sx_devloop is not built (python -m sxxcvr_amd.build)"}
+    try:
+        run = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=300)
+        if run.returncode != 0:
+            return {"error": (run.stdout + run.stderr)[-300:]}
+        out = json.loads(run.stdout.strip().splitlines()[-1])
+        out["note"] = "C caller through the flat Device API, virtual sample clock; mean over `calls` calls per block size"
+        return out
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps, step_into,

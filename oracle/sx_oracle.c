@@ -72,10 +72,13 @@ void sxo_convert_rx_mt(const int32_t *src, float *dst, size_t n, int threads)
     }
 }
 
-/* float -> int32 as the reference's real platform (ARM, saturating vcvt) does
- * it.  The reference's C++ (SoapySX.cpp:124-125) converts 2^31 * 1.0f, which
- * overflows int32 (undefined behaviour in C++; x86 yields INT32_MIN, the
- * Raspberry Pi's ARM saturates).  The build DEFINES: saturate, NaN -> 0. */
+/* One rule for both corners of convert_tx_buffer: the arithmetic is the C++ SOURCE's, evaluated
+ * as the abstract machine says (every product and sum rounded once, no contraction: fusing fi*fi + fq*fq into an
+ * fma is a compiler licence -- gcc's -ffp-contract=fast default takes it on AArch64 -- not something the source
+ * or the platform defines, and which operand it would fuse is the compiler's choice); where the abstract machine
+ * leaves a result UNDEFINED, the instruction the reference's platform executes decides.  That happens once:
+ * SoapySX.cpp:124-125 converts 2^31 * 1.0f to int32, which overflows; the Raspberry Pi's AArch64 FCVTZS saturates
+ * and maps NaN to 0 whatever the compiler does (x86's cvttss2si yields INT32_MIN).  So: saturate, NaN -> 0. */
 static int32_t sat_f32_to_i32(float v)
 {
     if (v != v) return 0;
@@ -99,7 +102,7 @@ void sxo_convert_tx(const float *src, int32_t *dst, size_t n, float tx_threshold
         int32_t vq = sat_f32_to_i32(scaling * cq);
         vi &= (int32_t)0xFFFFFFFC;
         vq &= (int32_t)0xFFFFFFFC;
-        /* two roundings for the products, one for the sum (no contraction) */
+        /* the source's arithmetic: two roundings for the products, one for the sum (rule above) */
         const float ii = fi * fi;
         const float qq = fq * fq;
         if (ii + qq >= tx_threshold2)

@@ -65,23 +65,36 @@ TARGETS = {
         "flags": ["-O2", "-ffp-contract=off", "-pthread", "-I" + os.path.join(CSRC, "compat")],
         "libs": ["-L" + LIBDIR, "-lsxfir", "-Wl,-rpath,$ORIGIN"],
     },
+    # a C caller of the flat Device API (include/sx_device.h): per-call cost of readStream / writeStream with no
+    # Python in the loop; bench.py runs it as a child process (through_device.c_caller)
+    "sx_devloop": {
+        "compiler": "gcc",
+        "executable": True,
+        "sources": [os.path.join(ROOT, "tools", "devloop.c")],
+        "flags": ["-O2"],
+        "libs": ["-L" + LIBDIR, "-lSXSupport", "-Wl,-rpath,$ORIGIN"],
+    },
 }
 
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    deps = _deps(CSRC, os.path.join(ROOT, "include"))
+    deps = _deps(CSRC, os.path.join(ROOT, "include")) + [os.path.join(ROOT, "tools", "devloop.c")]
     built = []
     for name, spec in TARGETS.items():
-        srcs = [os.path.join(CSRC, s) for s in spec["sources"]]
+        srcs = [s if os.path.isabs(s) else os.path.join(CSRC, s) for s in spec["sources"]]
         if not all(os.path.exists(s) for s in srcs):
             continue
         out = os.path.join(LIBDIR, name)
         if not (force or _newer(out, deps)):
             continue
-        cc = hipcc() if spec["compiler"] == "hipcc" else (shutil.which("g++") or "g++")
-        cmd = [cc, "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-               "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + ["-o", out] + spec.get("libs", [])
+        if spec.get("executable"):
+            cmd = [shutil.which("gcc") or "gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-Wall",
+                   "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + ["-o", out] + spec.get("libs", [])
+        else:
+            cc = hipcc() if spec["compiler"] == "hipcc" else (shutil.which("g++") or "g++")
+            cmd = [cc, "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                   "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + ["-o", out] + spec.get("libs", [])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

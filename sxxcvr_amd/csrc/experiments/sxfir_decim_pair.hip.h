@@ -25,8 +25,8 @@
 
 #include <utility>
 
-#include "sxfir_decim_tile.hip.h"
-#include "sxfir_decim_tile2.hip.h"
+#include "../sxfir_decim_tile.hip.h"
+#include "../sxfir_decim_tile2.hip.h"
 
 namespace sxfir {
 

@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "sxfir_decim_tile.hip.h"
+#include "../sxfir_decim_tile.hip.h"
 
 namespace sxfir {
 

@@ -22,8 +22,8 @@
 
 #include <utility>
 
-#include "sxfir_decim_tile.hip.h"
-#include "sxfir_decim_tile2.hip.h"
+#include "../sxfir_decim_tile.hip.h"
+#include "../sxfir_decim_tile2.hip.h"
 
 namespace sxfir {
 

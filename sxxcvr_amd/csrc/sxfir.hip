@@ -51,11 +51,11 @@
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
 #ifdef SXFIR_PROFILING
-#include "sxfir_decim_pair.hip.h"   // measured variants, not shipped
-#include "sxfir_decim_wide.hip.h"
+#include "experiments/sxfir_decim_pair.hip.h"   // measured variants, not shipped
+#include "experiments/sxfir_decim_wide.hip.h"
 #endif
 #ifdef SXFIR_PROFILING
-#include "sxfir_decim_sgpr.hip.h"
+#include "experiments/sxfir_decim_sgpr.hip.h"
 #include "../../include/sxfir_prof.h"
 #endif
 #include "sxfir_kernels.hip.h"

@@ -52,6 +52,13 @@ def test_bench_reports_device_and_cpu_figures():
     t = line["through_device"]
     assert "error" not in t, t
     assert t["256_sample_calls"]["readStream_us_per_call"] > 0 and t["65536_sample_calls"]["readStream_out_MS/s"] > 0
+    cc = t["c_caller"]                                   # tools/devloop.c, built by build(), run as a child process
+    assert "error" not in cc, cc
+    assert 0 < cc["256"]["readStream_us_per_call"] < 100 and 0 < cc["4096"]["writeStream_us_per_call"] < 1000
+    r = line["roofline"]
+    assert r["kernel_ms_first_20"] > 0 and "board" in r
+    if "error" not in r["board"]:
+        assert r["board"]["samples"] >= 10 and r["power_w"] > 100 and r["gfx_mhz_smi"] > 100
 
 
 def test_bench_starts_its_own_ranks_gloo_stand_in():

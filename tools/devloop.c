@@ -1,6 +1,7 @@
 /* readStream / writeStream per-call cost from a C caller (no Python in the loop), through the flat C view of the
  * Device (include/sx_device.h): what the plugin itself costs per call at the reference's block sizes.
- * Profiling aid: gcc -O2 -Iinclude tools/devloop.c -o /tmp/devloop -Lsxxcvr_amd/lib -lSXSupport -Wl,-rpath,$PWD/sxxcvr_amd/lib */
+ * Built by sxxcvr_amd/build.py as sxxcvr_amd/lib/sx_devloop (gcc -O2 -Iinclude tools/devloop.c -lSXSupport); bench.py runs
+ * it as a child process for through_device.c_caller.  Errors go to stdout as text and the exit status is 1. */
 #include <sx_device.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,9 +14,12 @@ static double now(void)
     return t.tv_sec + 1e-9 * t.tv_nsec;
 }
 
-int main(void)
+int main(int argc, char **argv)
 {
+    /* --json: one JSON object on stdout (bench.py's through_device.c_caller) */
+    const int json = argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 'j';
     const size_t sizes[] = {256, 1024, 4096, 8192, 65536};
+    if (json) printf("{");
     for (unsigned k = 0; k < sizeof(sizes) / sizeof(sizes[0]); ++k) {
         const size_t blk = sizes[k];
         sx_device *dev = sx_device_make("driver=sx,clock=virtual");
@@ -48,10 +52,15 @@ int main(void)
             if (sx_device_write_stream(dev, tx, cbuffs, blk, &flags, 0, 100000) != (int)blk) { printf("write: %s\n", sx_device_last_error()); return 1; }
         }
         const double tx_us = (now() - t0) / n * 1e6;
-        printf("block %6zu: readStream %.2f us/call (%.1f MS/s out) | writeStream %.2f us/call (%.1f MS/s in)\n", blk, rx_us, blk / rx_us,
-               tx_us, blk / tx_us);
+        if (json)
+            printf("%s\"%zu\": {\"readStream_us_per_call\": %.3f, \"readStream_out_MS/s\": %.1f, \"writeStream_us_per_call\": %.3f, "
+                   "\"writeStream_in_MS/s\": %.1f, \"calls\": %d}", k ? ", " : "", blk, rx_us, blk / rx_us, tx_us, blk / tx_us, n);
+        else
+            printf("block %6zu: readStream %.2f us/call (%.1f MS/s out) | writeStream %.2f us/call (%.1f MS/s in)\n", blk, rx_us,
+                   blk / rx_us, tx_us, blk / tx_us);
         free(buf);
         sx_device_unmake(dev);
     }
+    if (json) printf("}\n");
     return 0;
 }
