@@ -412,8 +412,7 @@ def c_caller():
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps, step_into,
-                   world_pipe_steps=None):
+def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps):
     """Exchange step of BASELINE config 4: RCCL gather of every rank's decimated output to rank 0 over xGMI,
     timed after (and outside) the timed region; rank 0 checks that the gathered tensor holds every rank's
     channels in global channel order."""
@@ -450,12 +449,21 @@ def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gp
         local = y.shape[0]
         out["root_holds_own_channels"] = bool(torch.equal(full[:local].to(y.device), y))
         out["gathered_shape"] = list(full.shape)
-    del full
+    return out
+
+
+def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_into, psteps=6):
+    """The same exchange in steady state; returns the keys to add to the line's "gather" object."""
+    import torch
+    import torch.distributed as dist
+    import sxxcvr_amd.dist as sxdist
+    out = {}
+    peer_bytes = y.numel() * 8
 
     # The same exchange in steady state (SURVEY 8(e)): each step's output is gathered in chunks of whole channels
     # behind the kernel that produced it and beside the kernels of the following steps (two output buffers in turn).
     # The throughput of that pipeline is max(kernel, gather) per step instead of their sum.
-    depth, psteps = 2, (6 if world_pipe_steps is None else world_pipe_steps)
+    depth = 2
     ybuf = [y, torch.empty_like(y)]
     pipe = sxdist.GatherPipeline(total_channels, tuple(y.shape), y.dtype, y.device, dst=0, chunks=4, depth=depth)
 
@@ -748,20 +756,34 @@ def main():
     gather = None
     if world > 1:
         import threading
-        finished = threading.Event()
+        finished, stage = threading.Event(), {"name": "serial", "gather": None}
 
         def watchdog():
-            if not finished.wait(240.0):
+            if finished.wait(240.0):
+                return
+            if stage["name"] == "serial":
                 emit({"error": "gather did not complete within 240 s"})
                 os._exit(3)
+            # the plain gather is on record; only the pipelined form hung: report that and leave (a collective
+            # that hangs cannot be cancelled)
+            emit(dict(stage["gather"], overlapped={"error": "pipelined gather did not complete within 240 s"}))
+            os._exit(0 if verified else 4)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps,
-                                    lambda out: plan.process(x, out=out))
+            gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps)
         except Exception as e:
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
         finished.set()
+        if "error" not in gather:
+            finished, stage["name"], stage["gather"] = threading.Event(), "overlapped", gather
+            threading.Thread(target=watchdog, daemon=True).start()
+            try:
+                gather.update(measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu,
+                                                       lambda out: plan.process(x, out=out)))
+            except Exception as e:
+                gather["overlapped"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finished.set()
     emit(gather)
 
     if world > 1:

@@ -279,6 +279,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
     }
     if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
+    if (getenv("SXFIR_MULTI_PS") || getenv("SXFIR_MULTI_W")) p->dense32 = false;   // those knobs belong to the multi-column kernel
     if (p->multi_capable && fmt != SXFIR_S32 && !p->dense32) {
         if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
         if (p->multi_ps == 4) p->multi_waves = ratio <= 4 ? 2 : (ratio == 8 ? 4 : 8);

@@ -4,6 +4,7 @@
 # Each step appends to gpurun_out/<tag>/<step>.txt; what is worth keeping is copied to profiles/ by hand.
 # Steps (arguments after ':' are passed on, ',' separated):
 #   tests[:expr]        pytest -m gpu (optionally -k expr)
+#   testsall            the whole GPU suite without -x;  repeat:expr  the selected tests five times (flakiness)
 #   bench[:config]      bench.py --config C (default 2) without the CPU legs
 #   benchfull           bench.py with everything (the driver's call)
 #   kb32 | kb32h | kb8 | kb16   kbench A/B of the /32 (CF32, CF16), /8, /16 kernels incl. ablations and stamps
@@ -26,6 +27,10 @@ for S in "$@"; do
   echo "=== $S" | tee -a $LOG
   case $NAME in
     tests)    if [ -n "$ARG" ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q -k "$ARG" >> $LOG 2>&1; else timeout 2400 python3 -m pytest tests -m gpu -x -q >> $LOG 2>&1; fi; tail -5 $LOG ;;
+    testsall) timeout 2700 python3 -m pytest tests -m gpu -q >> $LOG 2>&1; tail -15 $LOG ;;          # no -x: every failure
+    repeat)   for i in 1 2 3 4 5; do timeout 600 python3 -m pytest tests -m gpu -q -k "$ARG" 2>&1 | tail -3 >> $LOG; done; cat $LOG ;;
+    repfile)  for i in 1 2 3 4 5 6 7 8; do timeout 900 python3 -m pytest $ARG -m gpu -q 2>&1 | grep -E "passed|failed|differ" | cut -c1-400 >> $LOG; done; cat $LOG ;;
+    stress)   timeout 900 python3 tools/stress_direct_rx.py ${ARG//,/ } >> $LOG 2>&1; grep -v amdgpu.ids $LOG | tail -25 ;;
     bench)    timeout 600 python3 bench.py --config ${ARG:-2} --no-cpu-baseline --no-through-device >> $LOG 2>&1; tail -1 $LOG | cut -c1-1500 ;;
     benchfull) timeout 900 python3 bench.py >> $LOG 2>&1; tail -1 $LOG | cut -c1-3000 ;;
     kb32)     KB_D=32 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 dense:2:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -40 ;;
