@@ -52,6 +52,34 @@ if rank == 0:
         torch.cuda.synchronize()
         assert torch.equal(full[per * r:per * (r + 1)], want), r
     print("rccl ok world", world)
+
+# the pipelined gather (GatherPipeline) over nccl: async collectives behind the kernels, two buffers in turn;
+# every step's gathered block must be that step's output (steps differ: the stream moves on)
+depth, steps = 2, 5
+pipe = sxdist.GatherPipeline(per * world, (per, n_in // 4), torch.complex64, torch.device("cuda", local_rank), dst=0,
+                             chunks=4, depth=depth)
+assert not pipe.host and pipe.chunks == 4
+plan.reset()
+sxxcvr_amd.synth_fill(x, 0x51255, first_channel=lo, start=0)
+ys = [torch.empty((per, n_in // 4), dtype=torch.complex64, device="cuda") for _ in range(depth)]
+keep, seen = [], {}
+for s in range(steps):
+    k = s %% depth
+    pipe.reuse(k)
+    if rank == 0 and s >= depth:
+        seen[s - depth] = pipe.slot(k)[:per].clone()       # ordered behind the gather by reuse()'s stream wait
+    plan.process(x, out=ys[k])
+    keep.append(ys[k].clone())
+    pipe.submit(k, ys[k])
+pipe.drain()
+if rank == 0:
+    for s in range(steps - depth, steps):
+        seen[s] = pipe.slot(s %% depth)[:per].clone()
+    torch.cuda.synchronize()
+    for s in range(steps):
+        assert torch.equal(seen[s], keep[s]), s
+    assert not torch.equal(keep[0], keep[1])
+    print("rccl pipeline ok world", world)
 dist.destroy_process_group()
 """
 
@@ -86,3 +114,4 @@ def test_gather_allreduce_barrier_through_rccl(tmp_path):
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "rccl ok world %d" % world in outs[0]
+    assert "rccl pipeline ok world %d" % world in outs[0], outs[0][-1500:]
