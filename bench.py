@@ -45,13 +45,13 @@ CONFIGS = {
               kernel="sxfir::decim4_tile2_kernel<128, scalar taps>",
               name="128-tap polyphase decim-by-4, 1 ch CF32 streaming (BASELINE config 2)"),
     "3rx": dict(mode="decim", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=1.0,
-                kernel="sxfir::decim_multi_kernel<8, 4>",
+                kernel="sxfir::decim_dense_kernel<8>",
                 name="256-tap polyphase decim-by-8 RX, 1 ch CF32 streaming (BASELINE config 3, RX half)"),
     "3tx": dict(mode="interp", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=8.0,
                 kernel="sxfir::interp_tile_kernel<8>",
                 name="256-tap polyphase interp-by-8 TX, 1 ch CF32 streaming (BASELINE config 3, TX half)"),
     "5": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF32", bytes=8 + 8 / 32, flop=128, gain=1.0,
-              kernel="sxfir::decim32_dense_kernel",
+              kernel="sxfir::decim_dense_kernel<32>",
               name="1024-tap decim-by-32, 1 ch CF32 streaming (BASELINE config 5, CF32 leg)"),
     "5h": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF16", bytes=4 + 4 / 32, flop=128, gain=1.0,
                kernel="sxfir::decim_multi_kernel<32, 4, CF16>",

@@ -40,7 +40,7 @@
     X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
-    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576)
+    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112)
 // variants that also exist with phase stamps (ABL 5)
 #define SXFIR_TILE2_STAMPED(X) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
@@ -95,7 +95,7 @@ struct sxfir_plan {
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
-    bool dense32;          // decim32_dense_kernel (ratio 32, 1024 taps, CF32 / S32): the linear-image form
+    bool dense32;          // decim_dense_kernel (ratio 8 / 16 / 32, 32 taps per phase, CF32 / S32): the linear-image form
     int multi_waves;       // waves per workgroup of the multi kernel
     int multi_ps;          // lanes that share the 32 tap rows of one output (2 or 4) in the multi kernel
     int occ_multi;         // resident workgroups per CU of the multi kernel
@@ -253,9 +253,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // halo stays a small part of the staging
     p->multi_waves = ratio <= 4 ? 1 : 4;
     p->multi_ps = 2;
-    // ratio 32 (1024 taps) on CF32 / S32 words: the linear-image form (sxfir_decim_dense.hip.h), four workgroups
-    // per CU instead of three
-    p->dense32 = p->multi_capable && ratio == 32 && fmt != SXFIR_CF16;
+    // CF32 / S32 words at ratio 8, 16, 32: the linear-image form (sxfir_decim_dense.hip.h); CF16 and ratio 4 keep
+    // the multi-column kernel
+    p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && fmt != SXFIR_CF16;
     p->t2_wpg = p->t2_opt = 0;
     p->pair = false;
     p->pair_xsep = false;
@@ -299,8 +299,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         const void *k = nullptr;
         if (p->dense32) {
-            k = fmt == SXFIR_S32 ? (const void *)sxfir::decim32_dense_kernel<0, true>
-                                 : (const void *)sxfir::decim32_dense_kernel<0, false>;
+            const bool w = fmt == SXFIR_S32;
+            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false>)
+                : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true> : (const void *)sxfir::decim_dense_kernel<16, 0, false>)
+                              : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true> : (const void *)sxfir::decim_dense_kernel<32, 0, false>);
         } else if (fmt == SXFIR_S32) {   // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
             k = ratio == 8    ? (const void *)sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>
                 : ratio == 16 ? (const void *)sxfir::decim_multi_kernel<16, 4, false, 0, 2, true>
@@ -323,8 +325,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         // 128 symmetric taps (every linear-phase design): the scalar-tap form of the tile kernel
         const void *ksb = (ntaps == 128 && p->symmetric)
-                              ? (fmt == SXFIR_S32 ? (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR, 0, true>
-                                                  : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR>)
+                              ? (fmt == SXFIR_S32 ? (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED, 0, true>
+                                                  : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>)
                               : (ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
                                               : (const void *)sxfir::decim4_tile_kernel<64, false>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
@@ -589,6 +591,13 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         a.stamps = nullptr;
         if (p->dense32) {
+#define SXFIR_DENSE_LAUNCH(DD, AA, SS) hipLaunchKernelGGL((sxfir::decim_dense_kernel<DD, AA, SS>), grid, dim3(256), 0, st, a)
+#define SXFIR_DENSE_BY_RATIO(AA, SS) \
+    do { \
+        if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, AA, SS); \
+        else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, AA, SS); \
+        else SXFIR_DENSE_LAUNCH(32, AA, SS); \
+    } while (0)
 #ifdef SXFIR_PROFILING
             if (p->ablate == 3) {
                 const size_t need = (size_t)groups * p->nchan * W;
@@ -597,13 +606,15 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 p->stamps_n = need;
                 a.stamps = (unsigned long long *)p->stamps_dev;
             }
-            if (p->fmt != SXFIR_S32 && p->ablate == 1) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<1, false>), grid, dim3(256), 0, st, a);
-            else if (p->fmt != SXFIR_S32 && p->ablate == 2) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<2, false>), grid, dim3(256), 0, st, a);
-            else if (p->fmt != SXFIR_S32 && p->ablate == 3) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<3, false>), grid, dim3(256), 0, st, a);
+            if (p->fmt != SXFIR_S32 && p->ablate == 1) SXFIR_DENSE_BY_RATIO(1, false);
+            else if (p->fmt != SXFIR_S32 && p->ablate == 2) SXFIR_DENSE_BY_RATIO(2, false);
+            else if (p->fmt != SXFIR_S32 && p->ablate == 3) SXFIR_DENSE_BY_RATIO(3, false);
             else
 #endif
-            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim32_dense_kernel<0, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((sxfir::decim32_dense_kernel<0, false>), grid, dim3(256), 0, st, a);
+            if (p->fmt == SXFIR_S32) SXFIR_DENSE_BY_RATIO(0, true);
+            else SXFIR_DENSE_BY_RATIO(0, false);
+#undef SXFIR_DENSE_BY_RATIO
+#undef SXFIR_DENSE_LAUNCH
             HIPCHECK(hipGetLastError());
             *history_done = true;
             return SXFIR_OK;
@@ -855,9 +866,9 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         // (with one wave per workgroup both kernels take the same schedule constants)
         if (p->ntaps == 128 && p->symmetric && p->sched != 1) {
             if (p->fmt == SXFIR_S32)
-                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR, 0, true>), grid, dim3(64), 0, st, a);
+                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED, 0, true>), grid, dim3(64), 0, st, a);
             else
-                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SCALAR>), grid, dim3(64), 0, st, a);
+                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>), grid, dim3(64), 0, st, a);
         } else if (p->fmt == SXFIR_S32)
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
         else if (p->ntaps == 128)

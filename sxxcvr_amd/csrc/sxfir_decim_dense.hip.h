@@ -1,27 +1,32 @@
-// Decimate-by-32, 1024 taps (32 per phase), CF32 or S32 wire words: the dense-image form of the
-// multi-column decimator (sxfir_decim_multi.hip.h) for BASELINE config 5.  New code: the reference
-// decimates inside the SX1255 (SoapySX.cpp:180-208 only programs the chip's divider).
+// Decimate-by-D (D = 8, 16, 32), 32 taps per phase (NT = 32*D), CF32 or S32 wire words: the dense-image
+// form of the multi-column decimator (sxfir_decim_multi.hip.h) for BASELINE configs 3 (RX) and 5.  New code:
+// the reference decimates inside the SX1255 (SoapySX.cpp:180-208 only programs the chip's divider).
 //
-// Same arithmetic, same numeric contract (2, 4) as decim_multi_kernel<32, 4>: lanes = (row half p,
-// column group c of four phases, output group of 8), a 64-tap fmaf chain per lane and output, then the
-// adjacent-pair tree over p and over the eight column groups.  What changes is the LDS image and
-// everything that follows from it:
+// Same arithmetic, same numeric contract (2, 4) as decim_multi_kernel<D, 4>: lanes = (row half p, column
+// group c of four phases, output group of 8), a 64-tap fmaf chain per lane and output, then the
+// adjacent-pair tree over p and over the D/4 column groups.  What changes is the LDS image and everything
+// that follows from it:
 //
-//   * The tile (128 outputs + 31 halo rows = 159 rows of 32 samples = 40 704 bytes) sits in LDS as it
-//     sits in HBM: linear.  A DMA instruction (global_load_lds_dwordx4) moves 1 KiB of CONSECUTIVE bytes —
-//     eight whole lines — instead of 64 pieces picked from 32 different rows, so the 40 instructions of a
-//     tile are cheap to issue (the de-interleaved image needed 48 of the expensive kind: DESIGN.md 5.2).
-//   * One 16-byte pad slot after every 16 rows (between DMA instructions, so the pads cost no traffic):
-//     40 848 bytes per workgroup, FOUR workgroups (16 waves) per CU where the de-interleaved image
-//     (48 KiB) left three.
-//   * Bank conflicts: chunk k = 14 - 2c + h of a row holds column group c, half h.  With the lane bits
-//     (b0..b5) = (c1, c2, g1, c0, p, g0) the 16 lanes a ds_read_b128 is served with (MI355X_MICROARCH.md,
-//     LDS: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32) either hit 16 different slots mod 16 or the
-//     same address: c supplies the even residues, the pad count (g1 - p) the odd ones, and two lanes
-//     with g1 - p equal read the same window.  g0 (an offset of 8 rows, where the pads fall at other
-//     steps) is bit 5, which never varies inside a group.  Exhaustive check: tools/lds_bank_model.py.
-//   * Reduction without LDS: v_permlane16_swap over p (bit 4), then DPP butterflies over c0 (row_ror:8),
-//     c1 and c2 (quad_perm): the contract's tree ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)).
+//   * The tile (TILE_OUT outputs + 31 halo rows of D samples) sits in LDS as it sits in HBM: linear.  A DMA
+//     instruction (global_load_lds_dwordx4) moves 1 KiB of CONSECUTIVE bytes -- eight whole lines -- instead
+//     of 64 pieces picked from up to 32 different rows, so it is cheap to issue and a tile needs fewer of
+//     them (/32: 40 instead of 48).
+//   * One 16-byte pad slot after every PADROWS rows (between DMA instructions: the pads cost no traffic).
+//     /32: 40 848 bytes per workgroup, FOUR workgroups (16 waves) per CU where the de-interleaved image
+//     (48 KiB) left three; /16: 37 296, /8: 35 280 bytes.
+//   * Bank conflicts: chunk CPR - 2 - 2c + h of a row holds half h of column group c, so c supplies even
+//     residues (mod 16 slots) and the pad count before a lane's rows the rest.  For each D a lane map
+//     (which lane bit is which of c, p, g) exists under which the 16 lanes a ds_read_b128 is served with
+//     (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32) either hit 16 different
+//     slots mod 16 or the very same address (lanes whose rows coincide read the same window: a broadcast).
+//     Found by exhaustive search over the 720 assignments and checked by tools/lds_bank_model.py; among
+//     the conflict-free maps the one with the cheapest reduction is used:
+//         D = 32, pad per 16 rows: (b0..b5) = (c1, c2, g1, c0, p, g0)
+//         D = 16, pad per  8 rows: (b0..b5) = (g0, g2, g1, c1, p, c0)
+//         D =  8, pad per 16 rows: (b0..b5) = (g2, g3, g1, c0, p, g0)
+//   * Reduction without LDS, in the contract's order: v_permlane16_swap over p (bit 4 in all three maps), then
+//     the column tree with v_permlane32_swap where a column bit is lane bit 5 and DPP butterflies elsewhere
+//     (row_ror:8 for bit 3, quad_perm for bits 0 and 1).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -31,23 +36,29 @@
 
 namespace sxfir {
 
-struct DecimDense32 {
-    static constexpr int D = 32;
-    static constexpr int NT = 1024;
+template <int D>
+struct DecimDense {
+    static_assert(D == 8 || D == 16 || D == 32, "dense image: D = 8, 16 or 32");
+    static constexpr int NT = 32 * D;
+    static constexpr int NCOL = D / 4;
     static constexpr int W = 4;                       // waves per workgroup
-    static constexpr int OW = 32;                     // outputs per wave (4 groups of 8)
-    static constexpr int TILE_OUT = W * OW;           // 128
+    static constexpr int GW = 32 / NCOL;              // output groups (of 8) per wave
+    static constexpr int OW = 8 * GW;                 // outputs per wave
+    static constexpr int TILE_OUT = W * OW;           // 512 / 256 / 128
     static constexpr int NROWS = TILE_OUT + 31;       // rows q in [M0 - 31, M0 + TILE_OUT)
-    static constexpr int CPR = 16;                    // 16-byte chunks per row
-    static constexpr int CH = NROWS * CPR;            // 2544 chunks
-    static constexpr int PADROWS = 16;                // one pad slot after every 16 rows (4 DMA instructions)
-    static constexpr int NI = (CH + 63) / 64;         // 40 DMA instructions per tile
-    static constexpr int NIW = NI / W;                // 10 per wave
-    static constexpr int LAST_LANES = CH - 64 * (NI - 1);   // 48 lanes of the last instruction are inside the image
-    static constexpr int LDS_SLOTS = CH + (NROWS - 1) / PADROWS;   // 2553 slots = 40 848 bytes
+    static constexpr int CPR = D / 2;                 // 16-byte chunks per row
+    static constexpr int CH = NROWS * CPR;            // chunks of the image
+    static constexpr int RPI = 64 / CPR;              // rows per DMA instruction
+    static constexpr int PADROWS = D == 16 ? 8 : 16;  // one pad slot after every PADROWS rows
+    static constexpr int NI = (CH + 63) / 64;         // DMA instructions per tile
+    static constexpr int NIW = (NI + W - 1) / W;      // at most this many per wave
+    static constexpr int LAST_LANES = CH - 64 * (NI - 1);   // lanes of the last instruction that are inside the image
+    static constexpr int LDS_SLOTS = CH + (NROWS - 1) / PADROWS;
     static constexpr int WCH = 46;                    // window chunks per lane: 23 rows x 2
-    static_assert(NI % W == 0, "the waves share the DMA instructions evenly");
+    static_assert(PADROWS % RPI == 0 && PADROWS % 8 == 0, "pads fall between DMA instructions and between 8-row window segments");
     static_assert(LDS_SLOTS * 16 <= 160 * 1024 / 4, "four workgroups per CU");
+    // LDS slot the DMA instruction i (image chunks [64i, 64i + 64)) starts at
+    static constexpr int dma_slot(int i) { return 64 * i + (i * RPI) / PADROWS; }
 };
 
 template <int CTRL>
@@ -56,32 +67,44 @@ __device__ __forceinline__ float dpp_f32(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// butterfly over one lane bit (0, 1 or 3): both lanes of a pair end with the sum
+template <int BIT>
+__device__ __forceinline__ float butterfly_add(float v)
+{
+    static_assert(BIT == 0 || BIT == 1 || BIT == 3, "quad_perm covers lane bits 0 and 1, row_ror:8 bit 3");
+    if constexpr (BIT == 0) return __fadd_rn(v, dpp_f32<0xB1>(v));        // quad_perm [1,0,3,2]
+    else if constexpr (BIT == 1) return __fadd_rn(v, dpp_f32<0x4E>(v));   // quad_perm [2,3,0,1]
+    else return __fadd_rn(v, dpp_f32<0x128>(v));                          // row_ror:8 = lane ^ 8 inside a row of 16
+}
+
 // ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
 // kernel with s_memtime stamps around its phases (a.stamps, 5 counters per wave as decim_multi_kernel)
-template <int ABL = 0, bool S32IN = false>
+template <int D, int ABL = 0, bool S32IN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void
-decim32_dense_kernel(const DecimMultiArgs a)
+decim_dense_kernel(const DecimMultiArgs a)
 {
-    using C = DecimDense32;
+    using C = DecimDense<D>;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int ww = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = ((lane >> 3) & 1) | ((lane & 1) << 1) | (((lane >> 1) & 1) << 2);   // c0 = b3, c1 = b0, c2 = b1
-    const int p = (lane >> 4) & 1;
-    const int g1 = (lane >> 2) & 1, g0 = lane >> 5;
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = lane >> 5;
+    // the lane maps of the header comment
+    const int p = b4;
+    const int c = D == 32 ? (b3 | (b0 << 1) | (b1 << 2)) : (D == 16 ? (b5 | (b3 << 1)) : b3);
+    const int G = D == 32 ? (b5 | (b2 << 1)) : (D == 16 ? (b0 | (b2 << 1) | (b1 << 2)) : (b5 | (b2 << 1) | (b0 << 2) | (b1 << 3)));
     const int ch = blockIdx.y;
 
     const char *in = reinterpret_cast<const char *>(a.in) + 8LL * a.in_stride * ch;
     const char *hist = reinterpret_cast<const char *>(a.hist) + 8LL * a.hist_stride * ch;
     char *out = reinterpret_cast<char *>(a.out) + 8LL * a.out_stride * ch;
 
-    // lane taps: h[kl], kl = 4*jj + rr  <->  tap 32*(16*p + jj) + 4c + rr
+    // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16*p + jj) + 4c + rr
     f32x2 hp[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-        const float *t = a.taps + 32 * (16 * p + (k >> 1)) + 4 * c + 2 * (k & 1);
+        const float *t = a.taps + D * (16 * p + (k >> 1)) + 4 * c + 2 * (k & 1);
         float t0 = t[0], t1 = t[1];
         if constexpr (S32IN) {                        // a power of two commutes with the FMA
             t0 = __fmul_rn(t0, 4.656612873077393e-10f);
@@ -90,12 +113,14 @@ decim32_dense_kernel(const DecimMultiArgs a)
         hp[k] = (f32x2){t0, t1};
     }
 
-    // window: rows 8u .. 8u + 22 of the image (u = output group - 2p + 2), chunks 14 - 2c + {0, 1} of each;
-    // slot = chunk + (pads before its row).  The pads of a window fall after its row 16 (g0 = 0) or 8
-    // (g0 = 1): base A serves steps [0, 16), B = A + g0 steps [16, 32), A + 1 steps [32, 46).
-    const int u = 4 * ww + 2 * g1 + g0 - 2 * p + 2;
-    const f32x4 *winA = lds + (128 * u + 14 - 2 * c + (u >> 1));
-    const f32x4 *winB = winA + g0;
+    // Window: rows 8u .. 8u + 22 of the image (u = output group - 2p + 2), chunks CPR - 2 - 2c + {0, 1} of each;
+    // slot = chunk + (pads before its row).  The window's three 8-row segments -- steps [0, 16), [16, 32),
+    // [32, 46) -- each lie between two pad positions, so a segment has one base: win[r] = chunk 0 of the
+    // window + pads before row 8u + 8r.
+    const int u = C::GW * ww + G - 2 * p + 2;
+    const f32x4 *win0 = lds + (C::CPR * 8 * u + C::CPR - 2 - 2 * c + (8 * u) / C::PADROWS);
+    const f32x4 *win1 = win0 + ((8 * u + 8) / C::PADROWS - (8 * u) / C::PADROWS);
+    const f32x4 *win2 = win0 + ((8 * u + 16) / C::PADROWS - (8 * u) / C::PADROWS);
 
     const int NG = a.n_groups;
     const int first_tile = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
@@ -118,12 +143,15 @@ decim32_dense_kernel(const DecimMultiArgs a)
         tk = t_now; \
     }
 
-    // HBM -> LDS for one tile: instruction i = ww + 4*i0 moves image chunks [64i, 64i + 64) to slots
-    // 64i + i/4 onwards (i/4 = i0: the pads before it)
+    // HBM -> LDS for one tile: instruction i = ww + 4*i0 moves image chunks [64i, 64i + 64) to the slots from
+    // dma_slot(i) on.  dma_slot(ww + 4*i0) = dma_slot(4*i0) + (64 + PER_I) * ww: /32 has no pad inside a group
+    // of four instructions (PER_I = 0), /16 and /8 one after every instruction (PER_I = 1).
+    constexpr int PER_I = C::dma_slot(1) - 64;
+    static_assert(C::dma_slot(7) == C::dma_slot(4) + 3 * (64 + PER_I), "pads inside a group of four instructions are uniform");
     auto stage = [&](int tile) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
-        const long long s_first = 32 * (M0 - 31) - 31;                   // first sample of the image
-        const bool interior = s_first >= 0 && 32 * (M0 + C::TILE_OUT - 1) <= a.n_in - 1;
+        const long long s_first = D * (M0 - 31) - (D - 1);               // first sample of the image
+        const bool interior = s_first >= 0 && D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1;
         const char *base = in + 8 * s_first + 1024 * ww;
         if constexpr (ABL == 2) return;
         if (interior) {
@@ -131,29 +159,31 @@ decim32_dense_kernel(const DecimMultiArgs a)
             for (int i0 = 0; i0 < C::NIW; ++i0) {
                 unsigned lo = 16u * lane;
                 asm volatile("" : "+v"(lo));          // a 32-bit offset next to its use: SGPR base + VGPR offset form
-                // the tile's last instruction: 48 of its lanes are inside the image
                 const char *bi = base + 4096 * i0;
                 asm volatile("" : "+s"(bi));          // ... and the instruction's own base stays a scalar
-                if (i0 < C::NIW - 1 || ww < C::W - 1 || lane < C::LAST_LANES)
-                    glds16(bi + lo, lds + (64 * ww + 257 * i0));
+                const int i = ww + 4 * i0;
+                // the image's last instruction is only partly inside it
+                if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES))
+                    glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
             }
         } else {
             // edge tiles (first / last of a call): through registers, sample by sample
             const long long last = a.n_in - 1;
 #pragma nounroll
             for (int i0 = 0; i0 < C::NIW; ++i0) {
-                if (i0 < C::NIW - 1 || ww < C::W - 1 || lane < C::LAST_LANES) {
+                const int i = ww + 4 * i0;
+                if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES)) {
                     unsigned wds[4];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const long long s = s_first + 2 * (64 * (ww + 4 * i0) + lane) + e;
+                        const long long s = s_first + 2 * (64 * i + lane) + e;
                         const char *src = s >= 0 ? in + 8 * (s <= last ? s : last)
                                                  : hist + 8 * (s + C::NT >= 0 ? s + C::NT : 0);
                         wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
                         wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
                     }
-                    lds[64 * ww + 257 * i0 + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]),
-                                                             __uint_as_float(wds[2]), __uint_as_float(wds[3])};
+                    lds[64 * i + (i * C::RPI) / C::PADROWS + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]),
+                                                                            __uint_as_float(wds[2]), __uint_as_float(wds[3])};
                 }
             }
         }
@@ -174,8 +204,8 @@ decim32_dense_kernel(const DecimMultiArgs a)
         if constexpr (ABL != 1)
 #pragma unroll
         for (int t = 0; t < C::WCH; ++t) {
-            const f32x4 *wp = t < 16 ? winA : (t < 32 ? winB : winA + 1);
-            const f32x4 v = wp[16 * (t >> 1) + (t & 1)];
+            const f32x4 *wp = t < 16 ? win0 : (t < 32 ? win1 : win2);
+            const f32x4 v = wp[C::CPR * (t >> 1) + (t & 1)];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int w = 2 * t + s;
@@ -202,7 +232,7 @@ decim32_dense_kernel(const DecimMultiArgs a)
         SXFIR_PHASE(4)
 
         // ---- reduction in the order of the numeric contract.  p (lane bit 4): even 16-lane rows keep
-        // outputs 0-3, odd rows 4-7
+        // outputs 0-3 of the lane's 8, odd rows 4-7
         float ri[4], rq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -211,34 +241,53 @@ decim32_dense_kernel(const DecimMultiArgs a)
             ri[i] = __fadd_rn(ai[i], ai[i + 4]);
             rq[i] = __fadd_rn(aq[i], aq[i + 4]);
         }
-        // column groups: c0 = lane bit 3 (row_ror:8 = lane ^ 8 inside a row of 16), c1 = bit 0, c2 = bit 1
+        const long long mg = M0 + C::OW * ww + 8 * G + 4 * p;            // first of the 4 outputs held now
+        if constexpr (D == 16) {
+            // c0 = lane bit 5: the low half-wave keeps outputs 0-1 of those four, the high half 2-3; c1 = bit 3
+            float si[2], sq[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ri[i] = __fadd_rn(ri[i], dpp_f32<0x128>(ri[i]));
-            rq[i] = __fadd_rn(rq[i], dpp_f32<0x128>(rq[i]));
-        }
+            for (int i = 0; i < 2; ++i) {
+                permlane32_swap(ri[i], ri[i + 2]);
+                permlane32_swap(rq[i], rq[i + 2]);
+                si[i] = butterfly_add<3>(__fadd_rn(ri[i], ri[i + 2]));
+                sq[i] = butterfly_add<3>(__fadd_rn(rq[i], rq[i + 2]));
+            }
+            const long long m = mg + 2 * b5;
+            if (b3 == 0) {
+                char *dst = out + 8 * m;
+                if (m + 2 <= a.n_out) __builtin_nontemporal_store((f32x4){si[0], sq[0], si[1], sq[1]}, reinterpret_cast<f32x4 *>(dst));
+                else if (m < a.n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(si[0], sq[0]);
+            }
+        } else {
+            // column groups by butterflies: /32: c0 = bit 3, c1 = bit 0, c2 = bit 1; /8: c0 = bit 3
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ri[i] = __fadd_rn(ri[i], dpp_f32<0xB1>(ri[i]));     // quad_perm [1,0,3,2]
-            rq[i] = __fadd_rn(rq[i], dpp_f32<0xB1>(rq[i]));
-        }
+            for (int i = 0; i < 4; ++i) {
+                ri[i] = butterfly_add<3>(ri[i]);
+                rq[i] = butterfly_add<3>(rq[i]);
+            }
+            if constexpr (D == 32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ri[i] = __fadd_rn(ri[i], dpp_f32<0x4E>(ri[i]));     // quad_perm [2,3,0,1]
-            rq[i] = __fadd_rn(rq[i], dpp_f32<0x4E>(rq[i]));
-        }
-        // every lane of a column octet holds outputs 4p .. 4p+3 of its group; the lanes with c0 = c2 = 0
-        // store two of them each (c1 picks the pair): 16 lanes, 256 consecutive bytes per wave
-        const int b0 = lane & 1;
-        const long long m = M0 + 32 * ww + 16 * g1 + 8 * g0 + 4 * p + 2 * b0;
-        if ((lane & 0xA) == 0) {
-            const float s0 = b0 ? ri[2] : ri[0], s1 = b0 ? rq[2] : rq[0];
-            const float s2 = b0 ? ri[3] : ri[1], s3 = b0 ? rq[3] : rq[1];
-            char *dst = out + 8 * m;
-            if (m + 2 <= a.n_out) {
-                __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
-            } else if (m < a.n_out) {
-                reinterpret_cast<float2 *>(dst)[0] = make_float2(s0, s1);
+                for (int i = 0; i < 4; ++i) {
+                    ri[i] = butterfly_add<0>(ri[i]);
+                    rq[i] = butterfly_add<0>(rq[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ri[i] = butterfly_add<1>(ri[i]);
+                    rq[i] = butterfly_add<1>(rq[i]);
+                }
+            }
+            // every lane of a column group set holds the same four outputs; two lanes of it store a pair each:
+            // /32: the lanes with c0 = c2 = 0, c1 (bit 0) picks the pair; /8: both lanes, c0 (bit 3) picks the pair
+            const int sel = D == 32 ? b0 : b3;
+            const bool writer = D == 32 ? (lane & 0xA) == 0 : true;
+            const long long m = mg + 2 * sel;
+            if (writer) {
+                const float s0 = sel ? ri[2] : ri[0], s1 = sel ? rq[2] : rq[0];
+                const float s2 = sel ? ri[3] : ri[1], s3 = sel ? rq[3] : rq[1];
+                char *dst = out + 8 * m;
+                if (m + 2 <= a.n_out) __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
+                else if (m < a.n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(s0, s1);
             }
         }
         if constexpr (ABL == 3) ph[0] += 1;

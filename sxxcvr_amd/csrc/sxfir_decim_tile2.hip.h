@@ -50,7 +50,14 @@
 namespace sxfir {
 
 enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16, T2_PRIO = 32, T2_SCALAR = 64, T2_CUQ = 128,
-       T2_MASKPAD = 256, T2_KARG = 512 };
+       T2_MASKPAD = 256, T2_KARG = 512,
+       // issue order of the 16 packed FMAs of a step (same chains, same bits): XGROUP = the four FMAs that share a
+       // sample pair back to back (P1's four, then P0's four), XSTREAM = all eight of a window chunk back to back
+       T2_XGROUP = 1024, T2_XSTREAM = 2048,
+       // what the production library launches for 128 symmetric taps: scalar taps, and the FMAs that share a sample
+       // pair issued back to back (round 3: 1.3 % less time at the power cap than alternating the two sample streams,
+       // profiles/round3j_kbench_fma_order.txt; the x operand of four consecutive FMAs does not toggle)
+       T2_SHIPPED = T2_SCALAR | T2_XGROUP };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -189,7 +196,22 @@ __device__ __forceinline__ void pk_fma_s_hi(f32x2 &acc, const f32x2 &hpair, cons
 // function template per step instead of a loop: every tap index must be a compile-time constant for the
 // taps to stay in SGPRs, and the loop form is too large for the unroller's budget (it then indexes the tap
 // array dynamically, through scratch memory).
-template <bool S32IN, int T>
+template <int WHICH, int S, int T>
+__device__ __forceinline__ void fir_sym_quad(const f32x2 &x, const f32x2 (&hs)[32], f32x2 (&acc)[4])
+{
+    // the (up to) four FMAs of stream WHICH (1 = P1, 0 = P0) that use sample pair S of step T
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k0 = 4 * i + 64 - (2 * T + S);
+        if (k0 >= 0 && k0 < 64) {
+            const int k = WHICH ? 63 - k0 : k0;
+            if (k & 1) pk_fma_s_hi(acc[i], hs[k >> 1], x);
+            else pk_fma_s_lo(acc[i], hs[k >> 1], x);
+        }
+    }
+}
+
+template <bool S32IN, int T, int ORDER = 0>
 __device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], f32x2 (&a1)[4],
                                              f32x2 (&a0)[4])
 {
@@ -201,6 +223,22 @@ __device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, c
                      (float)__float_as_int(v1.w)};
         v0 = (f32x4){(float)__float_as_int(v0.x), (float)__float_as_int(v0.y), (float)__float_as_int(v0.z),
                      (float)__float_as_int(v0.w)};
+    }
+    if constexpr (ORDER != 0) {
+        const f32x2 x1l = __builtin_shufflevector(v1, v1, 0, 1), x1h = __builtin_shufflevector(v1, v1, 2, 3);
+        const f32x2 x0l = __builtin_shufflevector(v0, v0, 0, 1), x0h = __builtin_shufflevector(v0, v0, 2, 3);
+        if constexpr (ORDER == 1) {
+            fir_sym_quad<1, 0, T>(x1l, hs, a1);
+            fir_sym_quad<0, 0, T>(x0l, hs, a0);
+            fir_sym_quad<1, 1, T>(x1h, hs, a1);
+            fir_sym_quad<0, 1, T>(x0h, hs, a0);
+        } else {
+            fir_sym_quad<1, 0, T>(x1l, hs, a1);
+            fir_sym_quad<1, 1, T>(x1h, hs, a1);
+            fir_sym_quad<0, 0, T>(x0l, hs, a0);
+            fir_sym_quad<0, 1, T>(x0h, hs, a0);
+        }
+        return;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -221,21 +259,21 @@ __device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, c
     }
 }
 
-template <bool S32IN, int... Ts>
+template <bool S32IN, int ORDER, int... Ts>
 __device__ __forceinline__ void fir_sym_steps(std::integer_sequence<int, Ts...>, const f32x4 *w1, const f32x4 *w2,
                                               const f32x2 (&hs)[32], f32x2 (&a1)[4], f32x2 (&a0)[4])
 {
-    (fir_sym_step<S32IN, Ts>(w1, w2, hs, a1, a0), ...);
+    (fir_sym_step<S32IN, Ts, ORDER>(w1, w2, hs, a1, a0), ...);
 }
 
-template <bool S32IN>
+template <bool S32IN, int ORDER = 0>
 __device__ __forceinline__ void fir_tile_sym(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], float (&oi)[4],
                                              float (&oq)[4])
 {
     f32x2 a1[4], a0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a1[i] = (f32x2){0.0f, 0.0f}; a0[i] = (f32x2){0.0f, 0.0f}; }
-    fir_sym_steps<S32IN>(std::make_integer_sequence<int, 39>{}, w1, w2, hs, a1, a0);
+    fir_sym_steps<S32IN, ORDER>(std::make_integer_sequence<int, 39>{}, w1, w2, hs, a1, a0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         oi[i] = __fadd_rn(a0[i].x, a1[i].x);
@@ -455,7 +493,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             for (int i = 0; i < 4; ++i) { oi[i] = v0[i] + hp[0].x + hs[3].y; oq[i] = v1[i] + hp[SCALAR ? 0 : 31 % (C::TPL / 2)].y; }
         } else {
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
-            if constexpr (SCALAR) fir_tile_sym<S32IN>(buf + woff, buf + woff2, hs, oi, oq);
+            if constexpr (SCALAR) fir_tile_sym<S32IN, (OPT & T2_XGROUP) ? 1 : ((OPT & T2_XSTREAM) ? 2 : 0)>(buf + woff, buf + woff2, hs, oi, oq);
             else fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }

@@ -281,24 +281,27 @@ def test_every_configuration_against_scipy_fp64(name, mode, ntaps, ratio, fmt):
     assert err <= tol, "%s: max |GPU - scipy fp64| = %.3g > %.3g" % (name, err, tol)
 
 
+@pytest.mark.parametrize("D", [8, 16, 32])
 @pytest.mark.parametrize("nchan,pad", [(1, 0), (3, 6)])
-def test_dense32_kernel_edges(oracle, nchan, pad):
-    """decim32_dense_kernel (/32, 1024 taps, linear LDS image) at its seams, with ASYMMETRIC random taps so that a lane
-    that picked the wrong tap, row or column group cannot hide: calls of one output, of one tile (128 outputs) minus /
-    plus one, of many tiles plus a ragged tail, several channels with a stride that is not the block length; history
-    carried from call to call (the first tile of every call reads the previous call's tail through the plan's history,
-    the last tile clamps at the block's end).  Bit-exact against the oracle with the plan's contract (2, 4); a final
-    block that is not a multiple of 32 goes through the generic kernel and must continue the same stream."""
+def test_dense_kernel_edges(oracle, D, nchan, pad):
+    """decim_dense_kernel<D> (/8, /16, /32 with 32 taps per phase, linear LDS image) at its seams, with ASYMMETRIC
+    random taps so that a lane that picked the wrong tap, row or column group cannot hide: calls of one output, of one
+    tile (512 / 256 / 128 outputs) minus / plus one, of many tiles plus a ragged tail, several channels with a stride
+    that is not the block length; history carried from call to call (the first tile of every call reads the previous
+    call's tail through the plan's history, the last tile clamps at the block's end).  Bit-exact against the oracle
+    with the plan's contract (2, 4); a final block that is not a multiple of D goes through the generic kernel and
+    must continue the same stream."""
     import torch
     from sxxcvr_amd.resampler import KERNEL_TILED
-    h = (np.random.default_rng(32).standard_normal(1024) / 64.0).astype(np.float32)
-    outs = (1, 127, 128, 129, 2, 40 * 128 + 77, 128 * 3, 31)
+    h = (np.random.default_rng(D).standard_normal(32 * D) / 64.0).astype(np.float32)
+    T = 4096 // D                                       # outputs per workgroup tile
+    outs = (1, T - 1, T, T + 1, 2, 40 * T + 77, T * 3, 31)
     if nchan > 1:                                       # the tiled kernels take an even output stride between channels
-        outs = (2, 126, 128, 130, 2, 40 * 128 + 78, 128 * 3, 30)
-    blocks = [32 * m for m in outs] + [32 * 5 + 13, 32 * 9 + 19]
+        outs = (2, T - 2, T, T + 2, 2, 40 * T + 78, T * 3, 30)
+    blocks = [D * m for m in outs] + [D * 5 + D // 2 - 3, D * 9 + D // 2 + 3]
     total = sum(blocks)
     xs = [oracle.synth_iq(0x51255, 70 + c, 0, total) for c in range(nchan)]
-    plan = sxxcvr_amd.Resampler(DECIMATE, h, 32, nchan=nchan)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D, nchan=nchan)
     assert plan.contract == (2, 4)
     got = [[] for _ in range(nchan)]
     pos = 0
@@ -318,5 +321,5 @@ def test_dense32_kernel_edges(oracle, nchan, pad):
             got[c].append(y[c])
         pos += n
     for c in range(nchan):
-        ref = oracle.decim_f32(h, 32, xs[c], 2, 4)
-        assert_bit_exact(np.concatenate(got[c]), ref, "dense /32, channel %d of %d" % (c, nchan))
+        ref = oracle.decim_f32(h, D, xs[c], 2, 4)
+        assert_bit_exact(np.concatenate(got[c]), ref, "dense /%d, channel %d of %d" % (D, c, nchan))

@@ -141,3 +141,26 @@ def test_stream_placement_rules_against_the_oracle(tmp_path):
     subprocess.run(cmd, check=True)
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0 and run.stdout.strip().endswith("cases 400000 mismatches 0"), run.stdout[-1500:]
+
+
+def test_lds_bank_model_of_the_shipped_lane_maps():
+    """tools/lds_bank_model.py: the lane maps and pad periods compiled into decim_dense_kernel<8 / 16 / 32> and the
+    interpolator's lane map + XOR swizzle are free of LDS bank conflicts under the service groups of
+    MI355X_MICROARCH.md (a CPU model; the GPU counters that agree with it are in profiles/round3_*_summary.json)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "lds_bank_model.py")
+    run = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.count("-> 0 extra LDS cycles") == 3
+    # the maps in the tool are the maps in the kernel's header comment
+    hdr = open(os.path.join(root, "sxxcvr_amd", "csrc", "sxfir_decim_dense.hip.h")).read()
+    for D, bits in ((32, "c1, c2, g1, c0, p, g0"), (16, "g0, g2, g1, c1, p, c0"), (8, "g2, g3, g1, c0, p, g0")):
+        assert re.search(r"D = +%d, pad per +\d+ rows: \(b0\.\.b5\) = \(%s\)" % (D, re.escape(bits)), hdr), D
+        assert ("%d: (" % D) in open(tool).read()
+    run = subprocess.run([sys.executable, tool, "interp"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0
+    for L in (8, 16, 32):
+        assert re.search(r"x%-2d extra LDS cycles per sub-tile: window reads 0, transposition writes 0, read-back 0" % L, run.stdout), run.stdout

@@ -8,7 +8,7 @@
 #   bench[:config]      bench.py --config C (default 2) without the CPU legs
 #   benchfull           bench.py with everything (the driver's call)
 #   kb32 | kb32h | kb8 | kb16   kbench A/B of the /32 (CF32, CF16), /8, /16 kernels incl. ablations and stamps
-#   kb4                 the /4 production kernel + its memory side
+#   kb4                 the /4 production kernel + its memory side;  kb4o  FMA issue-order variants of it
 #   ib8                 interpolator x8 (tiled)
 #   pmc:D[,fmt]         LDS / VALU counters of one decimator shape (tools/pmc_pass.sh)
 #   profile:config      tools/profile_round.sh for one bench configuration
@@ -35,9 +35,10 @@ for S in "$@"; do
     benchfull) timeout 900 python3 bench.py >> $LOG 2>&1; tail -1 $LOG | cut -c1-3000 ;;
     kb32)     KB_D=32 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 dense:2:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -40 ;;
     kb32h)    KB_D=32 KB_FMT=CF16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
-    kb8)      KB_D=8 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
-    kb16)     KB_D=16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    kb8)      KB_D=8 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -24 ;;
+    kb16)     KB_D=16 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -20 ;;
     kb4)      KB_D=4 timeout 600 python3 tools/kbench.py x:16:0:0:0 t2.1.64:16:0:5:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    kb4o)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.64:16:0:0:0 t2.1.1088:16:0:0:0 t2.1.2112:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -10 ;;
     ib8)      KB_L=8 timeout 600 python3 tools/ibench.py >> $LOG 2>&1; tail -8 $LOG ;;
     pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; tail -2 $LOG ;;
     profile)  bash tools/profile_round.sh $TAG ${ARG:-2} >> $LOG 2>&1; tail -3 $LOG ;;

@@ -31,7 +31,7 @@ plans = []
 for v, ov, occ, abl, sched in configs:
     os.environ["SXFIR_TILE_VARIANT"] = v.replace(".", ":")      # "t2.2.3" -> "t2:2:3" (tile2 kernel: waves per workgroup, option bits)
     os.environ.pop("SXFIR_MULTI_W", None); os.environ.pop("SXFIR_MULTI_PS", None)
-    os.environ["SXFIR_DENSE"] = "0" if v[0] == "w" else "1"   # "dense" (or "x"): decim32_dense_kernel at /32; "w4": the multi-column kernel
+    os.environ["SXFIR_DENSE"] = "0" if v[0] == "w" else "1"   # "dense" (or "x"): decim_dense_kernel at /8, /16, /32; "w4": the multi-column kernel
     if v[0] == "w":                                  # "w4": multi kernel, 4 waves per workgroup; "w8p4": 4-way row split
         w, _, ps = v[1:].partition("p")
         os.environ["SXFIR_MULTI_W"] = w
