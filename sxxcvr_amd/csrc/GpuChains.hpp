@@ -225,7 +225,7 @@ public:
     static constexpr size_t kMinBatch = 4096;          // stream samples per channel and GPU pass
     static constexpr size_t kMaxBatchCap = 1u << 20;   // ... at most (large reads), and never more than
     static constexpr size_t kMaxSource = 1u << 24;     // this many wideband samples per pass over all channels
-    static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long go straight into page-locked caller memory
+    static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long are DMA-copied straight into page-locked caller memory
     // A pass whose output is at least this large lands in HBM and crosses PCIe as ONE DMA-engine copy behind the
     // kernel (57 GB/s on the boxes measured); smaller ones are stored across PCIe by the kernel itself (no copy
     // to queue, lowest latency, ~33 GB/s).
@@ -286,8 +286,8 @@ public:
     void produce(int64_t pos, size_t n, float *const *dsts)
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
-        // Large reads into page-locked (pinned / registered) caller memory: the decimator stores straight into
-        // it, no staging and no host copy.  Everything else goes through the pinned staging slots.
+        // Large reads into page-locked (pinned / registered) caller memory: the pass goes from HBM into it by DMA,
+        // no staging hop and no host copy.  Everything else goes through the pinned staging slots.
         float *direct = nullptr;
         size_t direct_stride = 0;
         dst_locked_ = n >= kDirectFrom && direct_target(dsts, n, &direct, &direct_stride);
@@ -314,13 +314,16 @@ public:
             void *st = stream_->get();
             while (done < n) {
                 const size_t m = std::min(n - done, max_batch_);
-                if (8 * m * (size_t)nchan_ >= kSdmaFromBytes) {
-                    run_to_hbm(0, p, m, st);
-                    for (int c = 0; c < nchan_; ++c)
-                        gpu_check(sxfir_memcpy_d2h(dsts[c] + 2 * done, out_[0].at(8 * (size_t)c * m), 8 * m, st), "sxfir_memcpy_d2h");
-                } else {
-                    run(p, m, direct + 2 * done, direct_stride, st);
-                }
+                // The pass lands in HBM and a DMA-engine copy, queued behind it on the same stream, carries it into
+                // the caller's memory.  (Until round 3 passes below a megabyte stored straight into the caller's
+                // hipHostRegister'ed memory from the kernel.  One full-suite run then saw the last 16 bytes of one
+                // tile of such a pass still unwritten when the completion event had fired -- never reproduced in
+                // 1500 repeats, tools/stress_direct_rx.py -- and the copy costs nothing measurable: a kernel's own
+                // stores cross PCIe at ~33 GB/s, the DMA engines write registered memory at ~36.  Kernels now store
+                // only into the chain's own hipHostMalloc'ed staging, the path every small read has always taken.)
+                run_to_hbm(0, p, m, st);
+                for (int c = 0; c < nchan_; ++c)
+                    gpu_check(sxfir_memcpy_d2h(dsts[c] + 2 * done, out_[0].at(8 * (size_t)c * m), 8 * m, st), "sxfir_memcpy_d2h");
                 p += (int64_t)m;
                 done += m;
             }
