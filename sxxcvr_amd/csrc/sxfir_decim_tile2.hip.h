@@ -57,6 +57,9 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // what the production library launches for 128 symmetric taps: scalar taps, and the FMAs that share a sample
        // pair issued back to back (round 3: 1.3 % less time at the power cap than alternating the two sample streams,
        // profiles/round3j_kbench_fma_order.txt; the x operand of four consecutive FMAs does not toggle)
+       // software-pipelined window reads (fir_tile_sym_pipe): the chunks of step T + PF are requested before the FMAs of
+       // step T, PF = 2 (PIPE2), 3 (PIPE3 = both bits) or 4 (PIPE4); x-grouped issue order
+       T2_PIPE2 = 4096, T2_PIPE4 = 8192,
        T2_SHIPPED = T2_SCALAR | T2_XGROUP };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
@@ -281,6 +284,87 @@ __device__ __forceinline__ void fir_tile_sym(const f32x4 *w1, const f32x4 *w2, c
     }
 }
 
+// ---- the same arithmetic with the window reads software-pipelined.  Left to itself hipcc places every
+// ds_read_b128 right before its first use and then waits for it with lgkmcnt(0): a wave exposes the whole LDS
+// latency once per step, and only its neighbours on the SIMD hide it.  Here the reads are volatile loads and the
+// FMAs volatile asm, which keeps them in program order: the chunks of step T + PF are requested before the FMAs
+// of step T, and the compiler's own s_waitcnt becomes a counted lgkmcnt(2 * PF - ...) that finds the data there.
+__device__ __forceinline__ void pk_fma_sv_lo(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_sv_hi(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
+}
+
+template <int WHICH, int S, int T>
+__device__ __forceinline__ void fir_sym_quad_v(const f32x2 &x, const f32x2 (&hs)[32], f32x2 (&acc)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k0 = 4 * i + 64 - (2 * T + S);
+        if (k0 >= 0 && k0 < 64) {
+            const int k = WHICH ? 63 - k0 : k0;
+            if (k & 1) pk_fma_sv_hi(acc[i], hs[k >> 1], x);
+            else pk_fma_sv_lo(acc[i], hs[k >> 1], x);
+        }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void fir_pipe_load(const f32x4 *w1, const f32x4 *w2, f32x4 (&q1)[39], f32x4 (&q0)[39])
+{
+    if constexpr (T < 39) {
+        constexpr int T0 = T + 32;
+        typedef const volatile __attribute__((address_space(3))) f32x4 *lds_vptr;   // volatile, and still an LDS pointer
+        q1[T] = *(lds_vptr)(((T & 15) >= 8 ? w2 : w1) + (T + (T >> 4)));
+        q0[T] = *(lds_vptr)(((T0 & 15) >= 8 ? w2 : w1) + (T0 + (T0 >> 4)));
+    }
+}
+
+template <bool S32IN, int T>
+__device__ __forceinline__ void fir_pipe_compute(const f32x4 (&q1)[39], const f32x4 (&q0)[39], const f32x2 (&hs)[32],
+                                                 f32x2 (&a1)[4], f32x2 (&a0)[4])
+{
+    f32x4 v1 = q1[T], v0 = q0[T];
+    if constexpr (S32IN) {
+        v1 = (f32x4){(float)__float_as_int(v1.x), (float)__float_as_int(v1.y), (float)__float_as_int(v1.z),
+                     (float)__float_as_int(v1.w)};
+        v0 = (f32x4){(float)__float_as_int(v0.x), (float)__float_as_int(v0.y), (float)__float_as_int(v0.z),
+                     (float)__float_as_int(v0.w)};
+    }
+    fir_sym_quad_v<1, 0, T>(__builtin_shufflevector(v1, v1, 0, 1), hs, a1);
+    fir_sym_quad_v<0, 0, T>(__builtin_shufflevector(v0, v0, 0, 1), hs, a0);
+    fir_sym_quad_v<1, 1, T>(__builtin_shufflevector(v1, v1, 2, 3), hs, a1);
+    fir_sym_quad_v<0, 1, T>(__builtin_shufflevector(v0, v0, 2, 3), hs, a0);
+}
+
+template <bool S32IN, int PF, int... Ps, int... Ts>
+__device__ __forceinline__ void fir_pipe_steps(std::integer_sequence<int, Ps...>, std::integer_sequence<int, Ts...>,
+                                               const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], f32x2 (&a1)[4],
+                                               f32x2 (&a0)[4])
+{
+    f32x4 q1[39], q0[39];
+    (fir_pipe_load<Ps>(w1, w2, q1, q0), ...);                                   // steps 0 .. PF-1
+    ((fir_pipe_load<Ts + PF>(w1, w2, q1, q0), fir_pipe_compute<S32IN, Ts>(q1, q0, hs, a1, a0)), ...);
+}
+
+template <bool S32IN, int PF>
+__device__ __forceinline__ void fir_tile_sym_pipe(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], float (&oi)[4],
+                                                  float (&oq)[4])
+{
+    f32x2 a1[4], a0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a1[i] = (f32x2){0.0f, 0.0f}; a0[i] = (f32x2){0.0f, 0.0f}; }
+    fir_pipe_steps<S32IN, PF>(std::make_integer_sequence<int, PF>{}, std::make_integer_sequence<int, 39>{}, w1, w2, hs, a1, a0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oi[i] = __fadd_rn(a0[i].x, a1[i].x);
+        oq[i] = __fadd_rn(a0[i].y, a1[i].y);
+    }
+}
+
 template <bool PLAIN>
 __device__ __forceinline__ void st16(const f32x4 &v, f32x4 *dst)
 {
@@ -493,7 +577,9 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             for (int i = 0; i < 4; ++i) { oi[i] = v0[i] + hp[0].x + hs[3].y; oq[i] = v1[i] + hp[SCALAR ? 0 : 31 % (C::TPL / 2)].y; }
         } else {
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
-            if constexpr (SCALAR) fir_tile_sym<S32IN, (OPT & T2_XGROUP) ? 1 : ((OPT & T2_XSTREAM) ? 2 : 0)>(buf + woff, buf + woff2, hs, oi, oq);
+            constexpr int PF = ((OPT & T2_PIPE2) ? 2 : 0) + ((OPT & T2_PIPE4) ? ((OPT & T2_PIPE2) ? 1 : 4) : 0);   // 0, 2, 3, 4
+            if constexpr (SCALAR && PF > 0) fir_tile_sym_pipe<S32IN, PF>(buf + woff, buf + woff2, hs, oi, oq);
+            else if constexpr (SCALAR) fir_tile_sym<S32IN, (OPT & T2_XGROUP) ? 1 : ((OPT & T2_XSTREAM) ? 2 : 0)>(buf + woff, buf + woff2, hs, oi, oq);
             else fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
