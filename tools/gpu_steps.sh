@@ -30,6 +30,7 @@ for S in "$@"; do
     testsall) timeout 2700 python3 -m pytest tests -m gpu -q >> $LOG 2>&1; tail -15 $LOG ;;          # no -x: every failure
     repeat)   for i in 1 2 3 4 5; do timeout 600 python3 -m pytest tests -m gpu -q -k "$ARG" 2>&1 | tail -3 >> $LOG; done; cat $LOG ;;
     repfile)  for i in 1 2 3 4 5 6 7 8; do timeout 900 python3 -m pytest $ARG -m gpu -q 2>&1 | grep -E "passed|failed|differ" | cut -c1-400 >> $LOG; done; cat $LOG ;;
+    devpath)  for n in ${ARG//,/ }; do timeout 300 python3 tools/devpath_probe.py $n 60 >> $LOG 2>&1; done; grep -v amdgpu.ids $LOG | tail -16 ;;
     stress)   timeout 900 python3 tools/stress_direct_rx.py ${ARG//,/ } >> $LOG 2>&1; grep -v amdgpu.ids $LOG | tail -25 ;;
     bench)    timeout 600 python3 bench.py --config ${ARG:-2} --no-cpu-baseline --no-through-device >> $LOG 2>&1; tail -1 $LOG | cut -c1-1500 ;;
     benchfull) timeout 900 python3 bench.py >> $LOG 2>&1; tail -1 $LOG | cut -c1-3000 ;;
