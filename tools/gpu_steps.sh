@@ -33,7 +33,7 @@ for S in "$@"; do
     devpath)  for n in ${ARG//,/ }; do timeout 300 python3 tools/devpath_probe.py $n 60 >> $LOG 2>&1; done; grep -v amdgpu.ids $LOG | tail -16 ;;
     stress)   timeout 900 python3 tools/stress_direct_rx.py ${ARG//,/ } >> $LOG 2>&1; grep -v amdgpu.ids $LOG | tail -25 ;;
     bench)    timeout 600 python3 bench.py --config ${ARG:-2} --no-cpu-baseline --no-through-device >> $LOG 2>&1; tail -1 $LOG | cut -c1-1500 ;;
-    benchfull) timeout 900 python3 bench.py >> $LOG 2>&1; tail -1 $LOG | cut -c1-3000 ;;
+    benchfull) T0=$(date +%s); timeout 900 python3 bench.py >> $LOG 2>&1; echo "bench.py wall seconds: $(( $(date +%s) - T0 ))" | tee -a $LOG; tail -2 $LOG | cut -c1-3000 ;;
     kb32)     KB_D=32 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 dense:2:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -40 ;;
     kb32h)    KB_D=32 KB_FMT=CF16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
     kb8)      KB_D=8 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -24 ;;
