@@ -128,7 +128,9 @@ for cfg in configs:
                                    "source": "profiles/%s_%s_summary.json" % (name, cfg),
                                    "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction)"}
     if "GRBM_GUI_ACTIVE" in pm and out.get("avg_ns_by_phase"):
-        out["effective_clock_mhz_from_GRBM"] = pm["GRBM_GUI_ACTIVE"] / 8.0 / out["avg_ns_by_phase"]["timed"] * 1e3
+        out["grbm_gui_active_over_8_over_duration_mhz"] = pm["GRBM_GUI_ACTIVE"] / 8.0 / out["avg_ns_by_phase"]["timed"] * 1e3
+        out["grbm_note"] = ("reads high on 0.5 ms dispatches (MI355X_MICROARCH.md, DVFS): not the shader clock; see "
+                            "bench.roofline.gfx_mhz_smi / shader_mhz and profiles/round3_clocks_and_power.txt")
     b = os.path.join(src, "bench.json")
     if os.path.exists(b):
         lines = [l for l in open(b) if l.startswith("{")]
