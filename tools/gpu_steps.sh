@@ -47,6 +47,7 @@ for S in "$@"; do
     pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; tail -2 $LOG ;;
     profile)  bash tools/profile_round.sh $TAG ${ARG:-2} >> $LOG 2>&1; tail -3 $LOG ;;
     clocks)   hipcc --offload-arch=gfx950 -O3 tools/clock_calib.hip -o /tmp/clock_calib >> $LOG 2>&1 && timeout 120 /tmp/clock_calib >> $LOG 2>&1; tail -9 $LOG ;;
+    mempower) timeout 300 python3 tools/mempower.py >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -5 ;;
     psplit)   timeout 300 python3 tools/power_split.py ${ARG:-4} >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -4 ;;
     pprobe)   timeout 300 python3 tools/power_probe.py ${ARG:-4} >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -6 ;;
     grbm)     # GRBM_GUI_ACTIVE on a short (2^28) and a long (2^34 samples, ~33 ms) dispatch of the same kernel
