@@ -63,7 +63,8 @@ def _compare_blocks(got, ref, what):
     return n
 
 
-@pytest.mark.parametrize("name,ntaps,ratio", [("config 2", 128, 4), ("config 3 RX", 256, 8), ("config 5 CF32", 1024, 32)])
+@pytest.mark.parametrize("name,ntaps,ratio", [("config 2", 128, 4), ("config 3 RX", 256, 8), ("decimate by 16", 512, 16),
+                                               ("config 5 CF32", 1024, 32)])
 def test_whole_stream_decimators_cf32(fast_oracle, name, ntaps, ratio):
     import torch
     _enough_memory(8)
