@@ -29,6 +29,7 @@ for S in "$@"; do
     tests)    if [ -n "$ARG" ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q -k "$ARG" >> $LOG 2>&1; else timeout 2400 python3 -m pytest tests -m gpu -x -q >> $LOG 2>&1; fi; tail -5 $LOG ;;
     testsall) timeout 2700 python3 -m pytest tests -m gpu -q >> $LOG 2>&1; tail -15 $LOG ;;          # no -x: every failure
     repeat)   for i in 1 2 3 4 5; do timeout 600 python3 -m pytest tests -m gpu -q -k "$ARG" 2>&1 | tail -3 >> $LOG; done; cat $LOG ;;
+    soak)     for i in $(seq 1 ${ARG:-16}); do timeout 900 python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|differ|Error" | cut -c1-300 >> $LOG; done; sort $LOG | uniq -c | tail -8 ;;
     repfile)  for i in 1 2 3 4 5 6 7 8; do timeout 900 python3 -m pytest $ARG -m gpu -q 2>&1 | grep -E "passed|failed|differ" | cut -c1-400 >> $LOG; done; cat $LOG ;;
     devpath)  for n in ${ARG//,/ }; do timeout 300 python3 tools/devpath_probe.py $n 60 >> $LOG 2>&1; done; grep -v amdgpu.ids $LOG | tail -16 ;;
     stress)   timeout 900 python3 tools/stress_direct_rx.py ${ARG//,/ } >> $LOG 2>&1; grep -v amdgpu.ids $LOG | tail -25 ;;
