@@ -40,7 +40,7 @@
     X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
-    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376)
+    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376) X(1, 16448)
 // variants that also exist with phase stamps (ABL 5)
 #define SXFIR_TILE2_STAMPED(X) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else

@@ -60,6 +60,10 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // software-pipelined window reads (fir_tile_sym_pipe): the chunks of step T + PF are requested before the FMAs of
        // step T, PF = 2 (PIPE2), 3 (PIPE3 = both bits) or 4 (PIPE4); x-grouped issue order
        T2_PIPE2 = 4096, T2_PIPE4 = 8192,
+       // tap-major issue order (fir_tile_sym_tapmajor): the four FMAs that share a TAP back to back -- the scalar operand,
+       // broadcast to all 128 multipliers, then changes once per four FMAs and the sample operand with every FMA
+       // (XGROUP is the opposite trade)
+       T2_TAPMAJOR = 16384,
        T2_SHIPPED = T2_SCALAR | T2_XGROUP };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
@@ -365,6 +369,83 @@ __device__ __forceinline__ void fir_tile_sym_pipe(const f32x4 *w1, const f32x4 *
     }
 }
 
+// ---- tap-major order: for tap index k0 = 63 .. 0, P1's tap h[63 - k0] meets outputs 0..3 at window samples
+// u = 4i + 64 - k0 (chunks two apart), then P0's tap h[k0] meets the samples 64 later.  Every accumulator still sees
+// its taps in descending order, so the bits are those of the other orders.  Eight chunks per stream are live.
+template <bool S32IN, int T>
+__device__ __forceinline__ void fir_tm_load(const f32x4 *w1, const f32x4 *w2, f32x4 (&q1)[39], f32x4 (&q0)[39])
+{
+    if constexpr (T >= 0 && T < 39) {
+        constexpr int T0 = T + 32;
+        f32x4 v1 = ((T & 15) >= 8 ? w2 : w1)[T + (T >> 4)];
+        f32x4 v0 = ((T0 & 15) >= 8 ? w2 : w1)[T0 + (T0 >> 4)];
+        if constexpr (S32IN) {
+            v1 = (f32x4){(float)__float_as_int(v1.x), (float)__float_as_int(v1.y), (float)__float_as_int(v1.z), (float)__float_as_int(v1.w)};
+            v0 = (f32x4){(float)__float_as_int(v0.x), (float)__float_as_int(v0.y), (float)__float_as_int(v0.z), (float)__float_as_int(v0.w)};
+        }
+        q1[T] = v1;
+        q0[T] = v0;
+    }
+}
+
+template <bool S32IN, int STEP>
+__device__ __forceinline__ void fir_tm_tap(const f32x4 *w1, const f32x4 *w2, f32x4 (&q1)[39], f32x4 (&q0)[39],
+                                           const f32x2 (&hs)[32], f32x2 (&a1)[4], f32x2 (&a0)[4])
+{
+    constexpr int K0 = 63 - STEP;                        // STEP 0 .. 63  <->  k0 63 .. 0
+    constexpr int K1 = 63 - K0;
+    // the chunk output 3 reaches with this tap, the first time it is reached (every second tap)
+    constexpr int UTOP = 4 * 3 + 64 - K0;
+    if constexpr (STEP == 0) {
+        fir_tm_load<S32IN, 0>(w1, w2, q1, q0); fir_tm_load<S32IN, 2>(w1, w2, q1, q0);
+        fir_tm_load<S32IN, 4>(w1, w2, q1, q0); fir_tm_load<S32IN, 6>(w1, w2, q1, q0);
+    } else if constexpr (STEP == 1) {
+        fir_tm_load<S32IN, 1>(w1, w2, q1, q0); fir_tm_load<S32IN, 3>(w1, w2, q1, q0);
+        fir_tm_load<S32IN, 5>(w1, w2, q1, q0); fir_tm_load<S32IN, 7>(w1, w2, q1, q0);
+    } else if constexpr ((UTOP & 1) == 0) {
+        fir_tm_load<S32IN, (UTOP >> 1)>(w1, w2, q1, q0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * i + 64 - K0;
+        const f32x4 v = q1[u >> 1];
+        const f32x2 x = (u & 1) ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
+        if (K1 & 1) pk_fma_sv_hi(a1[i], hs[K1 >> 1], x);
+        else pk_fma_sv_lo(a1[i], hs[K1 >> 1], x);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * i + 64 - K0;
+        const f32x4 v = q0[u >> 1];
+        const f32x2 x = (u & 1) ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
+        if (K0 & 1) pk_fma_sv_hi(a0[i], hs[K0 >> 1], x);
+        else pk_fma_sv_lo(a0[i], hs[K0 >> 1], x);
+    }
+}
+
+template <bool S32IN, int... Ss>
+__device__ __forceinline__ void fir_tm_steps(std::integer_sequence<int, Ss...>, const f32x4 *w1, const f32x4 *w2,
+                                             const f32x2 (&hs)[32], f32x2 (&a1)[4], f32x2 (&a0)[4])
+{
+    f32x4 q1[39], q0[39];
+    (fir_tm_tap<S32IN, Ss>(w1, w2, q1, q0, hs, a1, a0), ...);
+}
+
+template <bool S32IN>
+__device__ __forceinline__ void fir_tile_sym_tapmajor(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], float (&oi)[4],
+                                                      float (&oq)[4])
+{
+    f32x2 a1[4], a0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a1[i] = (f32x2){0.0f, 0.0f}; a0[i] = (f32x2){0.0f, 0.0f}; }
+    fir_tm_steps<S32IN>(std::make_integer_sequence<int, 64>{}, w1, w2, hs, a1, a0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oi[i] = __fadd_rn(a0[i].x, a1[i].x);
+        oq[i] = __fadd_rn(a0[i].y, a1[i].y);
+    }
+}
+
 template <bool PLAIN>
 __device__ __forceinline__ void st16(const f32x4 &v, f32x4 *dst)
 {
@@ -578,7 +659,8 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
         } else {
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
             constexpr int PF = ((OPT & T2_PIPE2) ? 2 : 0) + ((OPT & T2_PIPE4) ? ((OPT & T2_PIPE2) ? 1 : 4) : 0);   // 0, 2, 3, 4
-            if constexpr (SCALAR && PF > 0) fir_tile_sym_pipe<S32IN, PF>(buf + woff, buf + woff2, hs, oi, oq);
+            if constexpr (SCALAR && (OPT & T2_TAPMAJOR) != 0) fir_tile_sym_tapmajor<S32IN>(buf + woff, buf + woff2, hs, oi, oq);
+            else if constexpr (SCALAR && PF > 0) fir_tile_sym_pipe<S32IN, PF>(buf + woff, buf + woff2, hs, oi, oq);
             else if constexpr (SCALAR) fir_tile_sym<S32IN, (OPT & T2_XGROUP) ? 1 : ((OPT & T2_XSTREAM) ? 2 : 0)>(buf + woff, buf + woff2, hs, oi, oq);
             else fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);

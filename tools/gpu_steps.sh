@@ -43,6 +43,7 @@ for S in "$@"; do
     kb4g)     KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py x:16:0:0:0 x:8:0:0:0 x:32:0:0:0 x:64:0:0:0 x:24:0:0:0 t2.1.1088:16:0:1:0 t2.1.1088:64:0:1:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -9 ;;
     kb4p)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.5184:16:0:0:0 t2.1.13376:16:0:0:0 t2.1.9280:16:0:0:0 t2.1.1088:16:0:5:0 t2.1.9280:16:0:5:0 t2.1.5184:16:0:5:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep -v "wave lifetime\|mean lifetime\|distinct" | tail -14 ;;
     kb4c8)    KB_D=4 KB_NCHAN=8 timeout 600 python3 tools/kbench.py x:16:0:0:0 x:8:0:0:0 x:32:0:0:0 >> $LOG 2>&1; KB_D=4 KB_NCHAN=1 timeout 600 python3 tools/kbench.py x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -6 ;;
+    kb4t)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.16448:16:0:0:0 t2.1.64:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -9 ;;
     kb4o)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.64:16:0:0:0 t2.1.1088:16:0:0:0 t2.1.2112:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -10 ;;
     ib8)      KB_L=8 timeout 600 python3 tools/ibench.py >> $LOG 2>&1; tail -8 $LOG ;;
     pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; tail -2 $LOG ;;
