@@ -15,6 +15,11 @@
 #   clocks              tools/clock_calib.hip: shader clock by instruction count vs s_memtime / s_memrealtime
 #   pprobe[:D]          tools/power_probe.py: board power, caps and clocks, random vs all-zero input
 #   grbm                GRBM_GUI_ACTIVE-derived clock on a 0.5 ms and a 33 ms dispatch of the /4 kernel
+#   psplit[:D]          tools/power_split.py: power of the whole kernel / memory side alone / arithmetic alone
+#   mempower            tools/mempower.py: power beside plain streaming kernels (4:1 via registers / LDS-DMA, read, copy)
+#   kb4g kb4p kb4t kb4c8  /4 kernel: generations sweep, pipelined LDS reads, tap-major FMA order, 8-channel layout
+#   soak[:n]            the whole GPU suite n times (default 16), outcome lines counted
+#   devpath:n,..        tools/devpath_probe.py per-call times at the given block sizes
 #   power               board power / clock while the /4 kernel runs (tools/gpu_power.sh)
 set -u
 TAG=${1:?tag}; shift
