@@ -9,7 +9,9 @@ through the C ABI: one kernel launch, history carry-over fused) over the rank's 
 consecutive steps are consecutive blocks of one continuous stream (filter history carried over on the GPU).
 
   --config 2   (default, the headline) 128-tap decimate-by-4, CF32          BASELINE config 2
-  --config 3rx 256-tap decimate-by-8, CF32      --config 3tx  256-tap interpolate-by-8, CF32 (config 3)
+  --config 3   full duplex: the 256-tap decimate-by-8 RX pass and the 256-tap interpolate-by-8 TX pass side by side
+               on two HIP streams (BASELINE config 3), plus the timed readStream -> writeStream loop through the Device
+  --config 3rx 256-tap decimate-by-8, CF32      --config 3tx  256-tap interpolate-by-8, CF32 (config 3's halves)
   --config 5   1024-tap decimate-by-32, CF32    --config 5h   the same with IQ stored as CF16 (config 5)
 
 N = 1 runs one channel; N > 1 runs BASELINE config 4's layout (8 independent channels per GPU, 8*N in total,
@@ -50,6 +52,10 @@ CONFIGS = {
     "3tx": dict(mode="interp", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=8.0,
                 kernel="sxfir::interp_tile_kernel<8>",
                 name="256-tap polyphase interp-by-8 TX, 1 ch CF32 streaming (BASELINE config 3, TX half)"),
+    "3": dict(mode="duplex", ntaps=256, ratio=8, fmt="CF32", bytes=9.0, flop=128, gain=1.0,
+              kernel="sxfir::decim_dense_kernel<8> + sxfir::interp_tile_kernel<8> on two streams",
+              name="full-duplex 256-tap decim-8 RX + interp-8 TX (read+writeStream), timestamp-latency check "
+                   "(BASELINE config 3)"),
     "5": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF32", bytes=8 + 8 / 32, flop=128, gain=1.0,
               kernel="sxfir::decim_dense_kernel<32>",
               name="1024-tap decim-by-32, 1 ch CF32 streaming (BASELINE config 5, CF32 leg)"),
@@ -503,6 +509,174 @@ def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------
+# BASELINE config 3: full duplex
+# ----------------------------------------------------------------------------------------------------------
+def duplex_timed_loop(blocks=(256, 1024, 4096), latency_periods=3, rounds=400):
+    """The reference's full-duplex pattern (example/linear_repeater.py:40-69) through the Device at decimate-by-8 /
+    interpolate-by-8 (300 kS/s with decim=auto / interp=auto): every RX block is retransmitted with
+    HAS_TIME at timeNs + latency; after every writeStream the TX position must be exactly
+    rx_position + latency (SoapySX.cpp:950, :1012).  Reports microseconds per round trip; never part of value."""
+    import numpy as np
+    import sxxcvr_amd.soapy as SoapySDR
+    rate = 300000.0
+    out = {"note": "readStream -> writeStream(HAS_TIME, timeNs + latency) through the Device at /8 and x8, virtual sample "
+                   "clock; TX_POSITION == rx_position + latency asserted on every block", "sample_rate": rate}
+    for blk in blocks:
+        dev = SoapySDR.Device({"driver": "sx", "clock": "virtual", "decim": "auto", "interp": "auto"})
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, rate)
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_TX, 0, rate)
+        assert int(dev.readSetting("RX_DECIM")) == 8 and int(dev.readSetting("TX_INTERP")) == 8
+        rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CF32", [0], {"period": str(blk)})
+        tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(blk), "threshold": "0"})
+        dev.activateStream(rx)
+        dev.activateStream(tx)
+        latency = latency_periods * blk
+        dt_ns = SoapySDR.ticksToTimeNs(latency, rate)
+        buf = np.zeros(blk, dtype=np.complex64)
+        n_bad, ts = 0, []
+        for i in range(rounds + 20):
+            t0 = time.perf_counter()
+            r = dev.readStream(rx, [buf], blk)
+            w = dev.writeStream(tx, [buf], blk, flags=SoapySDR.SOAPY_SDR_HAS_TIME, timeNs=r.timeNs + dt_ns)
+            t1 = time.perf_counter()
+            if r.ret != blk or w.ret != blk:
+                raise RuntimeError("stream call returned %d / %d" % (r.ret, w.ret))
+            rx_pos = int(dev.readSetting("RX_POSITION"))
+            if int(dev.readSetting("TX_POSITION")) != rx_pos + latency:
+                n_bad += 1
+            if SoapySDR.timeNsToTicks(r.timeNs, rate) != rx_pos - blk:
+                n_bad += 1
+            if i >= 20:
+                ts.append(t1 - t0)
+        ts.sort()
+        out["%d_sample_blocks" % blk] = {"round_trip_us_median": round(ts[len(ts) // 2] * 1e6, 2),
+                                         "round_trip_us_p99": round(ts[int(len(ts) * 0.99)] * 1e6, 2),
+                                         "latency_samples": latency, "latency_ns": dt_ns, "rounds": rounds,
+                                         "blocks_off_position": n_bad}
+        out["latency_check_passed"] = out.get("latency_check_passed", True) and n_bad == 0
+        for st in (rx, tx):
+            dev.deactivateStream(st)
+            dev.closeStream(st)
+    return out
+
+
+def main_duplex(args):
+    """--config 3 (N = 1): one step = one decimate-by-8 pass over 2^28 wideband samples on the RX stream AND one
+    interpolate-by-8 pass producing 2^28 wideband samples on the TX stream, launched side by side; value = wideband
+    samples of both directions per second.  Per direction: HIP events on its own stream around the K timed steps."""
+    import torch
+    import sxxcvr_amd
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE, StreamTimer
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.gpus != 1:
+        raise SystemExit("--config 3 is a single-GPU workload (BASELINE config 3)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n = 1 << args.log2_samples
+    rxc, txc = CONFIGS["3rx"], CONFIGS["3tx"]
+    rx_plan = sxxcvr_amd.Resampler(DECIMATE, sxxcvr_amd.design_lowpass(256, 8, 8.0, rxc["gain"]), 8)
+    tx_plan = sxxcvr_amd.Resampler(INTERPOLATE, sxxcvr_amd.design_lowpass(256, 8, 8.0, txc["gain"]), 8)
+    xr = torch.empty((1, n), dtype=torch.complex64, device=dev)
+    yr = torch.empty((1, n // 8), dtype=torch.complex64, device=dev)
+    xt = torch.empty((1, n // 8), dtype=torch.complex64, device=dev)
+    yt = torch.empty((1, n), dtype=torch.complex64, device=dev)
+    sxxcvr_amd.synth_fill(xr, SEED, first_channel=0, start=0)
+    sxxcvr_amd.synth_fill(xt, SEED, first_channel=0, start=0)
+    torch.cuda.synchronize()
+    s_rx, s_tx = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+    def step():
+        rx_plan.process_ptr(xr.data_ptr(), n, n, yr.data_ptr(), n // 8, s_rx.cuda_stream)
+        tx_plan.process_ptr(xt.data_ptr(), n // 8, n // 8, yt.data_ptr(), n, s_tx.cuda_stream)
+
+    for _ in range(args.settle + args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t_rx, t_tx = StreamTimer(s_rx.cuda_stream), StreamTimer(s_tx.cuda_stream)
+    t0 = time.perf_counter()
+    t_rx.start()
+    t_tx.start()
+    for _ in range(args.steps):
+        step()
+    t_rx.stop()
+    t_tx.stop()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rx_ms, tx_ms = t_rx.elapsed_ms() / args.steps, t_tx.elapsed_ms() / args.steps
+
+    orc = load_oracle()
+    ok_rx, n_rx = verify(rxc, rx_plan, xr, yr, n, 0, True, orc)
+    ok_tx, n_tx = verify(txc, tx_plan, xt, yt, n // 8, 0, True, orc)
+    # each direction alone, same buffers, for the price of sharing the chip
+    alone = {}
+    for name, plan, a, b, ni, no in (("rx", rx_plan, xr, yr, n, n // 8), ("tx", tx_plan, xt, yt, n // 8, n)):
+        plan.reset()
+        torch.cuda.synchronize()
+        alone[name] = plan.time_passes_ptr(a.data_ptr(), ni, ni, b.data_ptr(), no, min(max(args.steps, 40), 200),
+                                           torch.cuda.current_stream(dev).cuda_stream)
+    sampler = BoardSampler(0, 0.02)
+    sampler.start()
+    t_tel = time.perf_counter()
+    while time.perf_counter() - t_tel < 1.0:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+    board = sampler.stop()
+    verified = ok_rx and ok_tx
+    ms_per_step = elapsed / args.steps * 1e3
+    value = 2 * n * args.steps / elapsed / 1e6
+    bytes_step = 9.0 * n * 2
+
+    def direction(ms, kernel):
+        ach = 9.0 * n / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "span_ms_per_step": round(ms, 4), "achieved": round(ach, 1),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(9.0 * n)}
+
+    achieved = bytes_step / (ms_per_step * 1e-3) / 1e9
+    line = {
+        "metric": "complex MS/s, full-duplex 256-tap decim-by-8 RX + interp-by-8 TX CF32 (wideband rate, both directions)",
+        "value": round(value, 1), "unit": "MS/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "verified": verified,
+        "config": {"workload": "1xMI355X: " + CONFIGS["3"]["name"], "bench_config": "3", "ntaps": 256, "decim": 8, "interp": 8,
+                   "format": "CF32", "wideband_samples_per_direction": n, "untimed_settle_launches": args.settle,
+                   "verified_outputs": n_rx + n_tx,
+                   "step": "one /8 pass over 2^%d wideband samples on the RX stream and one x8 pass producing 2^%d on the "
+                           "TX stream, side by side" % (args.log2_samples, args.log2_samples)},
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": CONFIGS["3"]["kernel"],
+            "algorithmic_bytes_per_step": int(bytes_step),
+            "how": "both directions' algorithmic bytes (9 B per wideband sample each) / wall time per step; per direction: "
+                   "HIP events on its own stream around the K timed steps / K (the two spans overlap in time)",
+            "rx": direction(rx_ms, rxc["kernel"]), "tx": direction(tx_ms, txc["kernel"]),
+            "alone_kernel_ms": {k: round(v, 4) for k, v in alone.items()},
+            "sum_alone_ms": round(alone["rx"] + alone["tx"], 4),
+            "fp32_TFLOPs": round(128.0 * 2 * n / (ms_per_step * 1e-3) / 1e12, 2),
+            "board": board,
+        },
+    }
+    for k in ("power_w", "power_cap_w", "gfx_mhz_smi"):
+        line["roofline"][k] = board.get(k)
+    if not args.no_through_device:
+        try:
+            line["timed_loop"] = duplex_timed_loop()
+            verified = verified and bool(line["timed_loop"].get("latency_check_passed"))
+            line["verified"] = verified
+        except Exception as e:
+            line["timed_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["verified"] = verified = False
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(rxc)
+        line["cpu_baseline"]["note_config3"] = "the RX direction's filter (256-tap decimate-by-8) on the host cores"
+    print(json.dumps(line), flush=True)
+    if not verified:
+        sys.exit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -518,6 +692,8 @@ def main():
                     help="untimed launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if cfg["mode"] == "duplex":
+        return main_duplex(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: be the launcher.  Nothing below this line has run in this process, so no GPU call has
@@ -767,7 +943,7 @@ def main():
             # the plain gather is on record; only the pipelined form hung: report that and leave (a collective
             # that hangs cannot be cancelled)
             emit(dict(stage["gather"], overlapped={"error": "pipelined gather did not complete within 240 s"}))
-            os._exit(0 if verified else 4)
+            os._exit(5)                                 # a rank that abandons a live collective never reports success
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:

@@ -50,8 +50,9 @@ extern "C" {
  *    (round 2).  Two diagnostic entry points of version 1, sxfir_debug_clock and sxfir_debug_stamps, moved out of
  *    libsxfir.so into the profiling build (libsxfir_prof.so, include/sxfir_prof.h): a version-1 client that referenced
  *    them no longer links against the production library; every other version-1 entry point is unchanged.
- * 3: sxfir_set_position added (round 3); nothing removed or changed. */
-#define SXFIR_ABI_VERSION 3
+ * 3: sxfir_set_position added (round 3); nothing removed or changed.
+ * 4: sxfir_interpolate_keyed and the sxfir_comm_* gather over RCCL added (round 4); nothing removed or changed. */
+#define SXFIR_ABI_VERSION 4
 
 enum {
     SXFIR_OK = 0,
@@ -138,6 +139,15 @@ int sxfir_decimate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_
 int sxfir_interpolate(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
                       void *out_dev, size_t out_stride, size_t *n_out, void *stream);
 
+/* sxfir_interpolate with convert_tx_buffer's transmitter-keying count (SX.cpp:132-133) taken in the same pass: adds
+ * to *counter (8-byte aligned word in DEVICE memory) how many of channel 0's input samples
+ * [key_first, key_first + key_count) reach the plan's squared-magnitude threshold (sxfir_set_tx_threshold; the
+ * rule is sxfir_count_keyed's).  The interpolator has every input sample in LDS anyway, so a pass whose input is
+ * device-visible HOST memory (the Device's pinned TX slots) crosses PCIe once instead of twice.  CF32 or S32 plans. */
+int sxfir_interpolate_keyed(sxfir_plan *plan, const void *in_dev, size_t n_in, size_t in_stride,
+                            void *out_dev, size_t out_stride, size_t *n_out, size_t key_first, size_t key_count,
+                            unsigned long long *counter, void *stream);
+
 /* Synthetic CF32/CF16 IQ source: out_dev[c*stride + i] = sample (start+i) of
  * channel (first_channel + c); index < 0 gives zero.  Counter-based, so any
  * range can be regenerated anywhere. */
@@ -200,6 +210,38 @@ int sxfir_event_sync(void *event);
 /* Work queued on `stream` after this call starts only when `event` (recorded on another stream) has fired: the
  * GPU-side ordering between a compute stream and a copy stream, without the host waiting. */
 int sxfir_stream_wait_event(void *stream, void *event);
+
+/* ---- The sharded path's one exchange step: gather of the decimated channels to a root GPU over xGMI (RCCL).
+ * Channels are independent (the reference is single-channel, SX.cpp:1591-1595); BASELINE config 4 shards 64 of them
+ * 8 per GPU and gathers the decimated output.  These entry points let a C / C++ host run that step itself:
+ *     per piece:  ncclGroupStart;  root: ncclRecv x (N-1);  peers: ncclSend;  ncclGroupEnd      on `stream`
+ * librccl is loaded on first use; without it (or without a GPU) they return SXFIR_EUNSUPPORTED / SXFIR_ENODEVICE.
+ *
+ * Rank-per-process form: rank 0 calls sxfir_comm_unique_id and hands the SXFIR_COMM_ID_BYTES bytes to the other
+ * ranks by any means it has (a file, a socket, the launcher's store); then every rank calls sxfir_comm_init_rank
+ * (collective: returns when all nranks have called it).  device -1 = the calling thread's current GPU.
+ * Single-process form (one Device per shard in one process): sxfir_comm_init_all fills comms[0..ndev) for the
+ * GPUs devices[0..ndev) (NULL = 0..ndev-1), rank i on devices[i]; drive them with sxfir_comm_gather_all. */
+#define SXFIR_COMM_ID_BYTES 128
+typedef struct sxfir_comm sxfir_comm;
+int sxfir_comm_unique_id(void *id);
+int sxfir_comm_init_rank(sxfir_comm **comm, const void *id, int nranks, int rank, int device);
+int sxfir_comm_init_all(sxfir_comm **comms, int ndev, const int *devices);
+int sxfir_comm_destroy(sxfir_comm *comm);
+int sxfir_comm_rank(const sxfir_comm *comm, int *rank, int *nranks, int *device);
+/* Every rank contributes `bytes` bytes at send_dev; on the root, rank r's block lands at recv_dev +
+ * r * recv_stride_bytes (recv_dev is ignored elsewhere; the root's own block is copied device-to-device on the
+ * same stream unless send_dev already is its place in recv_dev).  chunk_bytes > 0 cuts the transfer into pieces of
+ * that size, one RCCL group each (use a multiple of one channel's bytes: the root can then consume a step's first
+ * channels while the rest are on the links, and a piece queues behind the kernel that produced it without holding
+ * the whole block back); 0 = one piece.  Asynchronous on `stream`. */
+int sxfir_comm_gather(sxfir_comm *comm, const void *send_dev, void *recv_dev, size_t bytes,
+                      size_t recv_stride_bytes, int root, size_t chunk_bytes, void *stream);
+/* The same for the single-process form, all ranks driven by the calling thread: send_dev[i] and streams[i]
+ * (NULL = default streams) belong to rank i; recv_dev lives on the root's GPU. */
+int sxfir_comm_gather_all(sxfir_comm *const *comms, int ndev, const void *const *send_dev, void *recv_dev,
+                          size_t bytes, size_t recv_stride_bytes, int root, size_t chunk_bytes,
+                          void *const *streams);
 
 /* Timed launches for bench.py: runs `iters` back-to-back decimate passes of
  * the same buffers on `stream` bracketed by hipEvents ON THAT STREAM and

@@ -65,6 +65,14 @@ def load_sxfir(profiling=False):
         "sxfir_outputs_for": (ci, [vp, sz, P(sz)]),
         "sxfir_decimate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
         "sxfir_interpolate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
+        "sxfir_comm_unique_id": (ci, [vp]),
+        "sxfir_comm_init_rank": (ci, [P(vp), vp, ci, ci, ci]),
+        "sxfir_comm_init_all": (ci, [P(vp), ci, P(ci)]),
+        "sxfir_comm_destroy": (ci, [vp]),
+        "sxfir_comm_rank": (ci, [vp, P(ci), P(ci), P(ci)]),
+        "sxfir_comm_gather": (ci, [vp, vp, vp, sz, sz, ci, sz, vp]),
+        "sxfir_comm_gather_all": (ci, [P(vp), ci, P(vp), vp, sz, sz, ci, sz, P(vp)]),
+        "sxfir_interpolate_keyed": (ci, [vp, vp, sz, sz, vp, sz, P(sz), sz, sz, vp, vp]),
         "sxfir_time_decimate": (ci, [vp, vp, sz, sz, vp, sz, ci, vp, P(C.c_float)]),
         "sxfir_time_interpolate": (ci, [vp, vp, sz, sz, vp, sz, ci, vp, P(C.c_float)]),
         "sxfir_clock_probe_start": (ci, [P(vp), ci, ci]),

@@ -6,6 +6,7 @@
 Outputs (git-ignored, shipped to the GPU box by gpurun):
     sxxcvr_amd/lib/libsxfir.so       C ABI of the HIP resampling path (include/sxfir.h)
     sxxcvr_amd/lib/libSXSupport.so   SoapySDR-style Device plugin + its C ABI (include/sx_device.h)
+    sxxcvr_amd/lib/sx_devloop, sx_gather_c   plain-C callers of the two ABIs (tools/devloop.c, tools/gather_c.c)
     sxxcvr_amd/lib/libsxfir_prof.so  the same C ABI built with -DSXFIR_PROFILING: kernel A/B variants, ablation
                                      modes and environment knobs (include/sxfir_prof.h); tools/ and
                                      tests/test_gpu_variants.py only, never loaded by the product
@@ -53,11 +54,13 @@ TARGETS = {
         "compiler": "hipcc",
         "sources": ["sxfir.hip"],
         "flags": ["--offload-arch=" + ARCH, "-O3"],
+        "libs": ["-ldl"],           # librccl is dlopen'ed by sxfir_comm_* on first use, never linked
     },
     "libsxfir_prof.so": {
         "compiler": "hipcc",
         "sources": ["sxfir.hip"],
         "flags": ["--offload-arch=" + ARCH, "-O3", "-DSXFIR_PROFILING"],
+        "libs": ["-ldl"],
     },
     "libSXSupport.so": {
         "compiler": "g++",
@@ -74,18 +77,29 @@ TARGETS = {
         "flags": ["-O2"],
         "libs": ["-L" + LIBDIR, "-lSXSupport", "-Wl,-rpath,$ORIGIN"],
     },
+    # a C caller of the inner ABI (include/sxfir.h): the sharded path with the RCCL gather driven from plain C
+    # (sxfir_comm_*), rank-per-process or one process for all GPUs; tests/test_gpu_rccl.py and bench.py --gather capi
+    "sx_gather_c": {
+        "compiler": "gcc",
+        "executable": True,
+        "sources": [os.path.join(ROOT, "tools", "gather_c.c")],
+        "flags": ["-O2"],
+        "libs": ["-L" + LIBDIR, "-lsxfir", "-Wl,-rpath,$ORIGIN"],
+    },
 }
 
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    deps = _deps(CSRC, os.path.join(ROOT, "include")) + [os.path.join(ROOT, "tools", "devloop.c")]
+    common = _deps(CSRC, os.path.join(ROOT, "include"))
     built = []
     for name, spec in TARGETS.items():
         srcs = [s if os.path.isabs(s) else os.path.join(CSRC, s) for s in spec["sources"]]
         if not all(os.path.exists(s) for s in srcs):
             continue
         out = os.path.join(LIBDIR, name)
+        # sources outside csrc/ (the C caller under tools/) are dependencies of their own target only
+        deps = common + [s for s in srcs if not s.startswith(CSRC + os.sep)]
         if not (force or _newer(out, deps)):
             continue
         if spec.get("executable"):

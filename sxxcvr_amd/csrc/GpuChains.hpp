@@ -603,10 +603,10 @@ public:
     static constexpr size_t kFlushFrames = 4096;       // small writes are gathered up to this before a GPU pass
     static constexpr int kSlots = 4;
     // A pass whose input is at least this large crosses PCIe as DMA-engine copies into HBM before the kernels run
-    // (57 GB/s on the boxes measured, and the interpolator and the keying count both read HBM); smaller ones are
-    // read in place from the pinned slot by the kernels themselves (nothing to queue, lowest latency).  Measured
-    // alternatives for the blocks in between (32 KiB ... 512 KiB, 1.25 GS/s = two PCIe reads of the slot per pass,
-    // interpolator and keying count): a DMA threshold of 128 KiB halves their rate (the host then waits for the
+    // (57 GB/s on the boxes measured); smaller ones are read in place from the pinned slot by the interpolator,
+    // which takes the keying count from the same staged tiles (nothing to queue, lowest latency, one PCIe read).
+    // Measured in round 2 for the blocks in between (32 KiB ... 512 KiB; then 1.25 GS/s with two PCIe reads of the
+    // slot per pass): a DMA threshold of 128 KiB halves their rate (the host then waits for the
     // input blocks; with four input blocks instead of two it is a wash: 64 Ki-sample writes 15 % faster, 32 Ki-sample
     // writes 20 % slower), non-temporal stores into the slot change nothing (the copy is not what limits them).
     static constexpr size_t kH2dFromBytes = size_t(1) << 20;
@@ -634,6 +634,7 @@ public:
         stage_.reserve(8 * slot_frames_ * (size_t)nchan_ * kSlots);
         keyed_.reserve(64);
         zero_keyed();
+        set_threshold2(thr2_);                             // the plan and the chain count with the same threshold bits
         for (int k = 0; k < kSlots; ++k) {
             busy_[k] = false;
             done_[k] = nullptr;
@@ -676,7 +677,8 @@ public:
 
     // Transmitter keying of convert_tx_buffer (SoapySX.cpp:132-133): how many application samples of channel 0
     // reached the squared-magnitude threshold since the last reset.  Counted on the GPU as the staged blocks
-    // pass (sxfir_count_keyed into a device counter), so writeStream makes no pass of its own over the samples.
+    // pass (inside the interpolator, sxfir_interpolate_keyed, into a device counter), so writeStream makes no pass
+    // of its own over the samples and the GPU reads them once.
     int64_t keyed_samples()
     {
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
@@ -819,19 +821,33 @@ private:
     // data_ (application data, relative to base) take part in the keying count
     void pass(const char *base, size_t stride, size_t frames, void *st)
     {
+        // One range of application data (the usual case: a slot is all data, or data behind a timed gap): the
+        // interpolator takes the keying count itself from the tile it has staged in LDS, so a pass read in place from
+        // the pinned slot crosses PCIe once (round 3: a second kernel read the slot again, 1.2-1.8 GS/s for 4096 ...
+        // 65536-sample writes).  Several ranges in one slot (data, silence, data): the separate count kernel.
+        const bool fused = data_.size() == 1;
+        const size_t k_lo = fused ? data_[0].first : 0, k_hi = fused ? data_[0].first + data_[0].second : 0;
         size_t done = 0;
         while (done < frames) {
             const size_t off = (size_t)((next_ * interp_) % (int64_t)ring_len_);
             const size_t m = std::min(frames - done, (ring_len_ - off) / (size_t)interp_);
             size_t n_out = 0;
-            gpu_check(sxfir_interpolate(plan_, base + 8 * done, m, stride, ring_.at(8 * off), ring_len_, &n_out, st),
-                      "sxfir_interpolate");
+            // this call's share of the keying range, relative to its first sample
+            const size_t lo = std::min(std::max(k_lo, done), done + m) - done, hi = std::min(std::max(k_hi, done), done + m) - done;
+            if (fused && hi > lo)
+                gpu_check(sxfir_interpolate_keyed(plan_, base + 8 * done, m, stride, ring_.at(8 * off), ring_len_, &n_out, lo,
+                                                  hi - lo, keyed_counter(), st),
+                          "sxfir_interpolate_keyed");
+            else
+                gpu_check(sxfir_interpolate(plan_, base + 8 * done, m, stride, ring_.at(8 * off), ring_len_, &n_out, st),
+                          "sxfir_interpolate");
             next_ += (int64_t)m;
             done += m;
         }
-        for (const auto &r : data_)
-            gpu_check(sxfir_count_keyed(reinterpret_cast<const float *>(base + 8 * r.first), r.second, thr2_, keyed_counter(), st),
-                      "sxfir_count_keyed");
+        if (!fused)
+            for (const auto &r : data_)
+                gpu_check(sxfir_count_keyed(reinterpret_cast<const float *>(base + 8 * r.first), r.second, thr2_, keyed_counter(), st),
+                          "sxfir_count_keyed");
         data_.clear();
     }
 

@@ -40,9 +40,10 @@
     X(2, 0) X(2, 1) X(2, 2) X(2, 3) X(2, 6) X(2, 7) X(4, 2) X(4, 3) X(4, 7) X(8, 2) X(8, 3) \
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
-    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376) X(1, 16448)
+    X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376) X(1, 16448) \
+    X(1, 33856) X(1, 66624) X(1, 33872)
 // variants that also exist with phase stamps (ABL 5)
-#define SXFIR_TILE2_STAMPED(X) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
+#define SXFIR_TILE2_STAMPED(X) X(1, 33856) X(1, 66624) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
 #define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
 #endif
@@ -108,6 +109,7 @@ struct sxfir_plan {
     int sgpr_r;            // experiment: SGPR-tap variant with R outputs per lane (0 = off)
     int sched;             // tile schedule of the tile kernel (0 strided passes, 1 contiguous runs)
     int ablate;            // profiling only: 1 = memory side alone, 2 = compute side alone
+    int lds_pad;           // profiling only: extra dynamic LDS bytes per workgroup of a tile2 variant (caps the waves per CU)
     int t2_wpg, t2_opt;    // profiling only: decim4_tile2_kernel variant (waves per workgroup, T2_* bits); wpg 0 = off
     bool pair;             // decim4_pair_kernel: the two tap halves on the two waves of a workgroup
     bool pair_xsep;        // ... with a separate exchange buffer (two barriers per tile instead of four)
@@ -257,6 +259,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the multi-column kernel
     p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && fmt != SXFIR_CF16;
     p->t2_wpg = p->t2_opt = 0;
+    p->lds_pad = 0;
     p->pair = false;
     p->pair_xsep = false;
     p->occ_pair = 8;
@@ -378,8 +381,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                     }
                     p->t2_wpg = wpg;
                     p->t2_opt = opt;
+                    // SXFIR_LDS_PAD: dynamic LDS bytes on top of the kernel's own image: fewer waves fit a CU
+                    if (const char *lp = getenv("SXFIR_LDS_PAD")) p->lds_pad = atoi(lp) > 0 ? atoi(lp) : 0;
                     // occ_sb = resident WAVES per CU of this variant
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * wpg, 0) == hipSuccess && nb > 0)
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * wpg, (size_t)p->lds_pad) == hipSuccess && nb > 0)
                         p->occ_sb = nb * wpg;
                 }
             }
@@ -777,12 +782,12 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             }
             switch ((wpg * 100 + p->t2_opt) * 10 + (p->ablate == 1 || p->ablate == 2 || p->ablate == 5 ? p->ablate : 0)) {
 #define SXFIR_X(WW, OO) \
-            case (WW * 100 + OO) * 10: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO>), grid, dim3(64 * WW), 0, st, a); break; \
-            case (WW * 100 + OO) * 10 + 1: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 1>), grid, dim3(64 * WW), 0, st, a); break;
+            case (WW * 100 + OO) * 10: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO>), grid, dim3(64 * WW), p->lds_pad, st, a); break; \
+            case (WW * 100 + OO) * 10 + 1: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 1>), grid, dim3(64 * WW), p->lds_pad, st, a); break;
                 SXFIR_TILE2_VARIANTS(SXFIR_X)
 #undef SXFIR_X
 #define SXFIR_X(WW, OO) \
-            case (WW * 100 + OO) * 10 + 5: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 5>), grid, dim3(64 * WW), 0, st, a); break;
+            case (WW * 100 + OO) * 10 + 5: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 5>), grid, dim3(64 * WW), p->lds_pad, st, a); break;
                 SXFIR_TILE2_STAMPED(SXFIR_X)
 #undef SXFIR_X
             default: return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d ablate %d", wpg, p->t2_opt, p->ablate);
@@ -945,8 +950,11 @@ int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_str
 }
 
 // Launch only the interpolation kernel (no history swap, no position change).
+// key: count the input samples [lo, hi) of channel 0 that reach the plan's keying threshold into *counter
+struct KeyedRange { unsigned long long *counter; long long lo, hi; };
 static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
-                         size_t out_stride, long long n_out, hipStream_t st, bool *history_done)
+                         size_t out_stride, long long n_out, hipStream_t st, bool *history_done,
+                         const KeyedRange *key = nullptr)
 {
     *history_done = false;
     const bool tiled = p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && ((uintptr_t)out_dev % 16 == 0) &&
@@ -973,8 +981,25 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.n_tiles = (int)n_tiles;
         t.n_groups = (int)groups;
         t.thr2 = p->thr2;
+        t.key_counter = key ? key->counter : nullptr;
+        t.key_lo = key ? key->lo : 0;
+        t.key_hi = key ? key->hi : 0;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
-        if (p->fmt == SXFIR_S32) {
+        if (key && p->fmt == SXFIR_S32) {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true, true>), grid, dim3(64), 0, st, t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true, true>), grid, dim3(64), 0, st, t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true, true>), grid, dim3(64), 0, st, t); break;
+            }
+        } else if (key) {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, false, true>), grid, dim3(64), 0, st, t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, false, true>), grid, dim3(64), 0, st, t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, false, true>), grid, dim3(64), 0, st, t); break;
+            }
+        } else if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, st, t); break;
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, st, t); break;
@@ -1018,11 +1043,19 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
     else
         hipLaunchKernelGGL((sxfir::interp_generic_kernel<sxfir::CF32, sxfir::S32>), grid, dim3(256), 0, st, a);
     HIPCHECK(hipGetLastError());
+    if (key && key->hi > key->lo) {
+        // shapes the tiled kernel does not take: the count as a pass of its own (same rule, same counter)
+        const long long n = key->hi - key->lo;
+        unsigned g = (unsigned)std::min<long long>((n + 255) / 256, 256);
+        hipLaunchKernelGGL(sxfir::count_keyed_kernel, dim3(g), dim3(256), 0, st,
+                           reinterpret_cast<const float2 *>(in_dev) + key->lo, n, p->thr2, key->counter);
+        HIPCHECK(hipGetLastError());
+    }
     return SXFIR_OK;
 }
 
-int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
-                      size_t out_stride, size_t *n_out_p, void *stream)
+static int interpolate_impl(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                            size_t out_stride, size_t *n_out_p, void *stream, const KeyedRange *key)
 {
     if (n_out_p) *n_out_p = 0;
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
@@ -1032,7 +1065,7 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     if (n_in == 0) return SXFIR_OK;
     HIPCHECK(hipSetDevice(p->device));
     bool history_done = false;
-    rc = launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
+    rc = launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done, key);
     if (rc) return rc;
     if (!history_done) {
         rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
@@ -1043,6 +1076,26 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     p->produced += n_out;
     if (n_out_p) *n_out_p = (size_t)n_out;
     return SXFIR_OK;
+}
+
+int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                      size_t out_stride, size_t *n_out_p, void *stream)
+{
+    return interpolate_impl(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out_p, stream, nullptr);
+}
+
+int sxfir_interpolate_keyed(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                            size_t out_stride, size_t *n_out_p, size_t key_first, size_t key_count,
+                            unsigned long long *counter, void *stream)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (p->mode != SXFIR_INTERPOLATE) return fail(SXFIR_EINVAL, "not an interpolator plan");
+    if (p->fmt == SXFIR_CF16) return fail(SXFIR_EUNSUPPORTED, "the keying count is defined on CF32 input");
+    if (!counter || ((uintptr_t)counter & 7)) return fail(SXFIR_EINVAL, "counter must be an 8-byte aligned device word");
+    if (key_first > n_in || key_count > n_in - key_first) return fail(SXFIR_EINVAL, "keying range outside the block");
+    const KeyedRange key{counter, (long long)key_first, (long long)(key_first + key_count)};
+    return interpolate_impl(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out_p, stream, key_count ? &key : nullptr);
 }
 
 // Timed launches (bench.py): `iters` back-to-back passes of the resampling kernel over the same buffers and
@@ -1485,3 +1538,5 @@ int sxfir_stream_wait_event(void *stream, void *event)
 }
 
 }  // extern "C"
+
+#include "sxfir_comm.hip.h"

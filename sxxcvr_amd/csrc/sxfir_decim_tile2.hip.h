@@ -64,6 +64,11 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // broadcast to all 128 multipliers, then changes once per four FMAs and the sample operand with every FMA
        // (XGROUP is the opposite trade)
        T2_TAPMAJOR = 16384,
+       // cache policy of the staging DMAs (round 4, tools/membench5.hip: a read stream runs 4.6 % faster with nt loads,
+       // the decimator's 4:1 mix 6.5 %): NTLD = every DMA non-temporal; NTLD8 = DMAs 0..7 only -- the last kilobyte of
+       // a tile (DMAs 8 and 9) is the next tile's halo and stays a plain load, so that it is still in the XCD's L2
+       // when the neighbouring wave asks for it
+       T2_NTLD = 32768, T2_NTLD8 = 65536,
        T2_SHIPPED = T2_SCALAR | T2_XGROUP };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
@@ -105,7 +110,8 @@ constexpr unsigned long long pad_lanes(int q0)
 }
 
 // MASKPAD: the lanes whose slot is a pad slot sit the DMA out (6 % of the L2 -> LDS bytes)
-template <int NT, int Q0, int NI, int LASTL, bool MASKPAD = false>
+// NTMASK: bit j set = DMA instruction j is a non-temporal load (aux = 2)
+template <int NT, int Q0, int NI, int LASTL, bool MASKPAD = false, unsigned NTMASK = 0u>
 __device__ __forceinline__ void stage_range(const DecimTileCtx<NT> &c, int tile, f32x4 *buf, const unsigned (&off)[NI])
 {
     using C = DecimTile4<NT>;
@@ -120,7 +126,10 @@ __device__ __forceinline__ void stage_range(const DecimTileCtx<NT> &c, int tile,
             asm volatile("" : "+v"(b));                  // 32-bit offset next to its use (see stage_tile)
             bool on = j < NI - 1 || LASTL >= 64 || c.lane < LASTL;
             if constexpr (MASKPAD) on = on && !((pad_lanes(Q0 + 64 * j) >> c.lane) & 1ull);
-            if (on) glds16(src + b, buf + Q0 + 64 * j);
+            if (on) {
+                if ((NTMASK >> j) & 1u) glds16<2>(src + b, buf + Q0 + 64 * j);
+                else glds16(src + b, buf + Q0 + 64 * j);
+            }
         }
     } else {
 #pragma unroll
@@ -512,10 +521,11 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             unsigned aoff[NIA];
 #pragma unroll
             for (int j = 0; j < NIA; ++j) aoff[j] = slot_source_offset(64u * j + c.lane, C::CHUNKS);
-            stage_range<NT, 0, NIA, LASTA>(c, t, buf, aoff);
-            stage_range<NT, HS, NIB, LASTB>(c, t, buf, boff);
+            stage_range<NT, 0, NIA, LASTA, false, (OPT & T2_NTLD) ? 0xffffffffu : 0u>(c, t, buf, aoff);
+            stage_range<NT, HS, NIB, LASTB, false, (OPT & T2_NTLD) ? 0xffffffffu : 0u>(c, t, buf, boff);
         } else {
-            stage_range<NT, 0, NIF, LASTF, (OPT & T2_MASKPAD) != 0>(c, t, buf, boff);
+            constexpr unsigned NTM = (OPT & T2_NTLD) ? 0xffffffffu : ((OPT & T2_NTLD8) ? 0xffu : 0u);
+            stage_range<NT, 0, NIF, LASTF, (OPT & T2_MASKPAD) != 0, NTM>(c, t, buf, boff);
         }
     };
 
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
                     img[c.lane + (c.lane >> 4)] = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (ABL != 2) stage_range<NT, HS, NIB, LASTB>(c, tile, img, boff);
+                if constexpr (ABL != 2) stage_range<NT, HS, NIB, LASTB, false, (OPT & T2_NTLD) ? 0xffffffffu : 0u>(c, tile, img, boff);
             } else {
                 stage_full(tile, img);
             }

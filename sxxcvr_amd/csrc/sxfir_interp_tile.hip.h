@@ -38,7 +38,11 @@ struct InterpTileArgs {
     long long n_in;         // input samples per channel (outputs = n_in * L)
     long long in_stride, out_stride, hist_stride;
     int n_tiles, n_groups;
-    float thr2;             // S32 output: transmitter-keying threshold (squared magnitude)
+    float thr2;             // S32 output / KEYED: transmitter-keying threshold (squared magnitude)
+    // KEYED: the input samples [key_lo, key_hi) of channel 0 (indices relative to `in`) that reach thr2 are counted
+    // into *key_counter (convert_tx_buffer's keying rule, SoapySX.cpp:132-133), one atomic per wave and tile
+    unsigned long long *key_counter;
+    long long key_lo, key_hi;
 };
 
 template <int L>
@@ -68,7 +72,9 @@ struct InterpTile {
 };
 
 // S32OUT: outputs leave as S32_LE I2S wire words with the keying bits (convert_tx_buffer, SoapySX.cpp:116-137)
-template <int L, bool S32OUT = false>
+// KEYED: the transmitter-keying count of the call's input is taken from the staged tile (every input sample is in
+// LDS exactly once as a tile's own sample), so a pass that reads its input over PCIe reads it once, not twice
+template <int L, bool S32OUT = false, bool KEYED = false>
 __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 {
     using C = InterpTile<L>;
@@ -128,6 +134,27 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        if constexpr (KEYED) {
+            // the tile's own samples are chunks 16 .. 16 + TILE_IN/2 of the image (the 32 before them are history)
+            if (ch == 0 && q0 < a.key_hi && q0 + C::TILE_IN > a.key_lo) {
+                unsigned total = 0;
+#pragma unroll
+                for (int k = 0; k < (C::TILE_IN / 2 + 63) / 64; ++k) {
+                    const int cc = 64 * k + lane;
+                    const bool in_tile = C::TILE_IN / 2 >= 64 * (k + 1) || cc < C::TILE_IN / 2;
+                    const f32x4 v = lds[16 + (in_tile ? cc : 0)];
+                    const long long s = q0 + 2 * cc;
+                    // the rule as the reference's source states it: both products and the sum rounded once each
+                    const bool k0 = in_tile && s >= a.key_lo && s < a.key_hi &&
+                                    __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)) >= a.thr2;
+                    const bool k1 = in_tile && s + 1 >= a.key_lo && s + 1 < a.key_hi &&
+                                    __fadd_rn(__fmul_rn(v.z, v.z), __fmul_rn(v.w, v.w)) >= a.thr2;
+                    total += (unsigned)__builtin_popcountll(__ballot(k0)) + (unsigned)__builtin_popcountll(__ballot(k1));
+                }
+                if (lane == 0 && total) atomicAdd(a.key_counter, (unsigned long long)total);
+            }
+        }
 
 #pragma unroll 1
         for (int kt = 0; kt < C::KT; ++kt) {

@@ -170,6 +170,17 @@ class Resampler:
                  C.c_void_p(stream)))
         return n_out.value
 
+    def interpolate_keyed_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, key_first, key_count, counter_ptr,
+                              stream=0):
+        """sxfir_interpolate_keyed: the interpolation pass that also adds to the 8-byte device word at counter_ptr how
+        many of channel 0's input samples [key_first, key_first + key_count) reach the keying threshold
+        (convert_tx_buffer, SoapySX.cpp:132-133)."""
+        n_out = C.c_size_t()
+        self._ck(self._lib.sxfir_interpolate_keyed(self._plan, C.c_void_p(in_ptr), n_in, in_stride, C.c_void_p(out_ptr),
+                                                   out_stride, C.byref(n_out), key_first, key_count,
+                                                   C.c_void_p(counter_ptr), C.c_void_p(stream)))
+        return n_out.value
+
     def time_decimate_ptr(self, in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream=0):
         return self.time_passes_ptr(in_ptr, n_in, in_stride, out_ptr, out_stride, iters, stream)
 

@@ -146,4 +146,14 @@ int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_
     return SXFIR_OK;
 }
 
+// the interpolation pass with the keying count of channel 0's samples [key_first, key_first + key_count)
+int sxfir_interpolate_keyed(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev, size_t out_stride,
+                            size_t *n_out, size_t key_first, size_t key_count, unsigned long long *counter, void *st)
+{
+    if (key_first > n_in || key_count > n_in - key_first || !counter) return fail("fake backend: bad keying range");
+    const int rc = sxfir_interpolate(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, st);
+    if (rc) return rc;
+    return sxfir_count_keyed((const float *)in_dev + 2 * key_first, key_count, p->thr2, counter, st);
+}
+
 }  // extern "C"

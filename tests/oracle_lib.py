@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_ODIR = os.path.join(_ROOT, "oracle")
+# SXO_ORACLE_DIR: a copy of oracle/ to build and load instead (the build-race test works on a copy under tmp_path,
+# so that it never touches the tracked sources or swaps a library under a concurrently running session)
+_ODIR = os.environ.get("SXO_ORACLE_DIR") or os.path.join(_ROOT, "oracle")
 
 
 class StreamResult(C.Structure):

@@ -27,7 +27,7 @@ def test_sxfir_exports_every_declared_symbol():
         assert hasattr(lib, n), "libsxfir.so does not export " + n
     # and the python binding declares a prototype for each of them
     assert set(names) <= set(lib._sx_signatures), set(names) - set(lib._sx_signatures)
-    assert lib.sxfir_abi_version() == 3
+    assert lib.sxfir_abi_version() == 4
 
 
 def test_time_arithmetic_matches_oracle(oracle):
@@ -62,6 +62,12 @@ def test_no_cpu_fallback():
     with pytest.raises(sxxcvr_amd.NativeError) as ei:
         sxxcvr_amd.Resampler(0, np.ones(128, dtype=np.float32), 4)
     assert ei.value.code == -5
+    # the gather entry points refuse in the same way (and before librccl is even looked for)
+    ident = (C.c_ubyte * 128)()
+    assert lib.sxfir_comm_unique_id(ident) == -5
+    comm = C.c_void_p()
+    assert lib.sxfir_comm_init_rank(C.byref(comm), ident, 1, 0, 0) == -5 and not comm.value
+    assert lib.sxfir_comm_gather(None, None, None, 0, 0, 0, 0, None) == -1          # SXFIR_EINVAL: no communicator
 
 
 def test_product_does_not_touch_the_oracle():

@@ -151,15 +151,19 @@ def test_pipelined_gather_two_ranks_gloo(n_channels, chunks):
 def test_oracle_build_is_serialised(tmp_path):
     """Eight ranks of bench.py call oracle_lib.build() at once after a fresh checkout: the check-and-make must be
     one critical section (flock), or they race `make` over the .so files the others dlopen."""
+    import shutil
     import subprocess
     code = ("import sys, os; sys.path.insert(0, %r); import oracle_lib; oracle_lib.build(); "
             "o = oracle_lib.Oracle(); print(o.ticks_to_time_ns(256, 75000.0))" % os.path.join(ROOT, "tests"))
-    so = os.path.join(ROOT, "oracle", "libsxoracle.so")
-    old = os.path.getmtime(so) if os.path.exists(so) else None
-    os.utime(os.path.join(ROOT, "oracle", "sx_oracle.c"))          # "fresh checkout": sources newer than the libraries
-    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # a copy of oracle/ without its libraries = the fresh checkout; the tracked tree is left alone
+    odir = tmp_path / "oracle"
+    odir.mkdir()
+    for f in ("Makefile", "sx_oracle.c", "sx_oracle.h"):
+        shutil.copy(os.path.join(ROOT, "oracle", f), odir / f)
+    env = dict(os.environ, SXO_ORACLE_DIR=str(odir))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
              for _ in range(8)]
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
     assert all(o[0].strip() == "3413333" for o in outs), [o[0] for o in outs]
-    assert old is None or os.path.getmtime(so) > old
+    assert (odir / "libsxoracle.so").exists() and (odir / "libsxoracle_fast.so").exists()

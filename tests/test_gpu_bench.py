@@ -43,6 +43,28 @@ def test_bench_line_every_config(config):
     assert line["value"] > 0 and r["kernel_ms"] > 0
 
 
+def test_bench_config3_full_duplex_line():
+    """BASELINE config 3 as ONE workload: /8 RX and x8 TX side by side on two streams, both verified against the
+    oracle, a roofline entry per direction, and the timed readStream -> writeStream loop through the Device with the
+    latency check on every block (example/linear_repeater.py:40-69; SoapySX.cpp:950, :1012)."""
+    line = run_bench(["--config", "3", "--steps", "3", "--warmup", "2", "--settle", "4", "--log2-samples", "22",
+                      "--no-cpu-baseline"])
+    assert line["verified"] is True and line["config"]["bench_config"] == "3" and line["n_gpus"] == 1
+    assert "full-duplex" in line["config"]["workload"] and line["config"]["verified_outputs"] >= 8192
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    for d in ("rx", "tx"):
+        assert r[d]["span_ms_per_step"] > 0 and 0 < r[d]["frac"] < 1 and r["alone_kernel_ms"][d] > 0
+    assert r["algorithmic_bytes_per_step"] == 2 * 9 * (1 << 22)
+    t = line["timed_loop"]
+    assert "error" not in t, t
+    assert t["latency_check_passed"] is True
+    for blk in (256, 1024, 4096):
+        b = t["%d_sample_blocks" % blk]
+        assert b["blocks_off_position"] == 0 and b["round_trip_us_median"] > 0 and b["latency_samples"] == 3 * blk
+    assert t["256_sample_blocks"]["latency_ns"] == 2560000          # 768 samples at 300 kS/s
+
+
 def test_bench_reports_device_and_cpu_figures():
     line = run_bench(["--steps", "3", "--warmup", "2", "--settle", "4", "--log2-samples", "22"], timeout=900)
     assert line["verified"] is True

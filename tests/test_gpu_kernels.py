@@ -144,6 +144,53 @@ def test_tiled_interpolator_bit_exact(oracle, L, n_in):
     assert_bit_exact(to_cpu(gen.process(to_gpu(x))), ref, "generic interp L=%d" % L)
 
 
+@pytest.mark.parametrize("L,fmt,nchan,n_in,generic", [(8, "CF32", 1, 5000, False), (8, "S32", 1, 64 * 50 + 7, False),
+                                                      (4, "CF32", 2, 1 << 15, False), (16, "CF32", 1, 4099, False),
+                                                      (32, "S32", 3, 3333, False), (8, "CF32", 1, 3001, True),
+                                                      (4, "CF32", 1, 1, False), (8, "CF32", 1, 1 << 18, False)])
+def test_interpolator_takes_the_keying_count_in_the_same_pass(oracle, L, fmt, nchan, n_in, generic):
+    """sxfir_interpolate_keyed: outputs bit-identical to sxfir_interpolate, and the counter grows by the number of
+    channel-0 samples inside the given range whose I word carries the keying bits in the oracle's convert_tx_buffer
+    (SX.cpp:126-135): ranges that start / end inside tiles, the empty range, the whole block, two calls of one stream
+    (the counter accumulates), several channels (only channel 0 counts), the generic kernel's fallback."""
+    import torch
+    from sxxcvr_amd.resampler import KERNEL_GENERIC
+    thr2 = np.float32(0.49)
+    h = sxxcvr_amd.design_lowpass(32 * L, L, 8.0, float(L))
+    x = np.stack([oracle.synth_iq(SEED, 20 + c, 0, 2 * n_in) for c in range(nchan)])
+    keyed0 = (oracle.convert_tx(x[0], thr2).reshape(-1, 2)[:, 0] & 3) == 3
+    assert n_in < 100 or 0 < keyed0.sum() < keyed0.size
+    a, b = sxxcvr_amd.Resampler(INTERPOLATE, h, L, nchan=nchan, fmt=fmt), sxxcvr_amd.Resampler(INTERPOLATE, h, L, nchan=nchan, fmt=fmt)
+    for p in (a, b):
+        p.set_tx_threshold(float(thr2))
+        if generic:
+            p.set_kernel(KERNEL_GENERIC)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    xg = torch.from_numpy(x).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    want = 0
+    ranges = [(0, n_in), (n_in // 3, n_in - n_in // 3 - (1 if n_in > 2 else 0))]
+    for call, (first, count) in enumerate(ranges):
+        blk = xg[:, call * n_in:(call + 1) * n_in].contiguous()
+        ref = a.process(blk if nchan > 1 else blk[0])
+        out = torch.empty((nchan, n_in * L), dtype=torch.complex64, device="cuda")
+        got = b.interpolate_keyed_ptr(blk.data_ptr(), n_in, n_in, out.data_ptr(), n_in * L, first, count, counter.data_ptr(), st)
+        assert got == n_in * L
+        _sync()
+        ref = ref.view(torch.int32) if fmt == "S32" else torch.view_as_real(ref).view(torch.int32)
+        assert torch.equal(ref.reshape(-1), torch.view_as_real(out).view(torch.int32).reshape(-1)), "outputs differ"
+        want += int(keyed0[call * n_in + first:call * n_in + first + count].sum())
+        assert int(counter.item()) == want, (call, first, count)
+    # the empty range leaves the counter alone; a range outside the block is refused
+    blk = xg[:, :n_in].contiguous()
+    out = torch.empty((nchan, n_in * L), dtype=torch.complex64, device="cuda")
+    b.interpolate_keyed_ptr(blk.data_ptr(), n_in, n_in, out.data_ptr(), n_in * L, n_in, 0, counter.data_ptr(), st)
+    _sync()
+    assert int(counter.item()) == want
+    with pytest.raises(RuntimeError):
+        b.interpolate_keyed_ptr(blk.data_ptr(), n_in, n_in, out.data_ptr(), n_in * L, 1, n_in, counter.data_ptr(), st)
+
+
 @pytest.mark.parametrize("D,n_in", [(32, 1 << 18), (32, 4096 * 5 + 32 * 3), (8, 1 << 17), (4, 1 << 16), (16, 50000)])
 def test_cf16_tiled_decimators(oracle, D, n_in):
     """CF16 storage through the LDS-tiled multi-column kernel: bit-exact against the oracle applied

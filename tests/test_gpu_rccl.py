@@ -115,3 +115,73 @@ def test_gather_allreduce_barrier_through_rccl(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "rccl ok world %d" % world in outs[0]
     assert "rccl pipeline ok world %d" % world in outs[0], outs[0][-1500:]
+
+
+def _run(cmd, env=None, timeout=300):
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    return p.returncode, p.stdout
+
+
+def test_c_caller_gathers_through_the_c_abi(tmp_path):
+    """sxfir_comm_* (include/sxfir.h) from plain C, no Python and no torch.distributed in the processes that move
+    the data: tools/gather_c.c decimates 8 channels per rank and gathers the blocks to rank 0 over librccl -- rank per
+    process (the id travels through a file) on min(visible GPUs, 2) ranks, and one process driving all its
+    communicators (sxfir_comm_init_all / sxfir_comm_gather_all).  With one GPU the world is one rank: communicator
+    set-up, the root's own block, the chunking and the checks all run; with more, over xGMI."""
+    import json
+    import torch
+    exe = os.path.join(ROOT, "sxxcvr_amd", "lib", "sx_gather_c")
+    assert os.path.exists(exe), "sx_gather_c is missing: python -m sxxcvr_amd.build"
+    ngpu = max(torch.cuda.device_count(), 1)
+    world = min(ngpu, 2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    idfile = str(tmp_path / "rccl_id")
+    procs = [subprocess.Popen([exe, "ranks", str(world), str(r), idfile, "18", "3"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    line = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][-1])
+    assert line["verified"] is True and line["nranks"] == world and line["bytes_per_rank"] == 8 * 8 * (1 << 16)
+    rc, out = _run([exe, "all", str(world), "18", "3"], env=env)
+    assert rc == 0, out[-1500:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["verified"] is True and line["form"].startswith("one process")
+
+
+def test_comm_gather_from_python_world_of_one():
+    """The same entry points through ctypes on a world of one rank: the root's own block is copied into its place in
+    the gathered buffer (or left alone when it is already there), chunked and unchunked, on the caller's stream;
+    argument errors come back as SXFIR_EINVAL with a message."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import sxxcvr_amd
+    lib = sxxcvr_amd.load_sxfir()
+    ident = (C.c_ubyte * 128)()
+    assert lib.sxfir_comm_unique_id(ident) == 0, lib.sxfir_last_error()
+    comm = C.c_void_p()
+    assert lib.sxfir_comm_init_rank(C.byref(comm), ident, 1, 0, -1) == 0, lib.sxfir_last_error()
+    rank, n, dev = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    assert lib.sxfir_comm_rank(comm, C.byref(rank), C.byref(n), C.byref(dev)) == 0
+    assert (rank.value, n.value) == (0, 1) and dev.value == torch.cuda.current_device()
+    src = torch.arange(1 << 16, dtype=torch.int32, device="cuda")
+    dst = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = src.numel() * 4
+    for chunk in (0, 4096, 100000):
+        dst.zero_()
+        assert lib.sxfir_comm_gather(comm, src.data_ptr(), dst.data_ptr(), nbytes, nbytes, 0, chunk, st) == 0, lib.sxfir_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst), chunk
+    assert lib.sxfir_comm_gather(comm, src.data_ptr(), src.data_ptr(), nbytes, nbytes, 0, 0, st) == 0     # in place
+    assert lib.sxfir_comm_gather(comm, src.data_ptr(), dst.data_ptr(), nbytes, nbytes, 1, 0, st) == -1    # no such root
+    assert b"root" in lib.sxfir_last_error()
+    assert lib.sxfir_comm_gather(comm, src.data_ptr(), dst.data_ptr(), nbytes, nbytes - 4, 0, 0, st) == -1
+    assert lib.sxfir_comm_destroy(comm) == 0

@@ -21,7 +21,17 @@
 #   soak[:n]            the whole GPU suite n times (default 16), outcome lines counted
 #   devpath:n,..        tools/devpath_probe.py per-call times at the given block sizes
 #   power               board power / clock while the /4 kernel runs (tools/gpu_power.sh)
-set -u
+#   kb4nt               /4 kernel: non-temporal staging loads (all DMAs / all but the next tile's halo) against the shipped kernel, and their memory sides
+#   hostvis[:iters[,filter]]  tools/hostvis_probe.hip: kernel stores into host memory, every word checked after the wait
+#   gatherc[:log2n]     tools/gather_c.c: the C-ABI gather (sxfir_comm_*) on one rank, both forms
+#   kb4w                /4 kernel: 8 against 16 waves per CU (LDS padding), nt loads, whole kernel and memory side, random and all-zero input
+#   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
+#   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
+#   listpmc             rocprofv3 --list-avail (which counters this box exposes)
+# Every step's exit status is recorded (rc=N in its log and on stdout); the script exits non-zero if any step
+# failed or was unknown, so `gpurun -- 'bash tools/gpu_steps.sh ...'` reports a failing GPU suite.
+set -u -o pipefail
+FAILED=""
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -30,36 +40,50 @@ for S in "$@"; do
   NAME=${S%%:*}; ARG=""; [ "$S" != "$NAME" ] && ARG=${S#*:}
   LOG=$OUT/$(echo $S | tr ':,/ ' '____').txt
   echo "=== $S" | tee -a $LOG
+  RC=0
   case $NAME in
-    tests)    if [ -n "$ARG" ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q -k "$ARG" >> $LOG 2>&1; else timeout 2400 python3 -m pytest tests -m gpu -x -q >> $LOG 2>&1; fi; tail -5 $LOG ;;
-    testsall) timeout 2700 python3 -m pytest tests -m gpu -q >> $LOG 2>&1; tail -15 $LOG ;;          # no -x: every failure
-    repeat)   for i in 1 2 3 4 5; do timeout 600 python3 -m pytest tests -m gpu -q -k "$ARG" 2>&1 | tail -3 >> $LOG; done; cat $LOG ;;
-    soak)     for i in $(seq 1 ${ARG:-16}); do timeout 900 python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|differ|Error" | cut -c1-300 >> $LOG; done; sort $LOG | uniq -c | tail -8 ;;
-    repfile)  for i in 1 2 3 4 5 6 7 8; do timeout 900 python3 -m pytest $ARG -m gpu -q 2>&1 | grep -E "passed|failed|differ" | cut -c1-400 >> $LOG; done; cat $LOG ;;
-    devpath)  for n in ${ARG//,/ }; do timeout 300 python3 tools/devpath_probe.py $n 60 >> $LOG 2>&1; done; grep -v amdgpu.ids $LOG | tail -16 ;;
-    stress)   timeout 900 python3 tools/stress_direct_rx.py ${ARG//,/ } >> $LOG 2>&1; grep -v amdgpu.ids $LOG | tail -25 ;;
-    bench)    timeout 600 python3 bench.py --config ${ARG:-2} --no-cpu-baseline --no-through-device >> $LOG 2>&1; tail -1 $LOG | cut -c1-1500 ;;
-    benchfull) T0=$(date +%s); timeout 900 python3 bench.py >> $LOG 2>&1; echo "bench.py wall seconds: $(( $(date +%s) - T0 ))" | tee -a $LOG; tail -2 $LOG | cut -c1-3000 ;;
-    kb32)     KB_D=32 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 dense:2:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -40 ;;
-    kb32h)    KB_D=32 KB_FMT=CF16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
-    kb8)      KB_D=8 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -24 ;;
-    kb16)     KB_D=16 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -20 ;;
-    kb4)      KB_D=4 timeout 600 python3 tools/kbench.py x:16:0:0:0 t2.1.1088:16:0:5:0 t2.1.1088:16:0:1:0 t2.1.1088:16:0:2:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -14 ;;
-    kb4g)     KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py x:16:0:0:0 x:8:0:0:0 x:32:0:0:0 x:64:0:0:0 x:24:0:0:0 t2.1.1088:16:0:1:0 t2.1.1088:64:0:1:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -9 ;;
-    kb4p)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.5184:16:0:0:0 t2.1.13376:16:0:0:0 t2.1.9280:16:0:0:0 t2.1.1088:16:0:5:0 t2.1.9280:16:0:5:0 t2.1.5184:16:0:5:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep -v "wave lifetime\|mean lifetime\|distinct" | tail -14 ;;
-    kb4c8)    KB_D=4 KB_NCHAN=8 timeout 600 python3 tools/kbench.py x:16:0:0:0 x:8:0:0:0 x:32:0:0:0 >> $LOG 2>&1; KB_D=4 KB_NCHAN=1 timeout 600 python3 tools/kbench.py x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -6 ;;
-    kb4t)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.16448:16:0:0:0 t2.1.64:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -9 ;;
-    kb4o)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.64:16:0:0:0 t2.1.1088:16:0:0:0 t2.1.2112:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -10 ;;
-    ib8)      KB_L=8 timeout 600 python3 tools/ibench.py >> $LOG 2>&1; tail -8 $LOG ;;
-    pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; tail -2 $LOG ;;
-    profile)  bash tools/profile_round.sh $TAG ${ARG:-2} >> $LOG 2>&1; tail -3 $LOG ;;
-    clocks)   hipcc --offload-arch=gfx950 -O3 tools/clock_calib.hip -o /tmp/clock_calib >> $LOG 2>&1 && timeout 120 /tmp/clock_calib >> $LOG 2>&1; tail -9 $LOG ;;
-    mempower) timeout 300 python3 tools/mempower.py >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -5 ;;
-    psplit)   timeout 300 python3 tools/power_split.py ${ARG:-4} >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -4 ;;
-    pprobe)   timeout 300 python3 tools/power_probe.py ${ARG:-4} >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -6 ;;
+    tests)    if [ -n "$ARG" ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q -k "$ARG" >> $LOG 2>&1; else timeout 2400 python3 -m pytest tests -m gpu -x -q >> $LOG 2>&1; fi; RC=$?; tail -5 $LOG ;;
+    testsall) timeout 2700 python3 -m pytest tests -m gpu -q >> $LOG 2>&1; RC=$?; tail -15 $LOG ;; # no -x: every failure
+    repeat)   for i in 1 2 3 4 5; do timeout 600 python3 -m pytest tests -m gpu -q -k "$ARG" 2>&1 | tail -3 >> $LOG; done; RC=$?; cat $LOG ;;
+    soak)     for i in $(seq 1 ${ARG:-16}); do timeout 900 python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|differ|Error" | cut -c1-300 >> $LOG; done; RC=$?; sort $LOG | uniq -c | tail -8 ;;
+    repfile)  for i in 1 2 3 4 5 6 7 8; do timeout 900 python3 -m pytest $ARG -m gpu -q 2>&1 | grep -E "passed|failed|differ" | cut -c1-400 >> $LOG; done; RC=$?; cat $LOG ;;
+    devpath)  for n in ${ARG//,/ }; do timeout 300 python3 tools/devpath_probe.py $n 60 >> $LOG 2>&1; done; RC=$?; grep -v amdgpu.ids $LOG | tail -16 ;;
+    stress)   timeout 900 python3 tools/stress_direct_rx.py ${ARG//,/ } >> $LOG 2>&1; RC=$?; grep -v amdgpu.ids $LOG | tail -25 ;;
+    bench)    timeout 600 python3 bench.py --config ${ARG:-2} --no-cpu-baseline --no-through-device >> $LOG 2>&1; RC=$?; tail -1 $LOG | cut -c1-1500 ;;
+    benchfull) T0=$(date +%s); timeout 900 python3 bench.py >> $LOG 2>&1; RC=$?; echo "bench.py wall seconds: $(( $(date +%s) - T0 ))" | tee -a $LOG; tail -2 $LOG | cut -c1-3000 ;;
+    kb32)     KB_D=32 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 dense:2:0:0:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -40 ;;
+    kb32h)    KB_D=32 KB_FMT=CF16 timeout 600 python3 tools/kbench.py w4:8:0:0:0 w4:8:0:3:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    kb8)      KB_D=8 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 dense:4:0:0:0 dense:16:0:0:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -24 ;;
+    kb16)     KB_D=16 timeout 600 python3 tools/kbench.py dense:8:0:0:0 w4:8:0:0:0 dense:8:0:3:0 w4:8:0:3:0 dense:8:0:1:0 dense:8:0:2:0 w4:8:0:1:0 w4:8:0:2:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -20 ;;
+    kb4)      KB_D=4 timeout 600 python3 tools/kbench.py x:16:0:0:0 t2.1.1088:16:0:5:0 t2.1.1088:16:0:1:0 t2.1.1088:16:0:2:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -14 ;;
+    kb4g)     KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py x:16:0:0:0 x:8:0:0:0 x:32:0:0:0 x:64:0:0:0 x:24:0:0:0 t2.1.1088:16:0:1:0 t2.1.1088:64:0:1:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -9 ;;
+    kb4p)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.5184:16:0:0:0 t2.1.13376:16:0:0:0 t2.1.9280:16:0:0:0 t2.1.1088:16:0:5:0 t2.1.9280:16:0:5:0 t2.1.5184:16:0:5:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep -v "wave lifetime\|mean lifetime\|distinct" | tail -14 ;;
+    kb4c8)    KB_D=4 KB_NCHAN=8 timeout 600 python3 tools/kbench.py x:16:0:0:0 x:8:0:0:0 x:32:0:0:0 >> $LOG 2>&1; KB_D=4 KB_NCHAN=1 timeout 600 python3 tools/kbench.py x:16:0:0:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -6 ;;
+    kb4t)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.16448:16:0:0:0 t2.1.64:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -9 ;;
+    kb4o)     KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.64:16:0:0:0 t2.1.1088:16:0:0:0 t2.1.2112:16:0:0:0 x:16:0:0:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -10 ;;
+    ib8)      KB_L=8 timeout 600 python3 tools/ibench.py >> $LOG 2>&1; RC=$?; tail -8 $LOG ;;
+    pmc)      bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ${ARG//,/ } >> $LOG 2>&1; RC=$?; tail -2 $LOG ;;
+    profile)  bash tools/profile_round.sh $TAG ${ARG:-2} >> $LOG 2>&1; RC=$?; tail -3 $LOG ;;
+    clocks)   hipcc --offload-arch=gfx950 -O3 tools/clock_calib.hip -o /tmp/clock_calib >> $LOG 2>&1 && timeout 120 /tmp/clock_calib >> $LOG 2>&1; RC=$?; tail -9 $LOG ;;
+    mempower) timeout 300 python3 tools/mempower.py >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -5 ;;
+    psplit)   timeout 300 python3 tools/power_split.py ${ARG:-4} >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -4 ;;
+    pprobe)   timeout 300 python3 tools/power_probe.py ${ARG:-4} >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -6 ;;
     grbm)     # GRBM_GUI_ACTIVE on a short (2^28) and a long (2^34 samples, ~33 ms) dispatch of the same kernel
               for L in 28 34; do timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/grbm_$L -- python3 tools/onekernel.py 4 CF32 $L > /dev/null 2>&1; python3 tools/grbm_clock.py $OUT/grbm_$L $L >> $LOG 2>&1; done; find $OUT -name "*.csv" -size +1M -delete; tail -4 $LOG ;;
-    power)    bash tools/gpu_power.sh >> $LOG 2>&1; tail -20 $LOG ;;
-    *)        echo "unknown step $S" | tee -a $LOG ;;
+    power)    bash tools/gpu_power.sh >> $LOG 2>&1; RC=$?; tail -20 $LOG ;;
+    kb4nt)    KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py t2.1.1088:16:0:0:0 t2.1.33856:16:0:0:0 t2.1.66624:16:0:0:0 t2.1.33872:16:0:0:0 x:16:0:0:0 t2.1.1088:16:0:1:0 t2.1.33856:16:0:1:0 t2.1.66624:16:0:1:0 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -24 ;;
+    hostvis)  hipcc --offload-arch=gfx950 -O3 -w tools/hostvis_probe.hip -o /tmp/hostvis_probe >> $LOG 2>&1 && timeout 1500 /tmp/hostvis_probe ${ARG//,/ } >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -60 ;;
+    gatherc)  timeout 300 ./sxxcvr_amd/lib/sx_gather_c ranks 1 0 /tmp/sx_rccl_id_$$ ${ARG:-22} 5 >> $LOG 2>&1 && timeout 300 ./sxxcvr_amd/lib/sx_gather_c all 1 ${ARG:-22} 5 >> $LOG 2>&1; RC=$?; tail -4 $LOG ;;
+    kb4w)     # waves per CU capped through LDS padding (8 per CU, 32 generations) against 16 per CU, with and without nt loads; whole kernel and memory side; then the same on an all-zero input
+              V="t2.1.1088:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.1088:32:0:0:0:10600 t2.1.66624:32:0:0:0:10600 t2.1.66624:64:0:0:0:10600 t2.1.1088:16:0:1:0:0 t2.1.66624:16:0:1:0:0 t2.1.1088:32:0:1:0:10600 t2.1.66624:32:0:1:0:10600 t2.1.66624:64:0:1:0:0"
+              KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
+    mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
+    listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;
+    *)        echo "unknown step $S" | tee -a $LOG; RC=64 ;;
   esac
+  echo "rc=$RC ($S)" | tee -a $LOG
+  [ $RC -ne 0 ] && FAILED="$FAILED $S(rc=$RC)"
 done
+if [ -n "$FAILED" ]; then echo "FAILED STEPS:$FAILED"; exit 1; fi
+exit 0

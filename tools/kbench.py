@@ -17,18 +17,23 @@ configs = []
 for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
     f = spec.split(":")
     v, ov, occ = f[0], f[1], f[2]
-    configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0, int(f[4]) if len(f) > 4 else 0))
+    # v:oversub:occ:ablate:sched[:lds_pad]   lds_pad = extra dynamic LDS bytes per workgroup (tile2 variants: fewer waves per CU)
+    configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0, int(f[4]) if len(f) > 4 else 0, int(f[5]) if len(f) > 5 else 0))
 
 n = (1 << log2n) // nchan
 dt = torch.complex64 if FMT == "CF32" else torch.int32
 x = torch.empty((nchan, n), dtype=dt, device="cuda")
 sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=FMT)
+if os.environ.get("KB_ZERO") == "1":                 # all-zero input: no toggling in the FMA datapath, the clock stays free of the power cap
+    x.zero_()
+    print("# all-zero input (KB_ZERO=1): the kernel's structure without the power cap")
 yoff = int(os.environ.get("KB_YOFF", "0"))          # output buffer displaced by this many bytes (HBM channel phase probe)
 ybase = torch.empty(nchan * (n // D) * (8 if FMT == "CF32" else 4) + yoff + 64, dtype=torch.uint8, device="cuda")
 y = ybase[yoff:yoff + nchan * (n // D) * (8 if FMT == "CF32" else 4)].view(dt).view(nchan, n // D)
 taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
-for v, ov, occ, abl, sched in configs:
+for v, ov, occ, abl, sched, pad in configs:
+    os.environ["SXFIR_LDS_PAD"] = str(pad)
     os.environ["SXFIR_TILE_VARIANT"] = v.replace(".", ":")      # "t2.2.3" -> "t2:2:3" (tile2 kernel: waves per workgroup, option bits)
     os.environ.pop("SXFIR_MULTI_W", None); os.environ.pop("SXFIR_MULTI_PS", None)
     os.environ["SXFIR_DENSE"] = "0" if v[0] == "w" else "1"   # "dense" (or "x"): decim_dense_kernel at /8, /16, /32; "w4": the multi-column kernel
@@ -109,5 +114,5 @@ for c, p in zip(configs, plans):
 for c in configs:
     a = np.array(res[c])
     gbs = (8.0 + 8.0 / D) * (1.0 if FMT == "CF32" else 0.5) * (1 << log2n) / (a * 1e-3) / 1e9
-    print("%-12s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
-        "%s:%d:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
+    print("%-24s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
+        "%s:%d:%d:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
