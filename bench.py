@@ -458,6 +458,106 @@ def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gp
     return out
 
 
+def measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_per_gpu, elapsed, steps, step_into, psteps=6):
+    """--gather capi: the same exchange through the C ABI (sxfir_comm_* over librccl, include/sxfir.h), the way a
+    C / C++ host would run it: no torch.distributed in the data path.  torch.distributed only carries the 128-byte
+    communicator id from rank 0 to the others (any launcher's store would do) and the barriers of the timing.
+    Serial form, then the steady state: two output buffers in turn, each step's gather queued in 4 pieces (whole
+    channels) on a side stream behind an event of the kernel that produced the block."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import sxxcvr_amd
+    lib = sxxcvr_amd.load_sxfir()
+
+    def ck(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %d %s" % (what, rc, lib.sxfir_last_error().decode("utf-8", "replace")))
+
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        ck(lib.sxfir_comm_unique_id(buf), "sxfir_comm_unique_id")
+        ident = torch.tensor(list(buf), dtype=torch.uint8)
+    ident = ident.to(cdev)
+    dist.broadcast(ident, src=0)
+    raw = (C.c_ubyte * 128)(*ident.cpu().tolist())
+    comm = C.c_void_p()
+    ck(lib.sxfir_comm_init_rank(C.byref(comm), raw, world, rank, gpu_index), "sxfir_comm_init_rank")
+    peer_bytes = y.numel() * 8
+    full = torch.empty((total_channels,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device) if rank == 0 else None
+    recv = full.data_ptr() if rank == 0 else None
+    side = torch.cuda.Stream(y.device)
+    chunk = peer_bytes // 4
+
+    def gather(src, stream):
+        ck(lib.sxfir_comm_gather(comm, src.data_ptr(), recv, peer_bytes, peer_bytes, 0, chunk, stream), "sxfir_comm_gather")
+
+    main_stream = torch.cuda.current_stream(y.device)
+    for _ in range(2):
+        gather(y, main_stream.cuda_stream)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        gather(y, main_stream.cuda_stream)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g = (time.perf_counter() - g0) / reps
+    t = torch.tensor([g], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    g = float(t.item())
+    out = {
+        "via": "C ABI: sxfir_comm_gather over librccl (ncclGroupStart; root ncclRecv x %d; peers ncclSend; ncclGroupEnd; "
+               "4 pieces of whole channels)" % (world - 1),
+        "ms": round(g * 1e3, 3), "bytes_per_peer": peer_bytes,
+        "GB/s_into_root": round(peer_bytes * (world - 1) / g / 1e9, 2), "GB/s_per_link": round(peer_bytes / g / 1e9, 2),
+        "value_with_gather": round(world * wide_per_gpu * 1.0 / (elapsed / steps + g) / 1e6, 1),
+        "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part of value",
+    }
+    if rank == 0:
+        out["root_holds_own_channels"] = bool(torch.equal(full[: y.shape[0]], y))
+        out["gathered_shape"] = list(full.shape)
+    # steady state: kernel of step s on the main stream into buffer s % 2; its gather on the side stream behind an
+    # event; before a buffer is overwritten the main stream waits for the gather that last read it
+    ybuf = [y, torch.empty_like(y)]
+    produced = [torch.cuda.Event(), torch.cuda.Event()]
+    gathered = [None, None]
+
+    def run(nsteps):
+        for s_ in range(nsteps):
+            k = s_ % 2
+            if gathered[k] is not None:
+                main_stream.wait_event(gathered[k])
+            step_into(ybuf[k])
+            produced[k].record(main_stream)
+            side.wait_event(produced[k])
+            gather(ybuf[k], side.cuda_stream)
+            gathered[k] = torch.cuda.Event()
+            gathered[k].record(side)
+        torch.cuda.synchronize()
+
+    run(2)
+    dist.barrier()
+    p0 = time.perf_counter()
+    run(psteps)
+    dist.barrier()
+    tp = time.perf_counter() - p0
+    t = torch.tensor([tp], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tp = float(t.item())
+    per_link = peer_bytes * psteps / tp / 1e9
+    out["overlapped_value"] = round(world * wide_per_gpu * psteps / tp / 1e6, 1)
+    out["link_bound_frac"] = round(per_link / XGMI_LINK_GBS, 4)
+    out["overlapped"] = {"steps": psteps, "ms_per_step": round(tp / psteps * 1e3, 3), "chunks_per_step": 4,
+                         "GB/s_per_link": round(per_link, 2), "link_peak_GB/s": XGMI_LINK_GBS}
+    if rank == 0:
+        out["overlapped"]["root_holds_own_channels"] = bool(torch.equal(full[: y.shape[0]], ybuf[(psteps - 1) % 2]))
+    lib.sxfir_comm_destroy(comm)
+    return out
+
+
 def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_into, psteps=6):
     """The same exchange in steady state; returns the keys to add to the line's "gather" object."""
     import torch
@@ -688,6 +788,9 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=28, help="wideband-side samples per GPU (log2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-through-device", action="store_true")
+    ap.add_argument("--gather", default="torch", choices=["torch", "capi"],
+                    help="N > 1: the gather of the decimated output through torch.distributed (nccl = RCCL) or through the "
+                         "C ABI (sxfir_comm_gather over librccl directly)")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
@@ -922,7 +1025,8 @@ def main():
                 line["through_device"] = through_device()
             except Exception as e:                               # reported beside the value, never able to take it down
                 line["through_device"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, at every N: a SCALE line at N > 1 is self-contained
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
 
@@ -947,11 +1051,15 @@ def main():
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps)
+            if args.gather == "capi":
+                gather = measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_per_gpu, elapsed, args.steps,
+                                             lambda out: plan.process(x, out=out))
+            else:
+                gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps)
         except Exception as e:
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
         finished.set()
-        if "error" not in gather:
+        if "error" not in gather and args.gather != "capi":
             finished, stage["name"], stage["gather"] = threading.Event(), "overlapped", gather
             threading.Thread(target=watchdog, daemon=True).start()
             try:

@@ -21,12 +21,14 @@
 // for the occupancy query in sxfir_create and the launch in launch_decim.  The production library carries
 // what it launches; the profiling build (-DSXFIR_PROFILING, libsxfir_prof.so: tools/ and
 // tests/test_gpu_variants.py) adds the A/B variants, the ablation modes and the environment knobs.
+// (shipped: CF16 storage only -- since round 3 every CF32 / S32-word plan at ratio 8, 16, 32 runs decim_dense_kernel,
+// so the multi-column kernel's CF32 and S32 instances exist in the profiling build alone, as the A/B partner)
 #define SXFIR_MULTI_SHIPPED(X) \
-    X(8, 4, false, 2) X(16, 4, false, 2) X(32, 4, false, 2) \
     X(4, 1, true, 2) X(8, 4, true, 2) X(16, 4, true, 2) X(32, 4, true, 2)
 #ifdef SXFIR_PROFILING
 #define SXFIR_MULTI_VARIANTS(X) \
     SXFIR_MULTI_SHIPPED(X) \
+    X(8, 4, false, 2) X(16, 4, false, 2) X(32, 4, false, 2) \
     X(4, 1, false, 2) X(4, 4, false, 2) X(8, 1, false, 2) X(8, 2, false, 2) X(16, 2, false, 2) X(32, 8, false, 2) \
     X(8, 1, true, 2) X(8, 2, true, 2) X(16, 2, true, 2) X(32, 8, true, 2) \
     X(4, 2, false, 4) X(8, 2, false, 4) X(8, 4, false, 4) X(16, 4, false, 4) X(16, 8, false, 4) X(32, 8, false, 4) \
@@ -41,7 +43,7 @@
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
     X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376) X(1, 16448) \
-    X(1, 33856) X(1, 66624) X(1, 33872)
+    X(1, 33856) X(1, 66624) X(1, 33872) X(1, 66625) X(1, 67136) X(1, 132160) X(1, 197696)
 // variants that also exist with phase stamps (ABL 5)
 #define SXFIR_TILE2_STAMPED(X) X(1, 33856) X(1, 66624) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
@@ -96,6 +98,7 @@ struct sxfir_plan {
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
+    bool dense_nt;         // decim_dense_kernel with non-temporal staging loads (profiling build: SXFIR_DENSE_NT)
     bool dense32;          // decim_dense_kernel (ratio 8 / 16 / 32, 32 taps per phase, CF32 / S32): the linear-image form
     int multi_waves;       // waves per workgroup of the multi kernel
     int multi_ps;          // lanes that share the 32 tap rows of one output (2 or 4) in the multi kernel
@@ -259,6 +262,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the multi-column kernel
     p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && fmt != SXFIR_CF16;
     p->t2_wpg = p->t2_opt = 0;
+    p->dense_nt = false;
     p->lds_pad = 0;
     p->pair = false;
     p->pair_xsep = false;
@@ -282,6 +286,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
     }
     if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
+    if (const char *v = getenv("SXFIR_DENSE_NT")) p->dense_nt = atoi(v) != 0;
     if (getenv("SXFIR_MULTI_PS") || getenv("SXFIR_MULTI_W")) p->dense32 = false;   // those knobs belong to the multi-column kernel
     if (p->multi_capable && fmt != SXFIR_S32 && !p->dense32) {
         if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
@@ -306,10 +311,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false>)
                 : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true> : (const void *)sxfir::decim_dense_kernel<16, 0, false>)
                               : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true> : (const void *)sxfir::decim_dense_kernel<32, 0, false>);
+#ifdef SXFIR_PROFILING
         } else if (fmt == SXFIR_S32) {   // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
             k = ratio == 8    ? (const void *)sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>
                 : ratio == 16 ? (const void *)sxfir::decim_multi_kernel<16, 4, false, 0, 2, true>
                               : (const void *)sxfir::decim_multi_kernel<32, 4, false, 0, 2, true>;
+#endif
         } else {
             switch (SXFIR_MULTI_KEY(ratio, W, fmt == SXFIR_CF16, p->multi_ps)) {
 #define SXFIR_X(DD, WW, HH, PP) \
@@ -611,6 +618,15 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 p->stamps_n = need;
                 a.stamps = (unsigned long long *)p->stamps_dev;
             }
+            if (p->fmt != SXFIR_S32 && p->ablate == 0 && p->dense_nt) {
+                if (p->ratio == 8) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, true>), grid, dim3(256), 0, st, a);
+                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 0, false, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, true>), grid, dim3(256), 0, st, a);
+            } else if (p->fmt != SXFIR_S32 && p->ablate == 1 && p->dense_nt) {
+                if (p->ratio == 8) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 1, false, true>), grid, dim3(256), 0, st, a);
+                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 1, false, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 1, false, true>), grid, dim3(256), 0, st, a);
+            } else
             if (p->fmt != SXFIR_S32 && p->ablate == 1) SXFIR_DENSE_BY_RATIO(1, false);
             else if (p->fmt != SXFIR_S32 && p->ablate == 2) SXFIR_DENSE_BY_RATIO(2, false);
             else if (p->fmt != SXFIR_S32 && p->ablate == 3) SXFIR_DENSE_BY_RATIO(3, false);
@@ -624,6 +640,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             *history_done = true;
             return SXFIR_OK;
         }
+#ifdef SXFIR_PROFILING
         if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 8: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
@@ -634,6 +651,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             *history_done = true;
             return SXFIR_OK;
         }
+#endif
         int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps);
 #ifdef SXFIR_PROFILING
         if (p->ablate == 3) {

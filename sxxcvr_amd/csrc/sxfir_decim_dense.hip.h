@@ -79,7 +79,11 @@ __device__ __forceinline__ float butterfly_add(float v)
 
 // ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
 // kernel with s_memtime stamps around its phases (a.stamps, 5 counters per wave as decim_multi_kernel)
-template <int D, int ABL = 0, bool S32IN = false>
+// NTLD: the staging DMAs of image rows that no later tile reads again are non-temporal loads (round 4: a read stream
+// runs 4.6 % faster with them, tools/membench5.hip).  The image's last 31 rows are the next tile's halo: for all
+// three ratios they begin exactly at DMA instruction 32 (TILE_OUT / RPI), so instructions 0..31 are nt and the rest
+// stay plain loads whose lines are still in the XCD's L2 when the neighbouring workgroup asks for them.
+template <int D, int ABL = 0, bool S32IN = false, bool NTLD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 decim_dense_kernel(const DecimMultiArgs a)
 {
@@ -163,8 +167,11 @@ decim_dense_kernel(const DecimMultiArgs a)
                 asm volatile("" : "+s"(bi));          // ... and the instruction's own base stays a scalar
                 const int i = ww + 4 * i0;
                 // the image's last instruction is only partly inside it
-                if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES))
-                    glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
+                if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES)) {
+                    static_assert(C::TILE_OUT / C::RPI == 32, "the halo rows start at DMA instruction 32");
+                    if (NTLD && i0 < 8) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));   // i = ww + 4 i0 < 32
+                    else glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
+                }
             }
         } else {
             // edge tiles (first / last of a call): through registers, sample by sample

@@ -132,9 +132,13 @@ __device__ __forceinline__ void stage_edge_chunk(const DecimTileCtx<NT> &c, long
 // HBM -> LDS for one tile, no VGPR round trip.  Slot q = 64*i + lane of the
 // buffer holds logical chunk q - (q+1)/17 (a pad slot re-loads its left
 // neighbour and is never read).
-template <int NT, int AUX = 0>
+// AUX: cache policy bits of every DMA (profiling modes), or -1 (the default, round 4): instructions 0..7 are
+// non-temporal loads and the last two -- the tile's last kilobyte, which the next tile reads again as its halo --
+// stay plain loads, so that the re-read finds them in the XCD's L2 (tools/membench5.hip).
+template <int NT, int AUX = -1>
 __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, f32x4 *buf)
 {
+    static_assert(DecimTile4<NT>::NLOAD == 10, "the halo of the next tile lies in DMA instructions 8 and 9");
     using C = DecimTile4<NT>;
     const long long c0 = ((long long)tile * C::TILE_IN - C::HALO) >> 1;   // first chunk staged (may be < 0)
     const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= c.last_chunk - c.n_odd);
@@ -146,7 +150,9 @@ __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, 
             // works per basic block), which is what selects the SGPR-base + 32-bit VGPR offset form
             unsigned b = c.boff[i];
             asm volatile("" : "+v"(b));
-            glds16<AUX>(src + b, buf + 64 * i);
+            if constexpr (AUX >= 0) glds16<AUX>(src + b, buf + 64 * i);
+            else if (i < 8) glds16<2>(src + b, buf + 64 * i);
+            else glds16<0>(src + b, buf + 64 * i);
         }
     } else {
 #pragma unroll

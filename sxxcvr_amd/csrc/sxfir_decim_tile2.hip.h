@@ -54,9 +54,10 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // issue order of the 16 packed FMAs of a step (same chains, same bits): XGROUP = the four FMAs that share a
        // sample pair back to back (P1's four, then P0's four), XSTREAM = all eight of a window chunk back to back
        T2_XGROUP = 1024, T2_XSTREAM = 2048,
-       // what the production library launches for 128 symmetric taps: scalar taps, and the FMAs that share a sample
-       // pair issued back to back (round 3: 1.3 % less time at the power cap than alternating the two sample streams,
-       // profiles/round3j_kbench_fma_order.txt; the x operand of four consecutive FMAs does not toggle)
+       // what the production library launches for 128 symmetric taps (T2_SHIPPED, below): scalar taps, the FMAs that
+       // share a sample pair issued back to back (round 3: 1.3 % less time at the power cap than alternating the two
+       // sample streams, profiles/round3j_kbench_fma_order.txt; the x operand of four consecutive FMAs does not
+       // toggle) and, since round 4, non-temporal staging loads for everything but the next tile's halo (NTLD8)
        // software-pipelined window reads (fir_tile_sym_pipe): the chunks of step T + PF are requested before the FMAs of
        // step T, PF = 2 (PIPE2), 3 (PIPE3 = both bits) or 4 (PIPE4); x-grouped issue order
        T2_PIPE2 = 4096, T2_PIPE4 = 8192,
@@ -69,7 +70,11 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // a tile (DMAs 8 and 9) is the next tile's halo and stays a plain load, so that it is still in the XCD's L2
        // when the neighbouring wave asks for it
        T2_NTLD = 32768, T2_NTLD8 = 65536,
-       T2_SHIPPED = T2_SCALAR | T2_XGROUP };
+       // XGROUP with the FMAs as volatile asm: the issue order is then the source order (the plain asm leaves the
+       // machine scheduler free to interleave the quads: 60 % of adjacent FMAs share their sample pair in the
+       // round-3 code object, 75 % when pinned)
+       T2_PINNED = 131072,
+       T2_SHIPPED = T2_SCALAR | T2_XGROUP | T2_NTLD8 };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -227,7 +232,10 @@ __device__ __forceinline__ void fir_sym_quad(const f32x2 &x, const f32x2 (&hs)[3
     }
 }
 
-template <bool S32IN, int T, int ORDER = 0>
+template <int WHICH, int S, int T>
+__device__ __forceinline__ void fir_sym_quad_v(const f32x2 &x, const f32x2 (&hs)[32], f32x2 (&acc)[4]);
+
+template <bool S32IN, int T, int ORDER = 0, bool PINNED = false>
 __device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], f32x2 (&a1)[4],
                                              f32x2 (&a0)[4])
 {
@@ -243,7 +251,12 @@ __device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, c
     if constexpr (ORDER != 0) {
         const f32x2 x1l = __builtin_shufflevector(v1, v1, 0, 1), x1h = __builtin_shufflevector(v1, v1, 2, 3);
         const f32x2 x0l = __builtin_shufflevector(v0, v0, 0, 1), x0h = __builtin_shufflevector(v0, v0, 2, 3);
-        if constexpr (ORDER == 1) {
+        if constexpr (ORDER == 1 && PINNED) {
+            fir_sym_quad_v<1, 0, T>(x1l, hs, a1);
+            fir_sym_quad_v<0, 0, T>(x0l, hs, a0);
+            fir_sym_quad_v<1, 1, T>(x1h, hs, a1);
+            fir_sym_quad_v<0, 1, T>(x0h, hs, a0);
+        } else if constexpr (ORDER == 1) {
             fir_sym_quad<1, 0, T>(x1l, hs, a1);
             fir_sym_quad<0, 0, T>(x0l, hs, a0);
             fir_sym_quad<1, 1, T>(x1h, hs, a1);
@@ -275,21 +288,21 @@ __device__ __forceinline__ void fir_sym_step(const f32x4 *w1, const f32x4 *w2, c
     }
 }
 
-template <bool S32IN, int ORDER, int... Ts>
+template <bool S32IN, int ORDER, bool PINNED, int... Ts>
 __device__ __forceinline__ void fir_sym_steps(std::integer_sequence<int, Ts...>, const f32x4 *w1, const f32x4 *w2,
                                               const f32x2 (&hs)[32], f32x2 (&a1)[4], f32x2 (&a0)[4])
 {
-    (fir_sym_step<S32IN, Ts, ORDER>(w1, w2, hs, a1, a0), ...);
+    (fir_sym_step<S32IN, Ts, ORDER, PINNED>(w1, w2, hs, a1, a0), ...);
 }
 
-template <bool S32IN, int ORDER = 0>
+template <bool S32IN, int ORDER = 0, bool PINNED = false>
 __device__ __forceinline__ void fir_tile_sym(const f32x4 *w1, const f32x4 *w2, const f32x2 (&hs)[32], float (&oi)[4],
                                              float (&oq)[4])
 {
     f32x2 a1[4], a0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a1[i] = (f32x2){0.0f, 0.0f}; a0[i] = (f32x2){0.0f, 0.0f}; }
-    fir_sym_steps<S32IN, ORDER>(std::make_integer_sequence<int, 39>{}, w1, w2, hs, a1, a0);
+    fir_sym_steps<S32IN, ORDER, PINNED>(std::make_integer_sequence<int, 39>{}, w1, w2, hs, a1, a0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         oi[i] = __fadd_rn(a0[i].x, a1[i].x);
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             constexpr int PF = ((OPT & T2_PIPE2) ? 2 : 0) + ((OPT & T2_PIPE4) ? ((OPT & T2_PIPE2) ? 1 : 4) : 0);   // 0, 2, 3, 4
             if constexpr (SCALAR && (OPT & T2_TAPMAJOR) != 0) fir_tile_sym_tapmajor<S32IN>(buf + woff, buf + woff2, hs, oi, oq);
             else if constexpr (SCALAR && PF > 0) fir_tile_sym_pipe<S32IN, PF>(buf + woff, buf + woff2, hs, oi, oq);
-            else if constexpr (SCALAR) fir_tile_sym<S32IN, (OPT & T2_XGROUP) ? 1 : ((OPT & T2_XSTREAM) ? 2 : 0)>(buf + woff, buf + woff2, hs, oi, oq);
+            else if constexpr (SCALAR) fir_tile_sym<S32IN, (OPT & T2_XGROUP) ? 1 : ((OPT & T2_XSTREAM) ? 2 : 0), (OPT & T2_PINNED) != 0>(buf + woff, buf + woff2, hs, oi, oq);
             else fir_tile_pk<NT, S32IN>(buf + woff, hp, oi, oq);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }

@@ -145,6 +145,19 @@ def test_bench_two_ranks_over_rccl():
     assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
 
 
+def test_bench_two_ranks_gather_through_the_c_abi():
+    """--gather capi: the exchange step through sxfir_comm_gather (librccl directly), serial and in steady state."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    line = run_bench(["--gpus", "2", "--gather", "capi"] + SMALL)
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    g = line["gather"]
+    assert "error" not in g, g
+    assert g["via"].startswith("C ABI") and g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
+    assert g["overlapped"]["root_holds_own_channels"] is True and g["overlapped_value"] > 0
+
+
 def test_bench_refuses_mismatched_world():
     e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True,

@@ -25,6 +25,9 @@
 #   hostvis[:iters[,filter]]  tools/hostvis_probe.hip: kernel stores into host memory, every word checked after the wait
 #   gatherc[:log2n]     tools/gather_c.c: the C-ABI gather (sxfir_comm_*) on one rank, both forms
 #   kb4w                /4 kernel: 8 against 16 waves per CU (LDS padding), nt loads, whole kernel and memory side, random and all-zero input
+#   valu                tools/valu_power_probe.hip: the FIR's arithmetic alone by operand source and LDS read count
+#   kb4x                /4 kernel: tiles per wave x nt loads x taps by value x deferred stores x 12 waves per CU x pinned FMA order
+#   kbdnt               dense /32, /8, /16 kernels with non-temporal staging loads against the shipped ones (whole kernel, memory side)
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
@@ -77,6 +80,13 @@ for S in "$@"; do
     kb4w)     # waves per CU capped through LDS padding (8 per CU, 32 generations) against 16 per CU, with and without nt loads; whole kernel and memory side; then the same on an all-zero input
               V="t2.1.1088:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.1088:32:0:0:0:10600 t2.1.66624:32:0:0:0:10600 t2.1.66624:64:0:0:0:10600 t2.1.1088:16:0:1:0:0 t2.1.66624:16:0:1:0:0 t2.1.1088:32:0:1:0:10600 t2.1.66624:32:0:1:0:10600 t2.1.66624:64:0:1:0:0"
               KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    valu)     hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe >> $LOG 2>&1; RC=$?; tail -10 $LOG ;;
+    kb4x)     # one tile per wave (64 generations) with nt loads, taps by value, deferred stores, 12 waves per CU, pinned FMA order: whole kernel, then memory sides, then all-zero input
+              V="x:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.66624:32:0:0:0:0 t2.1.66624:64:0:0:0:0 t2.1.67136:64:0:0:0:0 t2.1.67136:16:0:0:0:0 t2.1.66625:16:0:0:0:0 t2.1.66624:21:0:0:0:3840 t2.1.132160:16:0:0:0:0 t2.1.197696:16:0:0:0:0"
+              KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
+              KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py t2.1.66624:32:0:1:0:0 t2.1.67136:64:0:1:0:0 t2.1.66625:16:0:1:0:0 t2.1.66624:21:0:1:0:3840 >> $LOG 2>&1
+              KB_ZERO=1 KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    kbdnt)    for D in 32 8 16; do KB_D=$D KB_ROUNDS=7 timeout 600 python3 tools/kbench.py dense:8:0:0:0 densent:8:0:0:0 dense:8:0:1:0 densent:8:0:1:0 >> $LOG 2>&1; done; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped\|checksum" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;
