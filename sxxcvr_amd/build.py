@@ -41,7 +41,7 @@ def _deps(*dirs):
     out = []
     for d in dirs:
         for base, _, files in os.walk(d):
-            out += [os.path.join(base, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
+            out += [os.path.join(base, f) for f in files if f.endswith((".hip", ".h", ".hpp", ".cpp", ".inc"))]
     return out
 
 

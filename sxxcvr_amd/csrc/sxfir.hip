@@ -43,7 +43,8 @@
     X(1, 16) X(1, 17) X(1, 19) X(2, 17) X(2, 19) X(1, 32) X(1, 33) X(2, 35) X(1, 49) X(2, 51) \
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
     X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376) X(1, 16448) \
-    X(1, 33856) X(1, 66624) X(1, 33872) X(1, 66625) X(1, 67136) X(1, 132160) X(1, 197696)
+    X(1, 33856) X(1, 66624) X(1, 33872) X(1, 66625) X(1, 67136) X(1, 132160) X(1, 197696) \
+    X(16, 66752) X(8, 66752) X(4, 66752) X(16, 1216)
 // variants that also exist with phase stamps (ABL 5)
 #define SXFIR_TILE2_STAMPED(X) X(1, 33856) X(1, 66624) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
@@ -98,7 +99,8 @@ struct sxfir_plan {
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
-    bool dense_nt;         // decim_dense_kernel with non-temporal staging loads (profiling build: SXFIR_DENSE_NT)
+    bool dense_nt;         // profiling build, SXFIR_DENSE_NT = 1 / 0: decim_dense_kernel with nt / plain staging loads at every ratio
+    int dense_nt_set;      // ... and whether the knob was given at all
     bool dense32;          // decim_dense_kernel (ratio 8 / 16 / 32, 32 taps per phase, CF32 / S32): the linear-image form
     int multi_waves;       // waves per workgroup of the multi kernel
     int multi_ps;          // lanes that share the 32 tap rows of one output (2 or 4) in the multi kernel
@@ -263,6 +265,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && fmt != SXFIR_CF16;
     p->t2_wpg = p->t2_opt = 0;
     p->dense_nt = false;
+    p->dense_nt_set = 0;
     p->lds_pad = 0;
     p->pair = false;
     p->pair_xsep = false;
@@ -286,7 +289,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
     }
     if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
-    if (const char *v = getenv("SXFIR_DENSE_NT")) p->dense_nt = atoi(v) != 0;
+    if (const char *v = getenv("SXFIR_DENSE_NT")) { p->dense_nt = atoi(v) != 0; p->dense_nt_set = 1; }
     if (getenv("SXFIR_MULTI_PS") || getenv("SXFIR_MULTI_W")) p->dense32 = false;   // those knobs belong to the multi-column kernel
     if (p->multi_capable && fmt != SXFIR_S32 && !p->dense32) {
         if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
@@ -308,9 +311,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const void *k = nullptr;
         if (p->dense32) {
             const bool w = fmt == SXFIR_S32;
-            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false>)
-                : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true> : (const void *)sxfir::decim_dense_kernel<16, 0, false>)
-                              : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true> : (const void *)sxfir::decim_dense_kernel<32, 0, false>);
+            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false, true>)
+                : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true, true> : (const void *)sxfir::decim_dense_kernel<16, 0, false, true>)
+                              : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true, false> : (const void *)sxfir::decim_dense_kernel<32, 0, false, false>);
 #ifdef SXFIR_PROFILING
         } else if (fmt == SXFIR_S32) {   // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
             k = ratio == 8    ? (const void *)sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>
@@ -565,6 +568,10 @@ static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t
     return SXFIR_OK;
 }
 
+#ifdef SXFIR_PROFILING
+#include "sxfir_prof_dispatch.inc"   // the A/B variants' launch tables: 0 = not mine, 1 = launched, < 0 = error
+#endif
+
 // Launch only the resampling kernel (no history update, no position change).
 static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
                         size_t out_stride, long long n_out, hipStream_t st, bool *history_done)
@@ -603,34 +610,21 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         a.stamps = nullptr;
         if (p->dense32) {
-#define SXFIR_DENSE_LAUNCH(DD, AA, SS) hipLaunchKernelGGL((sxfir::decim_dense_kernel<DD, AA, SS>), grid, dim3(256), 0, st, a)
+            // non-temporal staging loads (all but the next tile's halo) at /8 and /16, plain loads at /32: measured, round 4
+            // (profiles/round4e_kbench_dense_nt.txt: whole kernel -0.6 % and -1.6 %, /32 +1.4 %)
+#define SXFIR_DENSE_LAUNCH(DD, AA, SS, NN) hipLaunchKernelGGL((sxfir::decim_dense_kernel<DD, AA, SS, NN>), grid, dim3(256), 0, st, a)
 #define SXFIR_DENSE_BY_RATIO(AA, SS) \
     do { \
-        if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, AA, SS); \
-        else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, AA, SS); \
-        else SXFIR_DENSE_LAUNCH(32, AA, SS); \
+        if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, AA, SS, true); \
+        else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, AA, SS, true); \
+        else SXFIR_DENSE_LAUNCH(32, AA, SS, false); \
     } while (0)
 #ifdef SXFIR_PROFILING
-            if (p->ablate == 3) {
-                const size_t need = (size_t)groups * p->nchan * W;
-                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
-                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 40 * need));
-                p->stamps_n = need;
-                a.stamps = (unsigned long long *)p->stamps_dev;
+            if (const int pr = prof_launch_dense(p, a, grid, st, groups, W)) {       // ablations, stamps, nt-load A/B
+                if (pr < 0) return pr;
+                *history_done = true;
+                return SXFIR_OK;
             }
-            if (p->fmt != SXFIR_S32 && p->ablate == 0 && p->dense_nt) {
-                if (p->ratio == 8) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, true>), grid, dim3(256), 0, st, a);
-                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 0, false, true>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, true>), grid, dim3(256), 0, st, a);
-            } else if (p->fmt != SXFIR_S32 && p->ablate == 1 && p->dense_nt) {
-                if (p->ratio == 8) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 1, false, true>), grid, dim3(256), 0, st, a);
-                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 1, false, true>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 1, false, true>), grid, dim3(256), 0, st, a);
-            } else
-            if (p->fmt != SXFIR_S32 && p->ablate == 1) SXFIR_DENSE_BY_RATIO(1, false);
-            else if (p->fmt != SXFIR_S32 && p->ablate == 2) SXFIR_DENSE_BY_RATIO(2, false);
-            else if (p->fmt != SXFIR_S32 && p->ablate == 3) SXFIR_DENSE_BY_RATIO(3, false);
-            else
 #endif
             if (p->fmt == SXFIR_S32) SXFIR_DENSE_BY_RATIO(0, true);
             else SXFIR_DENSE_BY_RATIO(0, false);
@@ -641,46 +635,14 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             return SXFIR_OK;
         }
 #ifdef SXFIR_PROFILING
-        if (p->fmt == SXFIR_S32) {
-            switch (p->ratio) {
-            case 8: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
-            case 16: hipLaunchKernelGGL((sxfir::decim_multi_kernel<16, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 0, 2, true>), grid, dim3(256), 0, st, a); break;
-            }
-            HIPCHECK(hipGetLastError());
+        if (const int pr = prof_launch_multi(p, a, grid, st, groups, W)) {           // S32 words, ablations, stamps
+            if (pr < 0) return pr;
             *history_done = true;
             return SXFIR_OK;
         }
 #endif
-        int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps);
-#ifdef SXFIR_PROFILING
-        if (p->ablate == 3) {
-            const size_t need = (size_t)groups * p->nchan * W;
-            if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
-            if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 40 * need));
-            p->stamps_n = need;
-            a.stamps = (unsigned long long *)p->stamps_dev;
-        }
-        key += 100000 * p->ablate;
-#endif
+        const int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps);
         switch (key) {
-#ifdef SXFIR_PROFILING
-        case 100801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 1>), grid, dim3(64), 0, st, a); break;
-        case 200801: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 1, false, 2>), grid, dim3(64), 0, st, a); break;
-        case 100804: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 1>), grid, dim3(256), 0, st, a); break;
-        case 200804: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 2>), grid, dim3(256), 0, st, a); break;
-        case 300804: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 4, false, 3>), grid, dim3(256), 0, st, a); break;
-        case 103204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 1>), grid, dim3(256), 0, st, a); break;
-        case 203204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 2>), grid, dim3(256), 0, st, a); break;
-        case 403204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 4>), grid, dim3(256), 0, st, a); break;
-        case 503204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 5>), grid, dim3(256), 0, st, a); break;
-        case 303204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, false, 3>), grid, dim3(256), 0, st, a); break;
-        case 303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3>), grid, dim3(512), 0, st, a); break;
-        case 313204: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 4, true, 3>), grid, dim3(256), 0, st, a); break;
-        case 313208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, true, 3>), grid, dim3(512), 0, st, a); break;
-        case 1303208: hipLaunchKernelGGL((sxfir::decim_multi_kernel<32, 8, false, 3, 4>), grid, dim3(512), 0, st, a); break;
-        case 300802: hipLaunchKernelGGL((sxfir::decim_multi_kernel<8, 2, false, 3>), grid, dim3(128), 0, st, a); break;
-#endif
 #define SXFIR_X(DD, WW, HH, PP) \
         case SXFIR_MULTI_KEY(DD, WW, HH, PP): \
             hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>), grid, dim3(64 * WW), 0, st, a); \
@@ -723,96 +685,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.sched = p->sched;
         a.stamps = nullptr;
 #ifdef SXFIR_PROFILING
-        if ((p->pair || p->wide) && p->ntaps == 128) {
-            // decim4_pair_kernel / decim4_wide_kernel: tiles of 512 outputs, one workgroup (2 waves / 1 wave) each,
-            // strided XCD-blocked passes
-            const long long n_tiles2 = (n_out + 511) / 512;
-            long long G = ((long long)p->compute_units * (p->wide ? p->occ_wide : p->occ_pair) * p->oversub) / p->nchan;
-            if (G < 1) G = 1;
-            if (G > n_tiles2) G = n_tiles2;
-            a.n_tiles = (int)n_tiles2;
-            a.n_waves = (int)G;
-            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
-            a.run_base = a.run_extra = 0;
-            {
-                const int t = (int)((n_tiles2 - 1) % G);
-                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
-            }
-            dim3 grid((unsigned)G, (unsigned)p->nchan);
-            const int abl = p->ablate;
-            if (abl == 5) {
-                const size_t need = (size_t)G * p->nchan * (p->wide ? 1 : 2);
-                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
-                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
-                p->stamps_n = need;
-                a.stamps = (unsigned long long *)p->stamps_dev;
-            }
-            if (p->wide) {
-                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
-                else if (abl == 0 && p->wide_nb == 2) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 2>), grid, dim3(64), 0, st, a);
-                else if (abl == 0 && p->wide_nb == 4) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 4>), grid, dim3(64), 0, st, a);
-                else if (abl == 0 && p->wide_nb == 12) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 12>), grid, dim3(64), 0, st, a);
-                else if (abl == 0 && p->wide_nb == 16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 16>), grid, dim3(64), 0, st, a);
-                else if (abl == 1) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<1, false>), grid, dim3(64), 0, st, a);
-                else if (abl == 5) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<5, false>), grid, dim3(64), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
-            }
-            else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, true>), grid, dim3(128), 0, st, a);
-            else if (p->pair_xsep && abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false, true>), grid, dim3(128), 0, st, a);
-            else if (p->pair_xsep) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false, true>), grid, dim3(128), 0, st, a);
-            else if (abl == 1) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<1, false>), grid, dim3(128), 0, st, a);
-            else if (abl == 5) hipLaunchKernelGGL((sxfir::decim4_pair_kernel<5, false>), grid, dim3(128), 0, st, a);
-            else hipLaunchKernelGGL((sxfir::decim4_pair_kernel<0, false>), grid, dim3(128), 0, st, a);
-            HIPCHECK(hipGetLastError());
-            return SXFIR_OK;
-        }
-        if (p->t2_wpg) {
-            // decim4_tile2_kernel: G workgroups of t2_wpg waves per channel, wave ww of workgroup b takes tiles
-            // (S(b) + i*G)*wpg + ww
-            const int wpg = p->t2_wpg;
-            const long long n_super = (n_tiles + wpg - 1) / wpg;
-            long long G = ((long long)p->compute_units * p->occ_sb * p->oversub / wpg) / p->nchan;
-            if (G < 1) G = 1;
-            if (G > n_super) G = n_super;
-            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
-            a.run_base = a.run_extra = 0;
-            if (p->t2_opt & sxfir::T2_HCARRY) {
-                // contiguous runs of K tiles per wave, waves numbered in dispatch order
-                const long long K = (n_tiles + G * wpg - 1) / (G * wpg);
-                G = ((n_tiles + K - 1) / K + wpg - 1) / wpg;          // workgroups that have a tile
-                a.run_base = (int)K;
-                a.hist_wave = (int)((n_tiles - 1) / K);
-            } else {
-                const long long last = n_tiles - 1, sup = last / wpg;
-                const int t = (int)(sup % G);
-                const int bb = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
-                a.hist_wave = bb * wpg + (int)(last % wpg);
-            }
-            const unsigned grid_y = (unsigned)p->nchan;
-            a.n_waves = (int)G;
-            dim3 grid((unsigned)G, grid_y);
-            if (p->ablate == 5) {
-                const size_t need = (size_t)G * grid_y * wpg;
-                if (p->stamps_dev && p->stamps_n < need) { (void)hipFree(p->stamps_dev); p->stamps_dev = nullptr; }
-                if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 64 * need));
-                p->stamps_n = need;
-                a.stamps = (unsigned long long *)p->stamps_dev;
-            }
-            switch ((wpg * 100 + p->t2_opt) * 10 + (p->ablate == 1 || p->ablate == 2 || p->ablate == 5 ? p->ablate : 0)) {
-#define SXFIR_X(WW, OO) \
-            case (WW * 100 + OO) * 10: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO>), grid, dim3(64 * WW), p->lds_pad, st, a); break; \
-            case (WW * 100 + OO) * 10 + 1: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 1>), grid, dim3(64 * WW), p->lds_pad, st, a); break;
-                SXFIR_TILE2_VARIANTS(SXFIR_X)
-#undef SXFIR_X
-#define SXFIR_X(WW, OO) \
-            case (WW * 100 + OO) * 10 + 5: hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, WW, OO, 5>), grid, dim3(64 * WW), p->lds_pad, st, a); break;
-                SXFIR_TILE2_STAMPED(SXFIR_X)
-#undef SXFIR_X
-            default: return fail(SXFIR_EUNSUPPORTED, "no tile2 variant %d:%d ablate %d", wpg, p->t2_opt, p->ablate);
-            }
-            HIPCHECK(hipGetLastError());
-            return SXFIR_OK;
-        }
+        if (const int pr = prof_launch_tile_variant(p, a, n_out, n_tiles, st)) return pr < 0 ? pr : SXFIR_OK;   // pair / wide / tile2 variants
 #endif
         // Short-lived waves in generations: W = CUs * resident waves * oversub waves per launch, each covering
         // n_tiles / W tiles in strided, XCD-blocked passes (sxfir_decim_tile.hip.h).
@@ -834,57 +707,11 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             }
         }
 #ifdef SXFIR_PROFILING
-        if (p->sched == 3 && p->ntaps == 128 && p->symmetric) {
-            // short tail: the last generation of long waves (one CU-filling set) is replaced by as many one-tile
-            // waves as it had tiles
-            const long long W = per_chan, passes = n_tiles / W;
-            const long long resident = (long long)p->compute_units * p->occ_sb / p->nchan;
-            if (passes >= 2 && n_tiles % W == 0 && W > resident && resident % 8 == 0) {
-                const long long glong = W - resident, gshort = resident * passes;
-                a.long_waves = (int)glong;
-                a.long_tiles = (int)(glong * passes);
-                a.long_w8 = (glong % 8 == 0) ? (int)(glong / 8) : 0;
-                a.short_w8 = (gshort % 8 == 0) ? (int)(gshort / 8) : 0;
-                per_chan = glong + gshort;
-                a.n_waves = (int)per_chan;
-                const int t = (int)(gshort - 1);                       // the last tile's place among the short waves
-                a.hist_wave = (int)glong + (a.short_w8 ? (t % a.short_w8) * 8 + t / a.short_w8 : t);
-            }
-        }
+        prof_short_tail(p, a, n_tiles, &per_chan);                                    // SXFIR_SCHED=3
 #endif
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
 #ifdef SXFIR_PROFILING
-        if (p->ablate == 11 || p->ablate == 12) {
-            // diagnostic build: one {cycles, ticks} pair per wave, printed by sxfir_debug_clock()
-            if (!p->stamps_dev) HIPCHECK(hipMalloc(&p->stamps_dev, 16 * (size_t)per_chan * p->nchan));
-            p->stamps_n = (size_t)per_chan * p->nchan;
-            a.stamps = (unsigned long long *)p->stamps_dev;
-        }
-        if (p->fmt == SXFIR_CF32 && p->ntaps == 128 && (p->sgpr_r || p->ablate != 0 || dbuf)) {
-            if (p->sgpr_r == 8) {
-                hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<8>), grid, dim3(64), 0, st, a);
-            } else if (p->sgpr_r == 4) {
-                hipLaunchKernelGGL((sxfir::decim4_sgpr_kernel<4>), grid, dim3(64), 0, st, a);
-            } else if (p->ablate != 0) {
-                // profiling builds of the same kernel (SXFIR_ABLATE, sxfir_decim_tile.hip.h): wrong results
-                switch (p->ablate) {
-#define SXFIR_X(N) \
-                case N: hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, N>), grid, dim3(64), 0, st, a); break;
-                    SXFIR_TILE_ABLATIONS(SXFIR_X)
-#undef SXFIR_X
-                default: return fail(SXFIR_EINVAL, "SXFIR_ABLATE=%d is not a profiling mode of the tile kernel", p->ablate);
-                }
-            } else {
-                hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, true>), grid, dim3(64), 0, st, a);
-            }
-            HIPCHECK(hipGetLastError());
-            return SXFIR_OK;
-        }
-        if (p->fmt == SXFIR_CF32 && p->ntaps == 64 && dbuf) {
-            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, true>), grid, dim3(64), 0, st, a);
-            HIPCHECK(hipGetLastError());
-            return SXFIR_OK;
-        }
+        if (const int pr = prof_launch_tile_first_gen(p, a, grid, per_chan, dbuf, st)) return pr < 0 ? pr : SXFIR_OK;
 #endif
         // (with one wave per workgroup both kernels take the same schedule constants)
         if (p->ntaps == 128 && p->symmetric && p->sched != 1) {

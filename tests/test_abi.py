@@ -107,3 +107,30 @@ def test_build_entry_point_runs():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for name in ("libsxfir.so", "libSXSupport.so"):
         assert os.path.exists(os.path.join(ROOT, "sxxcvr_amd", "lib", name))
+
+
+def test_shipped_code_object():
+    """The gfx950 code object inside libsxfir.so (tools/shipped_isa.py: metadata notes + disassembly): no scratch and no
+    MFMA anywhere (north star: a short 1-D convolution, not a contraction), the /4 scalar-tap kernel has its 512 packed
+    FMAs with scalar tap operands, non-temporal staging loads, no barrier, four waves per SIMD -- and the x-grouped issue
+    order has not been lost to the machine scheduler of a new compiler (the FMAs are plain asm, only their dependency
+    chains are ordered: >= 0.55 of adjacent FMAs share their sample pair, 0.75 is the order as written, an alternating
+    order gives ~0)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import shipped_isa
+    rows = shipped_isa.kernels()
+    assert len(rows) >= 30
+    for r in rows:
+        assert r["scratch_bytes"] == 0, r["name"]
+        assert r["v_mfma"] == 0, r["name"]
+    t2 = [r for r in rows if r["name"].startswith("decim4_tile2_kernel<128, 1,") and r["name"].endswith("false>")]
+    assert len(t2) == 1, [r["name"] for r in rows]
+    t2 = t2[0]
+    assert t2["v_pk_fma_f32"] == 512 and t2["scalar_tap_fmas"] == 512 and t2["s_barrier"] == 0
+    assert t2["vgpr"] <= 128 and t2["lds_bytes"] == 9792                 # 4 waves per SIMD, 16 images per CU
+    assert 0 < t2["global_load_lds_dwordx4_nt"] < t2["global_load_lds_dwordx4"]   # nt for all but the next tile's halo
+    assert t2["adjacent_fmas_sharing_sample_pair"] >= 0.55, t2
+    for r in rows:
+        if r["name"].startswith("decim_dense_kernel"):
+            assert r["lds_bytes"] <= 40960 and r["vgpr"] <= 128 and r["v_pk_fma_f32"] == 512, r    # four workgroups per CU

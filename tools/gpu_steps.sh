@@ -28,6 +28,7 @@
 #   valu                tools/valu_power_probe.hip: the FIR's arithmetic alone by operand source and LDS read count
 #   kb4x                /4 kernel: tiles per wave x nt loads x taps by value x deferred stores x 12 waves per CU x pinned FMA order
 #   kbdnt               dense /32, /8, /16 kernels with non-temporal staging loads against the shipped ones (whole kernel, memory side)
+#   kb4q                /4 kernel: persistent workgroups with an LDS tile queue + nt loads against generations of short waves
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
@@ -87,6 +88,10 @@ for S in "$@"; do
               KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py t2.1.66624:32:0:1:0:0 t2.1.67136:64:0:1:0:0 t2.1.66625:16:0:1:0:0 t2.1.66624:21:0:1:0:3840 >> $LOG 2>&1
               KB_ZERO=1 KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
     kbdnt)    for D in 32 8 16; do KB_D=$D KB_ROUNDS=7 timeout 600 python3 tools/kbench.py dense:8:0:0:0 densent:8:0:0:0 dense:8:0:1:0 densent:8:0:1:0 >> $LOG 2>&1; done; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped\|checksum" ;;
+    kb4q)     # one persistent 16-wave workgroup per CU taking tiles from an LDS queue (one prologue per wave) with nt loads, against the shipped generations
+              V="x:16:0:0:0:0 t2.16.66752:1:0:0:0:0 t2.16.1216:1:0:0:0:0 t2.8.66752:1:0:0:0:0 t2.4.66752:1:0:0:0:0 t2.16.66752:2:0:0:0:0 t2.1.66624:16:0:0:0:0"
+              KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
+              KB_ZERO=1 KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

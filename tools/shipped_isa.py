@@ -1,0 +1,86 @@
+"""What actually ships: the gfx950 code object inside sxxcvr_amd/lib/libsxfir.so, per kernel (CPU only).
+
+    python3 tools/shipped_isa.py [substring of the kernel name] [--json]
+
+Registers / LDS / scratch come from the code object's metadata notes, instruction counts from its disassembly:
+v_pk_fma_f32, ds_read_b128, global_load_lds_dwordx4 (and how many of those carry `nt`), s_barrier, v_mfma, DPP and
+permlane ops.  For the /4 scalar-tap kernel also the issue order of its packed FMAs: the share of adjacent FMAs
+that use the same sample pair (source operand 1) -- 0.75 when every four FMAs of a sample pair are back to back
+(T2_XGROUP as written), 0.0 when the two sample streams alternate.  DESIGN.md quotes this table;
+tests/test_abi.py::test_shipped_code_object checks its invariants (no scratch, no MFMA, nt loads present, FMA
+grouping not lost to a compiler update).
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def extract(lib):
+    d = tempfile.mkdtemp(prefix="sxisa_")
+    fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    return co
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    return dict(zip(names, out))
+
+
+def kernels(lib=None):
+    lib = lib or os.path.join(ROOT, "sxxcvr_amd", "lib", "libsxfir.so")
+    co = extract(lib)
+    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+    meta = {}
+    for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name:
+            continue
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        meta[name.group(1)] = {"vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"), "lds_bytes": g("group_segment_fixed_size"),
+                               "scratch_bytes": g("private_segment_fixed_size")}
+    asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True).stdout
+    pretty = demangle(list(meta))
+    rows = []
+    for m in re.finditer(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^\n|\Z)", asm, re.S | re.M):
+        sym, body = m.group(1), m.group(2)
+        if sym not in meta:
+            continue
+        ops = re.findall(r"^\s+(\S+)", body, re.M)
+        cnt = lambda pat: sum(1 for o in ops if re.match(pat, o))
+        r = dict(meta[sym])
+        r["name"] = re.sub(r"\(.*\)$", "", pretty[sym]).replace("void sxfir::", "")
+        r.update({"v_pk_fma_f32": cnt(r"v_pk_fma_f32$"), "ds_read_b128": cnt(r"ds_read_b128$"),
+                  "global_load_lds_dwordx4": cnt(r"global_load_lds_dwordx4$"),
+                  "global_load_lds_dwordx4_nt": len(re.findall(r"global_load_lds_dwordx4[^\n]*\bnt\b", body)),
+                  "s_barrier": cnt(r"s_barrier$"), "v_mfma": cnt(r"v_mfma"), "dpp_or_permlane": len(re.findall(r"_dpp|v_permlane", body)),
+                  "s_load_dwordx16": cnt(r"s_load_dwordx16$")})
+        fm = re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], (s\[\d+:\d+\]), (v\[\d+:\d+\])", body)
+        if len(fm) > 1:
+            r["scalar_tap_fmas"] = len(fm)
+            r["adjacent_fmas_sharing_sample_pair"] = round(sum(1 for a, b in zip(fm, fm[1:]) if a[1] == b[1]) / (len(fm) - 1), 3)
+        rows.append(r)
+    return rows
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    flt = args[0] if args else ""
+    rows = [r for r in kernels() if flt in r["name"]]
+    if "--json" in sys.argv:
+        print(json.dumps(rows, indent=1))
+    else:
+        print("%-5s %-5s %-6s %-7s %-6s %-5s %-8s %-5s %-5s %-6s kernel" % ("VGPR", "SGPR", "LDS", "scratch", "pkfma", "ds128", "dma(nt)", "barr", "mfma", "xshare"))
+        for r in sorted(rows, key=lambda r: r["name"]):
+            print("%-5d %-5d %-6d %-7d %-6d %-5d %-8s %-5d %-5d %-6s %s" % (
+                r["vgpr"], r["sgpr"], r["lds_bytes"], r["scratch_bytes"], r["v_pk_fma_f32"], r["ds_read_b128"],
+                "%d(%d)" % (r["global_load_lds_dwordx4"], r["global_load_lds_dwordx4_nt"]), r["s_barrier"], r["v_mfma"],
+                r.get("adjacent_fmas_sharing_sample_pair", "-"), r["name"]))
