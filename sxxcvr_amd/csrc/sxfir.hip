@@ -44,9 +44,9 @@
     X(1, 64) X(1, 65) X(1, 68) X(1, 69) X(1, 80) X(1, 81) X(2, 64) X(2, 65) X(4, 65) \
     X(16, 192) X(16, 193) X(16, 128) X(8, 192) X(4, 192) X(16, 224) X(1, 320) X(1, 576) X(1, 1088) X(1, 2112) X(1, 5184) X(1, 9280) X(1, 13376) X(1, 16448) \
     X(1, 33856) X(1, 66624) X(1, 33872) X(1, 66625) X(1, 67136) X(1, 132160) X(1, 197696) \
-    X(16, 66752) X(8, 66752) X(4, 66752) X(16, 1216)
+    X(16, 66752) X(8, 66752) X(4, 66752) X(16, 1216) X(1, 263232) X(1, 525376)
 // variants that also exist with phase stamps (ABL 5)
-#define SXFIR_TILE2_STAMPED(X) X(1, 33856) X(1, 66624) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
+#define SXFIR_TILE2_STAMPED(X) X(1, 33856) X(1, 66624) X(1, 525376) X(1, 9280) X(1, 5184) X(1, 1088) X(1, 0) X(1, 1) X(2, 3) X(1, 17) X(1, 5) X(1, 64) X(1, 65) X(1, 69) X(16, 192) X(16, 128)
 #else
 #define SXFIR_MULTI_VARIANTS(X) SXFIR_MULTI_SHIPPED(X)
 #endif
@@ -99,7 +99,7 @@ struct sxfir_plan {
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
-    bool dense_nt;         // profiling build, SXFIR_DENSE_NT = 1 / 0: decim_dense_kernel with nt / plain staging loads at every ratio
+    int dense_nt;          // profiling build, SXFIR_DENSE_NT = 1 / 0: decim_dense_kernel with nt / plain staging loads at every ratio
     int dense_nt_set;      // ... and whether the knob was given at all
     bool dense32;          // decim_dense_kernel (ratio 8 / 16 / 32, 32 taps per phase, CF32 / S32): the linear-image form
     int multi_waves;       // waves per workgroup of the multi kernel
@@ -264,7 +264,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the multi-column kernel
     p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && fmt != SXFIR_CF16;
     p->t2_wpg = p->t2_opt = 0;
-    p->dense_nt = false;
+    p->dense_nt = 0;
     p->dense_nt_set = 0;
     p->lds_pad = 0;
     p->pair = false;
@@ -289,7 +289,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
     }
     if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
-    if (const char *v = getenv("SXFIR_DENSE_NT")) { p->dense_nt = atoi(v) != 0; p->dense_nt_set = 1; }
+    if (const char *v = getenv("SXFIR_DENSE_NT")) { p->dense_nt = atoi(v); p->dense_nt_set = 1; }
     if (getenv("SXFIR_MULTI_PS") || getenv("SXFIR_MULTI_W")) p->dense32 = false;   // those knobs belong to the multi-column kernel
     if (p->multi_capable && fmt != SXFIR_S32 && !p->dense32) {
         if (const char *v = getenv("SXFIR_MULTI_PS")) p->multi_ps = atoi(v) == 4 ? 4 : 2;
@@ -311,9 +311,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const void *k = nullptr;
         if (p->dense32) {
             const bool w = fmt == SXFIR_S32;
-            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false, true>)
-                : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true, true> : (const void *)sxfir::decim_dense_kernel<16, 0, false, true>)
-                              : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true, false> : (const void *)sxfir::decim_dense_kernel<32, 0, false, false>);
+            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, 2> : (const void *)sxfir::decim_dense_kernel<8, 0, false, 2>)
+                : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true, 2> : (const void *)sxfir::decim_dense_kernel<16, 0, false, 2>)
+                              : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true, 2> : (const void *)sxfir::decim_dense_kernel<32, 0, false, 2>);
 #ifdef SXFIR_PROFILING
         } else if (fmt == SXFIR_S32) {   // wire-word input: one instantiation per ratio (4 waves, 2-way row split)
             k = ratio == 8    ? (const void *)sxfir::decim_multi_kernel<8, 4, false, 0, 2, true>
@@ -610,14 +610,15 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         a.stamps = nullptr;
         if (p->dense32) {
-            // non-temporal staging loads (all but the next tile's halo) at /8 and /16, plain loads at /32: measured, round 4
-            // (profiles/round4e_kbench_dense_nt.txt: whole kernel -0.6 % and -1.6 %, /32 +1.4 %)
+            // non-temporal staging loads for the image rows no other tile reads (NTLD = 2: both halos stay plain loads),
+            // measured in round 4 (profiles/round4h_kbench_both_halos_plain.txt: whole kernel -0.9 % at /32, -2.8 % at /8
+            // and /16 against plain loads; with only the next tile's halo plain /32 lost 1.4 %)
 #define SXFIR_DENSE_LAUNCH(DD, AA, SS, NN) hipLaunchKernelGGL((sxfir::decim_dense_kernel<DD, AA, SS, NN>), grid, dim3(256), 0, st, a)
 #define SXFIR_DENSE_BY_RATIO(AA, SS) \
     do { \
-        if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, AA, SS, true); \
-        else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, AA, SS, true); \
-        else SXFIR_DENSE_LAUNCH(32, AA, SS, false); \
+        if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, AA, SS, 2); \
+        else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, AA, SS, 2); \
+        else SXFIR_DENSE_LAUNCH(32, AA, SS, 2); \
     } while (0)
 #ifdef SXFIR_PROFILING
             if (const int pr = prof_launch_dense(p, a, grid, st, groups, W)) {       // ablations, stamps, nt-load A/B

@@ -79,11 +79,15 @@ __device__ __forceinline__ float butterfly_add(float v)
 
 // ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
 // kernel with s_memtime stamps around its phases (a.stamps, 5 counters per wave as decim_multi_kernel)
-// NTLD: the staging DMAs of image rows that no later tile reads again are non-temporal loads (round 4: a read stream
+// NTLD: the staging DMAs of image rows that no other tile reads are non-temporal loads (round 4: a read stream
 // runs 4.6 % faster with them, tools/membench5.hip).  The image's last 31 rows are the next tile's halo: for all
-// three ratios they begin exactly at DMA instruction 32 (TILE_OUT / RPI), so instructions 0..31 are nt and the rest
-// stay plain loads whose lines are still in the XCD's L2 when the neighbouring workgroup asks for them.
-template <int D, int ABL = 0, bool S32IN = false, bool NTLD = false>
+// three ratios they begin exactly at DMA instruction 32 (TILE_OUT / RPI), so instructions 32.. stay plain loads whose
+// lines are still in the XCD's L2 when the neighbouring workgroup asks for them.  NTLD = 1: instructions 0..31 nt;
+// NTLD = 2: the image's FIRST 31 rows -- the re-read of the previous tile's halo, instructions 0 .. 31 / RPI, rounded up
+// to a group of four (one per wave) -- are plain too: an nt re-read that reaches the L2 first would stream through
+// without leaving the line for the neighbour's plain load, which then fetches it again (1.04 x the algorithmic bytes
+// measured on the /4 kernel).
+template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 decim_dense_kernel(const DecimMultiArgs a)
 {
@@ -169,7 +173,8 @@ decim_dense_kernel(const DecimMultiArgs a)
                 // the image's last instruction is only partly inside it
                 if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES)) {
                     static_assert(C::TILE_OUT / C::RPI == 32, "the halo rows start at DMA instruction 32");
-                    if (NTLD && i0 < 8) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));   // i = ww + 4 i0 < 32
+                    constexpr int FIRST_NT = NTLD == 2 ? (31 / C::RPI + 4) / 4 : 0;   // i0 below this: the halo re-read, plain
+                    if (NTLD && i0 >= FIRST_NT && i0 < 8) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));   // i = ww + 4 i0 < 32
                     else glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
                 }
             }

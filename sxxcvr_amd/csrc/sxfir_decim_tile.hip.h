@@ -132,9 +132,10 @@ __device__ __forceinline__ void stage_edge_chunk(const DecimTileCtx<NT> &c, long
 // HBM -> LDS for one tile, no VGPR round trip.  Slot q = 64*i + lane of the
 // buffer holds logical chunk q - (q+1)/17 (a pad slot re-loads its left
 // neighbour and is never read).
-// AUX: cache policy bits of every DMA (profiling modes), or -1 (the default, round 4): instructions 0..7 are
-// non-temporal loads and the last two -- the tile's last kilobyte, which the next tile reads again as its halo --
-// stay plain loads, so that the re-read finds them in the XCD's L2 (tools/membench5.hip).
+// AUX: cache policy bits of every DMA (profiling modes), or -1 (the default, round 4): instructions 1..7 are
+// non-temporal loads; the last two -- the tile's last kilobyte, which the next tile reads again as its halo -- and
+// instruction 0 -- this tile's re-read of the previous one's -- stay plain loads: whichever of the two reaches the
+// XCD's L2 first allocates the line, the other hits (tools/membench5.hip).
 template <int NT, int AUX = -1>
 __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, f32x4 *buf)
 {
@@ -151,7 +152,7 @@ __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, 
             unsigned b = c.boff[i];
             asm volatile("" : "+v"(b));
             if constexpr (AUX >= 0) glds16<AUX>(src + b, buf + 64 * i);
-            else if (i < 8) glds16<2>(src + b, buf + 64 * i);
+            else if (i >= 1 && i < 8) glds16<2>(src + b, buf + 64 * i);
             else glds16<0>(src + b, buf + 64 * i);
         }
     } else {

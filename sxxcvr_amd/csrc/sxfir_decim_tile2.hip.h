@@ -57,7 +57,7 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // what the production library launches for 128 symmetric taps (T2_SHIPPED, below): scalar taps, the FMAs that
        // share a sample pair issued back to back (round 3: 1.3 % less time at the power cap than alternating the two
        // sample streams, profiles/round3j_kbench_fma_order.txt; the x operand of four consecutive FMAs does not
-       // toggle) and, since round 4, non-temporal staging loads for everything but the next tile's halo (NTLD8)
+       // toggle) and, since round 4, non-temporal staging loads for everything but the two halos (NTLD7)
        // software-pipelined window reads (fir_tile_sym_pipe): the chunks of step T + PF are requested before the FMAs of
        // step T, PF = 2 (PIPE2), 3 (PIPE3 = both bits) or 4 (PIPE4); x-grouped issue order
        T2_PIPE2 = 4096, T2_PIPE4 = 8192,
@@ -74,7 +74,16 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        // machine scheduler free to interleave the quads: 60 % of adjacent FMAs share their sample pair in the
        // round-3 code object, 75 % when pinned)
        T2_PINNED = 131072,
-       T2_SHIPPED = T2_SCALAR | T2_XGROUP | T2_NTLD8 };
+       // NTLD9: DMAs 0..8 non-temporal, only the last (partial) instruction plain: most of the next tile's halo then
+       // depends on nt lines staying in the L2 for the few microseconds until the neighbouring wave asks (A/B)
+       T2_NTLD9 = 262144,
+       // NTLD7: DMAs 1..7 non-temporal; instruction 0 -- the re-read of the previous tile's last kilobyte -- is a plain
+       // load as well as 8 and 9.  With NTLD8 the counters show 5.4 % more HBM reads than bytes (traffic 1.043 x
+       // algorithmic): when the halo's nt re-read reaches the L2 before the neighbour's plain load has, it streams
+       // through without leaving the line there, and the plain load fetches it a second time.  Both plain: whichever
+       // comes first allocates, the other hits.
+       T2_NTLD7 = 524288,
+       T2_SHIPPED = T2_SCALAR | T2_XGROUP | T2_NTLD7 };
 
 // byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
 __device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(64 * WPG) void decim4_tile2_kernel(const DecimTileA
             stage_range<NT, 0, NIA, LASTA, false, (OPT & T2_NTLD) ? 0xffffffffu : 0u>(c, t, buf, aoff);
             stage_range<NT, HS, NIB, LASTB, false, (OPT & T2_NTLD) ? 0xffffffffu : 0u>(c, t, buf, boff);
         } else {
-            constexpr unsigned NTM = (OPT & T2_NTLD) ? 0xffffffffu : ((OPT & T2_NTLD8) ? 0xffu : 0u);
+            constexpr unsigned NTM = (OPT & T2_NTLD) ? 0xffffffffu : ((OPT & T2_NTLD9) ? 0x1ffu : ((OPT & T2_NTLD8) ? 0xffu : ((OPT & T2_NTLD7) ? 0xfeu : 0u)));
             stage_range<NT, 0, NIF, LASTF, (OPT & T2_MASKPAD) != 0, NTM>(c, t, buf, boff);
         }
     };

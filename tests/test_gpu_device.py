@@ -869,3 +869,21 @@ def test_config4_channel_shards_through_the_device_path(oracle, shards_per_gpu):
         for c in range(per):
             ref = oracle.decim_f32(h, 4, oracle.synth_iq(SEED, per * k + c, 0, 4 * n_read), 2, 4)
             assert_bit_exact(results[k][c], ref, "shard %d (gpu %d) channel %d" % (k, shards[k][0], per * k + c))
+
+
+def test_kernel_stores_into_host_memory_are_visible_after_the_wait(tmp_path):
+    """The mechanism the RX chain's small passes rely on (GpuChains.hpp: the decimator stores straight into the chain's
+    hipHostMalloc'ed staging, an event, then the host reads): tools/hostvis_probe.hip writes a per-launch pattern in the
+    decimator's store shape (whole lines + a ragged tile ending inside a line), waits, and checks EVERY word -- here
+    20000 launches for each of the 12 cells on hipHostMalloc'ed memory (nt / plain stores x three kinds of wait x idle /
+    beside a streaming kernel); profiles/round4c_hostvis_probe.txt holds the 10^6-launch runs of all the cells."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "hostvis_probe")
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-w", root + "/tools/hostvis_probe.hip", "-o", exe])
+    run = subprocess.run([exe, "20000", "hipHostMalloc default"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:]
+    lines = [l for l in run.stdout.splitlines() if "launches with stale words" in l]
+    assert len(lines) == 12 and all(" : 0 of 20000 " in l for l in lines), run.stdout[-2000:]

@@ -29,6 +29,7 @@
 #   kb4x                /4 kernel: tiles per wave x nt loads x taps by value x deferred stores x 12 waves per CU x pinned FMA order
 #   kbdnt               dense /32, /8, /16 kernels with non-temporal staging loads against the shipped ones (whole kernel, memory side)
 #   kb4q                /4 kernel: persistent workgroups with an LDS tile queue + nt loads against generations of short waves
+#   kb4f                /4 kernel: generations / dispatch order / nt mask around the shipped configuration
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
@@ -92,6 +93,14 @@ for S in "$@"; do
               V="x:16:0:0:0:0 t2.16.66752:1:0:0:0:0 t2.16.1216:1:0:0:0:0 t2.8.66752:1:0:0:0:0 t2.4.66752:1:0:0:0:0 t2.16.66752:2:0:0:0:0 t2.1.66624:16:0:0:0:0"
               KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
               KB_ZERO=1 KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    kb4f)     # fine tuning around the shipped /4 kernel (66624): generations, plain dispatch order, nt mask; 11 rounds, the shipped one first and last
+              V="t2.1.66624:16:0:0:0:0 t2.1.66624:8:0:0:0:0 t2.1.66624:12:0:0:0:0 t2.1.66624:24:0:0:0:0 t2.1.66624:16:0:0:2:0 t2.1.263232:16:0:0:0:0 t2.1.67136:16:0:0:0:0 t2.1.66624:16:0:0:0:16"
+              KB_D=4 KB_ROUNDS=11 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    kbnt2)    # nt masks that keep BOTH halos plain: /4 (525376) against the shipped 66624; dense /32, /8, /16: densent2 against densent / densepl
+              KB_D=4 KB_ROUNDS=11 timeout 900 python3 tools/kbench.py t2.1.66624:16:0:0:0:0 t2.1.525376:16:0:0:0:0 t2.1.1088:16:0:0:0:0 t2.1.525376:16:0:1:0:0 t2.1.66624:16:0:1:0:0 t2.1.525376:16:0:0:0:16 >> $LOG 2>&1; RC=$?
+              for D in 32 8 16; do KB_D=$D KB_ROUNDS=7 timeout 600 python3 tools/kbench.py densepl:8:0:0:0 densent:8:0:0:0 densent2:8:0:0:0 densent2:8:0:1:0 >> $LOG 2>&1; done; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    t2pmc)    # HBM traffic of /4 variants: FETCH_SIZE / WRITE_SIZE per launch (tools/pmc_pass.sh runs tools/onekernel.py)
+              for V in t2:1:1088 t2:1:66624 t2:1:525376; do for C in FETCH_SIZE WRITE_SIZE; do SXFIR_TILE_VARIANT=$V SXFIR_PROF=1 bash tools/pmc_pass.sh "$C" 4 CF32 28 >> $LOG 2>&1; done; done; RC=$?; grep -v amdgpu.ids $LOG | tail -8 ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

@@ -9,6 +9,7 @@ n = 1 << log2n
 dt = torch.complex64 if fmt == "CF32" else torch.int32
 x = torch.empty(n, dtype=dt, device="cuda"); sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=fmt)
 y = torch.empty(n // D, dtype=dt, device="cuda")
-p = sxxcvr_amd.Resampler(DECIMATE, sxxcvr_amd.design_lowpass(32 * D, D), D, fmt=fmt)
+# SXFIR_PROF=1: the profiling build, whose SXFIR_* knobs (SXFIR_TILE_VARIANT, SXFIR_DENSE_NT ...) pick the kernel variant
+p = sxxcvr_amd.Resampler(DECIMATE, sxxcvr_amd.design_lowpass(32 * D, D), D, fmt=fmt, profiling=os.environ.get("SXFIR_PROF") == "1")
 for _ in range(5): p.process(x, out=y)
 torch.cuda.synchronize()

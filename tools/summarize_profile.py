@@ -54,8 +54,60 @@ try:
 except Exception:
     traffic = {"configs": {}}
 
+def duplex_summary(src, name):
+    """--config 3: two kernels side by side on two streams; per direction the kernel-trace stats and the counters."""
+    def one(pattern):
+        f = glob.glob(os.path.join(src, pattern), recursive=True)
+        return f[0] if f else None
+    out = {"tag": name, "config": "3", "directions": {}}
+    stats = one("trace/**/*kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats))) if stats else []
+    if rows:
+        with open(os.path.join(dst, "%s_3_kernel_stats.csv" % name), "w") as f:
+            w = csv.DictWriter(f, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(rows)
+    for d, kern in (("rx", KERNELS["3rx"]), ("tx", KERNELS["3tx"])):
+        e = {}
+        for r in rows:
+            if kern in r["Name"]:
+                e.update({"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                          "max_ns": float(r["MaxNs"])})
+        pm = {}
+        for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_sq"):
+            f = one(sub + "/**/*counter_collection.csv")
+            if not f:
+                continue
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if kern in r.get("Kernel_Name", ""):
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            pm.update({k: sum(v) / len(v) for k, v in acc.items()})
+        e["pmc_mean_per_launch"] = pm
+        e["algorithmic_bytes_per_launch"] = 9.0 * (1 << 28)
+        if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+            fetch, write = 2.0 * pm["FETCH_SIZE"] * 1024.0, pm["WRITE_SIZE"] * 1024.0
+            e.update({"hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
+                      "traffic_over_algorithmic": (fetch + write) / e["algorithmic_bytes_per_launch"]})
+        if "avg_ns" in e:
+            e["frac_of_8TBs_at_avg_duration"] = e["algorithmic_bytes_per_launch"] / (e["avg_ns"] * 1e-9) / 8e12
+        out["directions"][d] = e
+    out["note"] = ("the two kernels overlap in time (two HIP streams), so each one's duration here is its span beside the other; "
+                   "counters are collected with the kernels serialised by the profiler")
+    b = os.path.join(src, "bench.json")
+    if os.path.exists(b):
+        lines = [l for l in open(b) if l.startswith("{")]
+        if lines:
+            out["bench"] = json.loads(lines[-1])
+    json.dump(out, open(os.path.join(dst, "%s_3_summary.json" % name), "w"), indent=1)
+    print("3", json.dumps({k: out[k] for k in out if k != "bench"})[:1500])
+
+
 for cfg in configs:
     src = os.path.join(ROOT, "gpurun_out", tag, cfg)
+    if cfg == "3":
+        duplex_summary(src, name)
+        continue
     kern = KERNELS[cfg]
 
     def one(pattern):
