@@ -44,7 +44,7 @@ XGMI_LINK_GBS = 153.0                            # one xGMI link, per direction 
 # of the interpolator); halo and tap re-reads excluded.
 CONFIGS = {
     "2": dict(mode="decim", ntaps=128, ratio=4, fmt="CF32", bytes=8 + 8 / 4, flop=128, gain=1.0,
-              kernel="sxfir::decim4_tile2_kernel<128, scalar taps>",
+              kernel="sxfir::decim4_wide_kernel<scalar taps, 8 outputs per lane>",
               name="128-tap polyphase decim-by-4, 1 ch CF32 streaming (BASELINE config 2)"),
     "3rx": dict(mode="decim", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=1.0,
                 kernel="sxfir::decim_dense_kernel<8>",

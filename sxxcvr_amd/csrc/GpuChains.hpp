@@ -227,8 +227,10 @@ public:
     static constexpr size_t kMaxSource = 1u << 24;     // this many wideband samples per pass over all channels
     static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long are DMA-copied straight into page-locked caller memory
     // A pass whose output is at least this large lands in HBM and crosses PCIe as ONE DMA-engine copy behind the
-    // kernel (57 GB/s on the boxes measured); smaller ones are stored across PCIe by the kernel itself (no copy
-    // to queue, lowest latency, ~33 GB/s).
+    // kernel (57 GB/s on the boxes measured); smaller ones are stored across PCIe by the kernel itself, into the
+    // chain's own hipHostMalloc'ed staging slot and nowhere else (no copy to queue, lowest latency, ~33 GB/s; the
+    // mechanism -- kernel stores, an event, the host reads -- probed clean over 10^6 launches per cell,
+    // tools/hostvis_probe.hip, profiles/round4c_hostvis_probe.txt).
     static constexpr size_t kSdmaFromBytes = size_t(1) << 20;
 
     // wire_s32: the synthetic ADC stream is S32_LE I2S words and the decimator converts them on
@@ -288,9 +290,7 @@ public:
         gpu_check(sxfir_set_device(gpu_), "sxfir_set_device");
         // Large reads into page-locked (pinned / registered) caller memory: the pass goes from HBM into it by DMA,
         // no staging hop and no host copy.  Everything else goes through the pinned staging slots.
-        float *direct = nullptr;
-        size_t direct_stride = 0;
-        dst_locked_ = n >= kDirectFrom && direct_target(dsts, n, &direct, &direct_stride);
+        dst_locked_ = n >= kDirectFrom && page_locked(dsts, n);
         // a reader of megabyte blocks into page-locked memory: the batches read ahead for it stay in HBM and are
         // DMA-copied into ITS buffer when it asks (no staging hop, no host copy)
         if (8 * n * (size_t)nchan_ >= kSdmaFromBytes) prefer_hbm_ = dst_locked_;
@@ -411,23 +411,14 @@ private:
         return b;
     }
 
-    // Are the caller's buffers device visible, 16-byte aligned and one uniform channel stride apart?  Then
-    // *dev / *stride (samples) describe them as one multi-channel output block.
-    bool direct_target(float *const *dsts, size_t n, float **dev, size_t *stride) const
+    // Are the caller's buffers page-locked (pinned / registered with sxfir_host_register), every channel's whole range?
+    // Then the DMA engines can write them as they are (any alignment, any layout: one copy per channel).
+    bool page_locked(float *const *dsts, size_t n) const
     {
-        if ((reinterpret_cast<uintptr_t>(dsts[0]) & 15) != 0) return false;
-        size_t st = n;
-        if (nchan_ > 1) {
-            const ptrdiff_t d = reinterpret_cast<const char *>(dsts[1]) - reinterpret_cast<const char *>(dsts[0]);
-            if (d <= 0 || d % 16 != 0 || (size_t)d < 8 * n) return false;
-            for (int c = 2; c < nchan_; ++c)
-                if (reinterpret_cast<const char *>(dsts[c]) - reinterpret_cast<const char *>(dsts[c - 1]) != d) return false;
-            st = (size_t)d / 8;
+        for (int c = 0; c < nchan_; ++c) {
+            void *d = nullptr;
+            if (sxfir_host_device_pointer(dsts[c], 8 * n, &d) != SXFIR_OK) return false;
         }
-        void *d0 = nullptr;
-        if (sxfir_host_device_pointer(dsts[0], 8 * (st * (size_t)(nchan_ - 1) + n), &d0) != SXFIR_OK) return false;
-        *dev = static_cast<float *>(d0);
-        *stride = st;
         return true;
     }
 
@@ -592,7 +583,7 @@ private:
     size_t batch_, max_batch_;
     int64_t direct_samples_ = 0;     // samples that reached page-locked caller memory without a host copy
     size_t grown_ = 0;               // batch length a reader that outran the read-ahead has earned (0 = none)
-    bool dst_locked_ = false;        // this call's destination is page-locked (and laid out for direct stores)
+    bool dst_locked_ = false;        // this call's destination is page-locked
     bool prefer_hbm_ = false;        // the last megabyte-sized read went to page-locked memory
 };
 

@@ -54,9 +54,9 @@
 #include "sxfir_decim_dense.hip.h"
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
+#include "sxfir_decim_wide.hip.h"               // /4, 128 symmetric taps: the shipped form since round 4
 #ifdef SXFIR_PROFILING
-#include "experiments/sxfir_decim_pair.hip.h"   // measured variants, not shipped
-#include "experiments/sxfir_decim_wide.hip.h"
+#include "experiments/sxfir_decim_pair.hip.h"   // measured variant, not shipped
 #endif
 #ifdef SXFIR_PROFILING
 #include "experiments/sxfir_decim_sgpr.hip.h"
@@ -119,8 +119,11 @@ struct sxfir_plan {
     bool pair;             // decim4_pair_kernel: the two tap halves on the two waves of a workgroup
     bool pair_xsep;        // ... with a separate exchange buffer (two barriers per tile instead of four)
     int occ_pair;          // its resident workgroups per CU
-    bool wide;             // decim4_wide_kernel: 8 outputs per lane, 512-output tiles (symmetric 128-tap plans)
+    bool wide8;            // product: /4 with 128 symmetric taps runs decim4_wide_kernel (8 outputs per lane, 512-output tiles)
+    bool wide;             // (profiling) a non-default build of decim4_wide_kernel was asked for ("wide<nb>", "wident<nb>")
     int wide_nb;           // (profiling) its LDS read-ahead depth: 0 = default
+    bool wide_nt;          // (profiling) "wident...": with non-temporal staging loads
+    bool wide_pin;         // (profiling) "widentp...": and the FMA issue order pinned (volatile asm)
     int occ_wide;
     int compute_units;
     float *taps_dev;
@@ -270,7 +273,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->pair = false;
     p->pair_xsep = false;
     p->occ_pair = 8;
+    p->wide8 = false;
     p->wide = false;
+    p->wide_nt = false;
+    p->wide_pin = false;
     p->wide_nb = 0;
     p->occ_wide = 8;
     p->occ_multi = 2;
@@ -336,19 +342,26 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     }
     if (p->tile_capable) {
         int nb = 0;
-        // 128 symmetric taps (every linear-phase design): the scalar-tap form of the tile kernel
-        const void *ksb = (ntaps == 128 && p->symmetric)
-                              ? (fmt == SXFIR_S32 ? (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED, 0, true>
-                                                  : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>)
-                              : (ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false>
-                                              : (const void *)sxfir::decim4_tile_kernel<64, false>);
+        // the 4-outputs-per-lane kernels: the VGPR-tap form for any 128 or 64 taps -- and, in the profiling build, round 3's
+        // scalar-tap form for 128 symmetric taps ("t2s"), the A/B partner of the wide kernel that replaced it
+        const void *ksb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, false> : (const void *)sxfir::decim4_tile_kernel<64, false>;
+#ifdef SXFIR_PROFILING
+        if (ntaps == 128 && p->symmetric)
+            ksb = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED, 0, true>
+                                   : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>;
+#endif
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
+        if (ntaps == 128 && p->symmetric) {
+            // the shipped form for 128 symmetric taps: eight outputs per lane (sxfir_decim_wide.hip.h); 18.5 KB of LDS
+            // per wave -> 8 waves per CU
+            p->wide8 = true;
+            const void *kw = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_wide_kernel<0, true> : (const void *)sxfir::decim4_wide_kernel<0, false>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
+        }
 #ifdef SXFIR_PROFILING
         if (ntaps == 128) {
             const void *kp = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_pair_kernel<0, true> : (const void *)sxfir::decim4_pair_kernel<0, false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 128, 0) == hipSuccess && nb > 0) p->occ_pair = nb;
-            const void *kw = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_wide_kernel<0, true> : (const void *)sxfir::decim4_wide_kernel<0, false>;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
         }
         const void *kdb = ntaps == 128 ? (const void *)sxfir::decim4_tile_kernel<128, true>
                                        : (const void *)sxfir::decim4_tile_kernel<64, true>;
@@ -356,7 +369,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
             p->tile_dbuf = (strcmp(v, "db") == 0);
             // "sb", "db", "sg": the first-generation tile kernel (taps in VGPR pairs) also for symmetric taps
-            if (strcmp(v, "sb") == 0 || strcmp(v, "db") == 0 || strncmp(v, "sg", 2) == 0) p->symmetric = false;
+            if (strcmp(v, "sb") == 0 || strcmp(v, "db") == 0 || strncmp(v, "sg", 2) == 0) { p->symmetric = false; p->wide8 = false; }
+            // "t2s": round 3's shipped form (decim4_tile2_kernel, T2_SHIPPED) as the A/B partner of the wide kernel
+            if (strcmp(v, "t2s") == 0) p->wide8 = false;
             p->sgpr_r = strcmp(v, "sg") == 0 ? 8 : (strcmp(v, "sg4") == 0 ? 4 : 0);
             if (p->sgpr_r && ntaps == 128) {
                 const void *k = p->sgpr_r == 8 ? (const void *)sxfir::decim4_sgpr_kernel<8>
@@ -367,7 +382,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             // "wide": decim4_wide_kernel (sxfir_decim_wide.hip.h), symmetric taps only
             if (strncmp(v, "wide", 4) == 0 && ntaps == 128 && p->symmetric) {
                 p->wide = true;
-                p->wide_nb = atoi(v + 4);
+                p->wide_nt = strncmp(v, "wident", 6) == 0;
+                p->wide_pin = strncmp(v, "widentp", 7) == 0;
+                p->wide_nb = atoi(v + (p->wide_pin ? 7 : (p->wide_nt ? 6 : 4)));
             }
             // "pair": decim4_pair_kernel (sxfir_decim_pair.hip.h)
             if (strncmp(v, "pair", 4) == 0 && ntaps == 128) {
@@ -688,6 +705,27 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
 #ifdef SXFIR_PROFILING
         if (const int pr = prof_launch_tile_variant(p, a, n_out, n_tiles, st)) return pr < 0 ? pr : SXFIR_OK;   // pair / wide / tile2 variants
 #endif
+        if (p->wide8 && p->sched != 1) {
+            // 128 symmetric taps: decim4_wide_kernel, tiles of 512 outputs, one wave (= one workgroup) per tile and pass;
+            // G = CUs x 8 resident waves x 16 generations waves per launch, strided XCD-blocked passes
+            const long long n_tiles2 = (n_out + 511) / 512;
+            long long G = ((long long)p->compute_units * p->occ_wide * p->oversub) / p->nchan;
+            if (G < 1) G = 1;
+            if (G > n_tiles2) G = n_tiles2;
+            a.n_tiles = (int)n_tiles2;
+            a.n_waves = (int)G;
+            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
+            a.run_base = a.run_extra = 0;
+            {
+                const int t = (int)((n_tiles2 - 1) % G);
+                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+            }
+            dim3 grid((unsigned)G, (unsigned)p->nchan);
+            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
+        }
         // Short-lived waves in generations: W = CUs * resident waves * oversub waves per launch, each covering
         // n_tiles / W tiles in strided, XCD-blocked passes (sxfir_decim_tile.hip.h).
         const bool dbuf = p->tile_dbuf;
@@ -714,13 +752,16 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
 #ifdef SXFIR_PROFILING
         if (const int pr = prof_launch_tile_first_gen(p, a, grid, per_chan, dbuf, st)) return pr < 0 ? pr : SXFIR_OK;
 #endif
-        // (with one wave per workgroup both kernels take the same schedule constants)
+#ifdef SXFIR_PROFILING
+        // "t2s": round 3's shipped form (with one wave per workgroup both kernels take the same schedule constants)
         if (p->ntaps == 128 && p->symmetric && p->sched != 1) {
             if (p->fmt == SXFIR_S32)
                 hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED, 0, true>), grid, dim3(64), 0, st, a);
             else
                 hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>), grid, dim3(64), 0, st, a);
-        } else if (p->fmt == SXFIR_S32)
+        } else
+#endif
+        if (p->fmt == SXFIR_S32)
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
         else if (p->ntaps == 128)
             hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);

@@ -1,9 +1,16 @@
 // Decimate-by-4, 128 symmetric taps: 8 outputs per lane, one wave per tile of 512 outputs (gfx950).
+// The production kernel of BASELINE config 2 since round 4 (a measured variant in rounds 2-3).
 //
 // The /4 kernels are bound by the energy of their arithmetic at the board's power cap, and the
 // arithmetic probe ranks the instruction mixes: taps as SGPR operands, and as few LDS reads per FMA as possible.
 // sxfir_decim_tile2.hip.h (T2_SCALAR) has the SGPR taps with 4 outputs per lane: 71 ds_read_b128 per 512 packed
-// FMAs.  This kernel doubles the outputs per lane:
+// FMAs.  This kernel doubles the outputs per lane.  In round 2 it tied with the 4-output form: two waves per SIMD left
+// its structure no faster than the power cap allowed the other.  Round 4's non-temporal staging loads (DESIGN.md 5.1
+// "Round 4") and a deeper LDS read-ahead (NB = 24 chunks; two waves per SIMD leave a wave 256 VGPRs) moved its
+// structure well below the cap (0.44 ms on an all-zero input), and at the cap its lower energy per sample -- 39.5 instead
+// of 71 LDS reads per 512 FMAs, a 6 % instead of a 12.5 % halo, sixteen consecutive FMAs sharing a sample pair -- now
+// shows: 1.2 ... 2.4 % less time than the 4-output form on the same box (profiles/round4j_kbench_wide_nt.txt,
+// round4k_kbench_wide_read_ahead.txt).
 //
 //   * lane l -> outputs 8l..8l+7 of the tile over ALL 128 taps: 16 accumulators (P1 = taps 127..64 and P0 = taps
 //     63..0 of each output, the chains of the numeric contract, y = P0 + P1), one window of 79 chunks read ONCE:
@@ -22,8 +29,8 @@
 
 #include <utility>
 
-#include "../sxfir_decim_tile.hip.h"
-#include "../sxfir_decim_tile2.hip.h"
+#include "sxfir_decim_tile.hip.h"
+#include "sxfir_decim_tile2.hip.h"
 
 namespace sxfir {
 
@@ -45,7 +52,9 @@ struct DecimWide {
 // tap 64 + kl, kl = 4i + 64 - w1, which is h[63 - kl]; seen from the P0 chain the same sample is w0 = w1 - 64 and
 // meets output i at tap kl0 = 4i + 64 - w0.  A function template per chunk: every tap index is a compile-time
 // constant, so the taps stay in SGPRs.
-template <bool S32IN, int CIDX, int NB>
+// PIN: the packed FMAs as volatile asm, i.e. issued in source order -- all (up to sixteen) FMAs of a sample pair back to
+// back; left to the machine scheduler only 0.28 of adjacent FMAs share their sample pair in the CF32 build
+template <bool S32IN, int CIDX, int NB, bool PIN = false>
 __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB], const f32x2 (&hs)[32], f32x2 (&a1)[8],
                                               f32x2 (&a0)[8])
 {
@@ -67,7 +76,8 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
                 const int kl = 4 * i + 64 - w1;
                 if (kl >= 0 && kl < 64) {
                     const int j = 63 - kl;               // h[64 + kl] == h[63 - kl]
-                    if (j & 1) pk_fma_s_hi(a1[i], hs[j >> 1], x);
+                    if constexpr (PIN) { if (j & 1) pk_fma_sv_hi(a1[i], hs[j >> 1], x); else pk_fma_sv_lo(a1[i], hs[j >> 1], x); }
+                    else if (j & 1) pk_fma_s_hi(a1[i], hs[j >> 1], x);
                     else pk_fma_s_lo(a1[i], hs[j >> 1], x);
                 }
             }
@@ -78,7 +88,8 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
             for (int i = 0; i < 8; ++i) {
                 const int kl = 4 * i + 64 - w0;
                 if (kl >= 0 && kl < 64) {
-                    if (kl & 1) pk_fma_s_hi(a0[i], hs[kl >> 1], x);
+                    if constexpr (PIN) { if (kl & 1) pk_fma_sv_hi(a0[i], hs[kl >> 1], x); else pk_fma_sv_lo(a0[i], hs[kl >> 1], x); }
+                    else if (kl & 1) pk_fma_s_hi(a0[i], hs[kl >> 1], x);
                     else pk_fma_s_lo(a0[i], hs[kl >> 1], x);
                 }
             }
@@ -86,20 +97,22 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
     }
 }
 
-template <bool S32IN, int NB, int... Cs>
+template <bool S32IN, int NB, bool PIN, int... Cs>
 __device__ __forceinline__ void fir_wide_steps(std::integer_sequence<int, Cs...>, const f32x4 *win, const f32x2 (&hs)[32],
                                                f32x2 (&a1)[8], f32x2 (&a0)[8])
 {
     f32x4 buf[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) buf[c] = win[c + (c >> 4)];
-    (fir_wide_step<S32IN, Cs, NB>(win, buf, hs, a1, a0), ...);
+    (fir_wide_step<S32IN, Cs, NB, PIN>(win, buf, hs, a1, a0), ...);
 }
 
 // ABL (profiling): 0 = the real kernel, 1 = staging + stores without the FIR, 5 = phase stamps (per wave 8 x uint64:
 // tiles, cycles issuing DMAs, waiting for data, FIR, transposition + stores, whole wave cycles, whole wave 100 MHz
 // ticks, XCC_ID | HW_ID << 8).
-template <int ABL = 0, bool S32IN = false, int NB = 8>
+// NTL (round 4): DMA instructions 1..16 -- the rows no other tile reads -- are non-temporal loads; 0 (the re-read of the
+// previous tile's last kilobyte) and 17, 18 (this tile's last kilobyte, the next tile's halo) stay plain.
+template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false>
 __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
 {
     using C = DecimWide;
@@ -148,7 +161,10 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
             for (int j = 0; j < C::NI; ++j) {
                 unsigned bo = boff[j];
                 asm volatile("" : "+v"(bo));             // 32-bit offset next to its use (see stage_tile)
-                if (j < C::NI - 1 || lane < C::LASTL) glds16(src + bo, img + 64 * j);
+                if (j < C::NI - 1 || lane < C::LASTL) {
+                    if (NTL && j >= 1 && j <= 16) glds16<2>(src + bo, img + 64 * j);
+                    else glds16(src + bo, img + 64 * j);
+                }
             }
         } else {
 #pragma unroll
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
             a0[4] = (f32x2){v1.x, v1.y};
             a0[7] = (f32x2){v1.z, v1.w};
         } else {
-            fir_wide_steps<S32IN, NB>(std::make_integer_sequence<int, C::WCH>{}, win, hs, a1, a0);
+            fir_wide_steps<S32IN, NB, PIN>(std::make_integer_sequence<int, C::WCH>{}, win, hs, a1, a0);
         }
         f32x4 y[4];
 #pragma unroll

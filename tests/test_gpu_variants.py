@@ -15,7 +15,8 @@ from gpu_util import assert_bit_exact, to_cpu, to_gpu
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SXFIR_SCHED")
+KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SXFIR_SCHED", "SXFIR_LDS_PAD", "SXFIR_DENSE_NT",
+         "SXFIR_DENSE", "SXFIR_MULTI_W", "SXFIR_MULTI_PS")
 
 
 @pytest.mark.parametrize("env", [
@@ -33,6 +34,15 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_TILE_VARIANT": "t2:1:576", "SXFIR_OVERSUB": "64"},
     {"SXFIR_TILE_VARIANT": "wide"},
     {"SXFIR_TILE_VARIANT": "wide", "SXFIR_OVERSUB": "3"},
+    {"SXFIR_TILE_VARIANT": "wident12"},
+    {"SXFIR_TILE_VARIANT": "wident32", "SXFIR_OVERSUB": "5"},
+    {"SXFIR_TILE_VARIANT": "widentp24"},
+    {"SXFIR_TILE_VARIANT": "t2s"},                                   # round 3's shipped form, now the A/B partner
+    {"SXFIR_TILE_VARIANT": "t2s", "SXFIR_OVERSUB": "3"},
+    {"SXFIR_TILE_VARIANT": "t2:1:525376"},                           # ... and its option-bit spelling, nt loads
+    {"SXFIR_TILE_VARIANT": "t2:1:66624", "SXFIR_OVERSUB": "64"},
+    {"SXFIR_TILE_VARIANT": "t2:1:197696"},
+    {"SXFIR_TILE_VARIANT": "t2:16:66752", "SXFIR_OVERSUB": "1"},
     {"SXFIR_TILE_VARIANT": "wide", "SXFIR_OVERSUB": "64", "SXFIR_SCHED": "2"},
     {"SXFIR_TILE_VARIANT": "pairx"},
     {"SXFIR_TILE_VARIANT": "pairx", "SXFIR_OVERSUB": "5"},
@@ -72,6 +82,7 @@ def test_short_tail_schedule_matches_oracle(oracle, monkeypatch):
     import torch
     for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_TILE_VARIANT", "t2s")          # the schedule belongs to the 4-outputs-per-lane kernel
     monkeypatch.setenv("SXFIR_SCHED", "3")
     monkeypatch.setenv("SXFIR_OVERSUB", "2")
     h = sxxcvr_amd.design_lowpass(128, 4)

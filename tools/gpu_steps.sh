@@ -30,6 +30,7 @@
 #   kbdnt               dense /32, /8, /16 kernels with non-temporal staging loads against the shipped ones (whole kernel, memory side)
 #   kb4q                /4 kernel: persistent workgroups with an LDS tile queue + nt loads against generations of short waves
 #   kb4f                /4 kernel: generations / dispatch order / nt mask around the shipped configuration
+#   kb4wide             /4 kernel: eight outputs per lane + nt loads against the shipped form
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
@@ -101,6 +102,18 @@ for S in "$@"; do
               for D in 32 8 16; do KB_D=$D KB_ROUNDS=7 timeout 600 python3 tools/kbench.py densepl:8:0:0:0 densent:8:0:0:0 densent2:8:0:0:0 densent2:8:0:1:0 >> $LOG 2>&1; done; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
     t2pmc)    # HBM traffic of /4 variants: FETCH_SIZE / WRITE_SIZE per launch (tools/pmc_pass.sh runs tools/onekernel.py)
               for V in t2:1:1088 t2:1:66624 t2:1:525376; do for C in FETCH_SIZE WRITE_SIZE; do SXFIR_TILE_VARIANT=$V SXFIR_PROF=1 bash tools/pmc_pass.sh "$C" 4 CF32 28 >> $LOG 2>&1; done; done; RC=$?; grep -v amdgpu.ids $LOG | tail -8 ;;
+    kb4wide)  # eight outputs per lane (39.5 LDS reads per 512 FMAs, 2 waves per SIMD) with nt staging loads, against the shipped /4 kernel
+              V="x:16:0:0:0:0 wident:16:0:0:0:0 wident12:16:0:0:0:0 wident16:16:0:0:0:0 wide:16:0:0:0:0 wident:8:0:0:0:0 wident:32:0:0:0:0 wident:16:0:1:0:0 x:16:0:0:0:16"
+              KB_D=4 KB_ROUNDS=9 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
+              KB_ZERO=1 KB_D=4 KB_ROUNDS=5 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    kb4wide2) # the wide form's read-ahead depth and generations, nt loads, against the shipped kernel (first and last)
+              V="x:16:0:0:0:0 wident16:16:0:0:0:0 wident24:16:0:0:0:0 wident32:16:0:0:0:0 wident16:8:0:0:0:0 wident16:32:0:0:0:0 wident16:4:0:0:0:0 wident12:16:0:0:0:0 x:16:0:0:0:16"
+              KB_D=4 KB_ROUNDS=11 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    kb4wide3) # the shipped wide kernel (x) against round 3's form with nt loads (t2s), read-ahead depths and the pinned FMA order
+              V="x:16:0:0:0:0 t2s:16:0:0:0:0 wident16:16:0:0:0:0 widentp24:16:0:0:0:0 widentp16:16:0:0:0:0 wident32:16:0:0:0:0 t2s:16:0:0:0:16 x:16:0:0:0:16"
+              KB_D=4 KB_ROUNDS=11 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    kb4ab)    # wide (x) against round 3's form with nt loads (t2s): long runs (100 untimed + 200 timed launches per visit), 7 rounds, both orders
+              KB_D=4 KB_ROUNDS=7 KB_ITERS=200 KB_SETTLE=100 timeout 1200 python3 tools/kbench.py x:16:0:0:0:0 t2s:16:0:0:0:0 wident16:16:0:0:0:0 wident32:16:0:0:0:0 widentp24:16:0:0:0:0 t2s:16:0:0:0:16 x:16:0:0:0:16 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

@@ -10,6 +10,7 @@ from sxxcvr_amd.resampler import DECIMATE
 log2n = int(os.environ.get("KB_LOG2N", "28"))
 rounds = int(os.environ.get("KB_ROUNDS", "5"))
 iters = int(os.environ.get("KB_ITERS", "10"))
+settle = int(os.environ.get("KB_SETTLE", "0"))
 nchan = int(os.environ.get("KB_NCHAN", "1"))
 D = int(os.environ.get("KB_D", "4"))
 FMT = os.environ.get("KB_FMT", "CF32")
@@ -57,6 +58,9 @@ for r in range(rounds):
     for c, p in zip(configs, plans):
         p.reset()
         try:
+            # KB_SETTLE untimed launches of THIS variant first: the chip's power management carries the previous
+            # variant's state over for milliseconds, so a short timed run partly measures its predecessor
+            if settle: p.time_decimate_ptr(x.data_ptr(), n, n, y.data_ptr(), n // D, settle, st)
             ms = p.time_decimate_ptr(x.data_ptr(), n, n, y.data_ptr(), n // D, iters, st)
         except Exception as e:                       # e.g. a variant that has no instantiation for this ablation mode
             if r == 0: print("config", c, "skipped:", e)
