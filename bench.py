@@ -50,7 +50,7 @@ CONFIGS = {
                 kernel="sxfir::decim_dense_kernel<8>",
                 name="256-tap polyphase decim-by-8 RX, 1 ch CF32 streaming (BASELINE config 3, RX half)"),
     "3tx": dict(mode="interp", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=8.0,
-                kernel="sxfir::interp_tile_kernel<8>",
+                kernel="sxfir::interp8_pass_kernel<2 inputs per lane, scalar taps>",
                 name="256-tap polyphase interp-by-8 TX, 1 ch CF32 streaming (BASELINE config 3, TX half)"),
     "3": dict(mode="duplex", ntaps=256, ratio=8, fmt="CF32", bytes=9.0, flop=128, gain=1.0,
               kernel="sxfir::decim_dense_kernel<8> + sxfir::interp_tile_kernel<8> on two streams",

@@ -53,6 +53,7 @@
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_decim_dense.hip.h"
 #include "sxfir_interp_tile.hip.h"
+#include "sxfir_interp_pass.hip.h"
 #include "sxfir_decim_tile2.hip.h"
 #include "sxfir_decim_wide.hip.h"               // /4, 128 symmetric taps: the shipped form since round 4
 #ifdef SXFIR_PROFILING
@@ -127,7 +128,11 @@ struct sxfir_plan {
     int occ_wide;
     int compute_units;
     float *taps_dev;
-    float *taps_scaled_dev;   // taps * 2^-31 (exact): scalar-tap kernel on S32 wire words
+    float *taps_scaled_dev;   // decimators: taps * 2^-31 (exact), the scalar-tap kernels on S32 wire words; x8 interpolators: the
+                              // pass-major tap table of interp8_pass_kernel (pass (c, p) at 64 (2c + p), (jj, rr) at 4 jj + rr)
+    bool ipass;               // x8, 256 taps, CF32: interp8_pass_kernel (scalar taps, four passes per tile)
+    int occ_ipass;
+    int ipass_qi;             // inputs per lane of that kernel (2; profiling: 4)
     float taps_k[64];         // the first 64 taps (times 2^-31 for S32 plans) for kernels that take them by value
     bool symmetric;           // taps[k] == taps[ntaps-1-k] bit for bit (every linear-phase design)
     void *hist_dev;        // current history: nchan * hist_len samples
@@ -207,6 +212,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->consumed = p->produced = 0;
     p->taps_dev = nullptr;
     p->taps_scaled_dev = nullptr;
+    p->ipass = false;
+    p->occ_ipass = 16;
+    p->ipass_qi = 2;
     p->symmetric = true;
     for (int k = 0; k < ntaps / 2; ++k)
         if (memcmp(&taps[k], &taps[ntaps - 1 - k], sizeof(float)) != 0) p->symmetric = false;
@@ -285,6 +293,13 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // interpolator is flat between 2 and 16 (tools/ibench.py)
     if (p->multi_capable) p->oversub = 8;
     if (p->itile_capable) p->oversub = 4;
+    if (p->itile_capable && ratio == 8 && fmt == SXFIR_CF32) {
+        p->ipass = true;
+        p->oversub = 8;                                 // measured (tools/ibench2.py): 4 / 8 / 16 generations within 0.3 %
+        int nbi = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<2>, 64, 0) == hipSuccess && nbi > 0)
+            p->occ_ipass = nbi;
+    }
 #ifdef SXFIR_PROFILING
     // A/B knobs of the profiling build.  The production library never looks at the environment.
     if (const char *v = getenv("SXFIR_TILE_VARIANT")) {
@@ -295,6 +310,15 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
     }
     if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
+    if (const char *v = getenv("SXFIR_IPASS")) {     // 0: interp_tile_kernel at x8 too (A/B); 4: four inputs per lane
+        p->ipass = p->ipass && atoi(v) != 0;
+        if (p->ipass && atoi(v) == 4) {
+            p->ipass_qi = 4;
+            int nbi = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<4>, 64, 0) == hipSuccess && nbi > 0)
+                p->occ_ipass = nbi;
+        }
+    }
     if (const char *v = getenv("SXFIR_DENSE_NT")) { p->dense_nt = atoi(v); p->dense_nt_set = 1; }
     if (getenv("SXFIR_MULTI_PS") || getenv("SXFIR_MULTI_W")) p->dense32 = false;   // those knobs belong to the multi-column kernel
     if (p->multi_capable && fmt != SXFIR_S32 && !p->dense32) {
@@ -429,7 +453,15 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     for (int k = 0; k < 64; ++k) p->taps_k[k] = k < ntaps ? (fmt == SXFIR_S32 ? taps[k] * 4.656612873077393e-10f : taps[k]) : 0.0f;
     if (e == hipSuccess) {
         std::vector<float> scaled(taps, taps + ntaps);
-        for (float &t : scaled) t *= 4.656612873077393e-10f;      // 2^-31: exact
+        if (mode == SXFIR_INTERPOLATE && p->itile_capable && ratio == 8) {
+            for (int c = 0; c < 2; ++c)
+                for (int ph = 0; ph < 2; ++ph)
+                    for (int jj = 0; jj < 16; ++jj)
+                        for (int rr = 0; rr < 4; ++rr)
+                            scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] = taps[(16 * ph + jj) * 8 + 4 * c + rr];
+        } else {
+            for (float &t : scaled) t *= 4.656612873077393e-10f;      // 2^-31: exact
+        }
         e = hipMemcpy(p->taps_scaled_dev, scaled.data(), sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(&p->hist_dev, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
@@ -848,6 +880,38 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
                        (p->nchan == 1 || out_stride % 2 == 0);
     if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
         return fail(SXFIR_EUNSUPPORTED, "tiled interpolator needs a 16-byte aligned output and even strides");
+    if (tiled && p->ipass && !key) {
+        // x8, 256 taps, CF32: the scalar-tap form, tiles of 128 inputs (two per lane), four (phase group, row half) passes per tile
+        sxfir::InterpTileArgs t;
+        t.in = (const float *)in_dev;
+        t.hist = (const float *)p->hist_dev;
+        t.hist_out = (float *)p->hist_alt;
+        t.out = (float *)out_dev;
+        t.taps = p->taps_scaled_dev;                            // the pass-major table
+        t.n_in = (long long)n_in;
+        t.in_stride = (long long)in_stride;
+        t.out_stride = (long long)out_stride;
+        t.hist_stride = p->hist_len;
+        const int tile_in = 64 * p->ipass_qi;
+        const long long n_tiles = ((long long)n_in + tile_in - 1) / tile_in;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        long long groups = ((long long)p->compute_units * p->occ_ipass * p->oversub) / p->nchan;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        t.n_tiles = (int)n_tiles;
+        t.n_groups = (int)groups;
+        t.thr2 = p->thr2;
+        t.key_counter = nullptr;
+        t.key_lo = t.key_hi = 0;
+#ifdef SXFIR_PROFILING
+        if (p->ipass_qi == 4) hipLaunchKernelGGL(sxfir::interp8_pass_kernel<4>, dim3((unsigned)groups, (unsigned)p->nchan), dim3(64), 0, st, t);
+        else
+#endif
+        hipLaunchKernelGGL(sxfir::interp8_pass_kernel<2>, dim3((unsigned)groups, (unsigned)p->nchan), dim3(64), 0, st, t);
+        HIPCHECK(hipGetLastError());
+        *history_done = true;
+        return SXFIR_OK;
+    }
     if (tiled) {
         sxfir::InterpTileArgs t;
         t.in = (const float *)in_dev;

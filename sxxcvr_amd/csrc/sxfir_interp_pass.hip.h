@@ -1,0 +1,231 @@
+// Interpolate-by-8, 256 taps (32 per phase), CF32: the scalar-tap form of the TX half of BASELINE config 3 (gfx950).
+//
+// interp_tile_kernel (sxfir_interp_tile.hip.h) spreads a tile's work over lanes (p, g, c) -- tap-row half, input group,
+// phase group -- so lanes of one wave use different taps, and the taps sit in VGPRs: three vector operands per packed
+// FMA.  At the board's power cap the time is energy per sample, and the arithmetic probe (tools/valu_power_probe.hip,
+// profiles/round4p_valu_power_probe.txt) prices a scalar tap operand at 12 % of the FIR phase at this kernel's mix of
+// LDS reads.  A scalar operand is wave-uniform, so the work split changes:
+//
+//   * lane g (0..63) owns QI consecutive inputs q0 + QI g + {0..QI-1} of a tile of 64 QI inputs and produces ALL their
+//     8 QI outputs (the description below is for QI = 4; QI = 2 ships, see the end);
+//   * the four (phase group c, row half p) tap subsets are four PASSES over the same LDS image; a pass's 64 taps
+//     h[(16p + jj)*8 + 4c + rr] are 32 SGPR pairs, loaded with four s_load_dwordx16 from a pass-major copy of the taps
+//     (constant address space); the lane's window -- 36 samples, 18 ds_read_b128 -- is read ONCE per tile and serves all
+//     four passes (the row halves' windows overlap, the phase groups share them): 18 LDS reads per 1024 v_pk_fma_f32
+//     with the tap as the scalar operand, where the other kernel has 40 and a VGPR operand more per FMA;
+//   * with the window in registers the input image is free again: the NEXT tile's three LDS-DMA instructions are
+//     issued before the arithmetic starts, and a counted s_waitcnt (the stores issued behind them stay outstanding)
+//     finds them landed a tile later -- a wave hides its own memory latency, two per SIMD suffice;
+//   * the two row halves of a phase group meet inside the lane: y = P0 + P1 (the contract's tree, no v_permlane32_swap);
+//   * a lane's 32 outputs are 256 consecutive bytes; the tile's 16 KiB go through LDS (chunk k of lane g at slot
+//     16g + (k ^ (g & 15)): the eight lanes a ds_write_b128 is served with hit eight different slots, the read-back is
+//     linear) so that every global store instruction writes four whole 256-byte rows;
+//   * 16 KiB + the 2.3 KiB input image = 18.7 KB of LDS per wave: 8 waves per CU, 2 per SIMD; sixteen accumulator chains
+//     keep the FMA pipe busy from two waves (the trade the /4 wide kernel makes).
+//
+// Measured (tools/ibench2.py, long interleaved visits, profiles/round4q_ibench_pass.txt): QI = 4 takes 4-5 % less time
+// than interp_tile_kernel -- and on an all-zero input 16 % MORE (0.43-0.46 against 0.37-0.38 ms): its energy per sample is
+// lower, its structure (two waves per SIMD, sixteen stores per wave in a burst) slower, and the two walls are close.
+// QI = 2 halves the tile: 8 KiB of outputs + a 1.3 KiB image = 10 KB of LDS and 125 VGPRs, i.e. 16 waves per CU, eight
+// stores per wave and tile, 17 window reads per 512 FMAs (still fewer than the VGPR-tap kernel's 20): structure 0.39-0.41
+// ms on zeros, **9.6 % less time than interp_tile_kernel on random IQ** (0.4636 against 0.5124 ms on the same box).  That
+// form ships for CF32 x8; wire-word output, the keying count and the other ratios keep interp_tile_kernel.
+//
+// Numeric contract: partial_p = fmaf chain from +0.0f over j DESCENDING in [16p, 16p+16); y = P0 + P1 --
+// the same chains in the same order as interp_tile_kernel, so the outputs are bit-identical.
+//
+// New code: in the reference the SX1255 interpolates what snd_pcm_writei hands it (SoapySX.cpp:1093).
+#pragma once
+
+#include <utility>
+
+#include "sxfir_interp_tile.hip.h"
+#include "sxfir_decim_tile2.hip.h"       // pk_fma_s_lo / pk_fma_s_hi
+
+namespace sxfir {
+
+// QI = inputs per lane: 4 (tile of 256 inputs, 16 KiB of outputs, 8 waves per CU -- the form described above) or 2 (tile
+// of 128 inputs, 8 KiB of outputs, 10 KB of LDS: 16 waves per CU when the registers allow, at 17 instead of 18 window
+// reads per HALF as many FMAs).
+template <int QI>
+struct InterpPass8 {
+    static_assert(QI == 2 || QI == 4, "inputs per lane");
+    static constexpr int L = 8;
+    static constexpr int TILE_IN = 64 * QI;               // inputs per tile
+    static constexpr int HIST = 32;
+    static constexpr int CHUNKS = (TILE_IN + HIST) / 2;   // staged chunks: samples [q0 - 32, q0 + TILE_IN)
+    static constexpr int NLOAD = (CHUNKS + 63) / 64;      // DMA instructions
+    static constexpr int IMG = NLOAD * 64;
+    static constexpr int CPL = 4 * QI;                    // output chunks per lane (QI inputs x 8 outputs x 8 bytes / 16)
+    static constexpr int OBUF = 64 * CPL;                 // output chunks per tile
+    static constexpr int NW = (QI + 16) / 2;              // window chunks of one pass
+    static constexpr int NWU = NW + 8;                    // ... of both row halves together (the lane reads these once)
+};
+
+// One window chunk T (0..9) of a pass: samples w = 2T, 2T+1 of the lane's window meet input qi at tap row
+// jj = qi + 16 - w (when 0 <= jj < 16); hs[(4 jj + rr) >> 1] holds the pass's taps (jj, rr) pairwise.
+template <int QI, int T>
+__device__ __forceinline__ void interp_pass_step(const f32x4 &v, const f32x2 (&hs)[32], f32x2 (&acc)[QI][4])
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int w = 2 * T + s;
+        const f32x2 x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            const int jj = qi + 16 - w;
+            if (jj >= 0 && jj < 16) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (rr & 1) pk_fma_s_hi(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
+                    else pk_fma_s_lo(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
+                }
+            }
+        }
+    }
+}
+
+template <int QI, int... Ts>
+__device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts...>, const f32x4 (&win)[(QI + 16) / 2], const f32x2 (&hs)[32],
+                                                  f32x2 (&acc)[QI][4])
+{
+    (interp_pass_step<QI, Ts>(win[Ts], hs, acc), ...);
+}
+
+template <int QI>
+__global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
+{
+    using C = InterpPass8<QI>;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[C::IMG + C::OBUF];
+    f32x4 *obuf = lds + C::IMG;
+
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.y;
+    const float *in = a.in + 2 * a.in_stride * ch;
+    const float *hist = a.hist + 2 * a.hist_stride * ch;
+    float *out = a.out + 2 * a.out_stride * ch;
+    // the pass-major tap table: pass (c, p) at 64 * (2c + p), inside it (jj, rr) at 4 jj + rr
+    const __attribute__((address_space(4))) f32x2 *tq = (const __attribute__((address_space(4))) f32x2 *)a.taps;
+
+    if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && lane < C::HIST) {
+        const long long s = a.n_in - C::HIST + lane;
+        const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
+        reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
+    }
+
+    // HBM -> LDS for one tile: samples [q0 - 32, q0 + 256).  The first and the last 16 chunks are shared with the
+    // neighbouring tiles (plain loads), the 112 in between are this tile's alone (instruction 1 entirely: non-temporal).
+    auto stage = [&](int tile) __attribute__((always_inline)) {
+        const long long q0 = (long long)tile * C::TILE_IN;
+        const bool interior = (q0 >= 32) && (q0 + C::TILE_IN <= a.n_in);
+#pragma unroll
+        for (int i = 0; i < C::NLOAD; ++i) {
+            unsigned cc = 64 * i + lane;
+            cc = cc < (unsigned)C::CHUNKS ? cc : (unsigned)C::CHUNKS - 1u;
+            asm volatile("" : "+v"(cc));
+            const long long s = q0 - 32 + 2 * (long long)cc;
+            if (interior) {
+                const char *src = reinterpret_cast<const char *>(in + 2 * (q0 - 32)) + 16u * cc;
+                // chunks 16 .. CHUNKS - 17 are this tile's alone: with QI = 4 that is all of instruction 1 (non-temporal)
+                if (QI == 4 && i == 1) glds16<2>(src, lds + 64 * i);
+                else glds16(src, lds + 64 * i);
+            } else {
+                // edge tiles (first / last of a call): through registers; a DMA-free tile still issues NLOAD vector memory
+                // operations... it does not: the counted wait below is only used when the staged tile was interior
+                float2 v0, v1;
+                const long long last = a.n_in - 1;
+                if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
+                else v0 = reinterpret_cast<const float2 *>(hist)[s + C::HIST];
+                if (s + 1 >= 0) v1 = reinterpret_cast<const float2 *>(in)[s + 1 <= last ? s + 1 : last];
+                else v1 = reinterpret_cast<const float2 *>(hist)[s + 1 + C::HIST];
+                lds[64 * i + lane] = (f32x4){v0.x, v0.y, v1.x, v1.y};
+            }
+        }
+        return interior;
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.n_tiles) return;
+    stage(tile);
+    bool counted = false;                                       // the staged tile's DMAs sit in front of CPL stores
+    while (true) {
+        // s_waitcnt vmcnt counts loads and stores together, in issue order: with the next tile's three DMAs issued
+        // BEFORE this tile's sixteen stores, "at most 16 outstanding" means the DMAs have landed
+        if (counted) {
+            if constexpr (QI == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const long long q0 = (long long)tile * C::TILE_IN;
+
+        // ---- the lane's window, once: samples q0 + QI g - 32 .. q0 + QI g + QI - 1  ->  image chunks (QI/2) g .. + NWU - 1
+        // (pass p uses chunks 8 - 8p + t, t = 0 .. NW - 1, of these)
+        f32x4 win[C::NWU];
+        {
+            const f32x4 *wp = lds + (QI / 2) * lane;
+#pragma unroll
+            for (int t = 0; t < C::NWU; ++t) win[t] = wp[t];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the image is free: fetch the next tile behind the arithmetic of this one
+        const int next = tile + a.n_groups;
+        counted = false;
+        if (next < a.n_tiles) counted = stage(next);
+
+        // ---- four passes: phase group c (outer), row half p (inner)
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            f32x2 y[QI][4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f32x2 hs[32];
+#pragma unroll
+                for (int m = 0; m < 32; ++m) hs[m] = tq[32 * (2 * c + p) + m];
+                f32x4 wv[C::NW];
+#pragma unroll
+                for (int t = 0; t < C::NW; ++t) wv[t] = win[8 - 8 * p + t];
+                f32x2 acc[QI][4];
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) acc[qi][rr] = (f32x2){0.0f, 0.0f};
+                interp_pass_steps<QI>(std::make_integer_sequence<int, C::NW>{}, wv, hs, acc);
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        if (p == 0) y[qi][rr] = acc[qi][rr];
+                        else y[qi][rr] = (f32x2){__fadd_rn(y[qi][rr].x, acc[qi][rr].x), __fadd_rn(y[qi][rr].y, acc[qi][rr].y)};
+                    }
+            }
+            // phases 4c..4c+3 of the lane's inputs: chunks k = 4 qi + 2c + {0, 1} of its CPL
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi) {
+                const int k = 4 * qi + 2 * c;
+                obuf[C::CPL * lane + (k ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][0].x, y[qi][0].y, y[qi][1].x, y[qi][1].y};
+                obuf[C::CPL * lane + ((k + 1) ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][2].x, y[qi][2].y, y[qi][3].x, y[qi][3].y};
+            }
+        }
+
+        // ---- store: instruction i moves slots 64i .. 64i+63 = the rows of lanes 4i .. 4i+3, each lane the chunk its
+        // slot holds (a permutation inside the 256-byte row): four whole rows per instruction.  Always sixteen store
+        // instructions per tile (lanes past the end of the call sit theirs out): the counted wait relies on it.
+        const long long o0 = q0 * C::L;                         // first output sample of the tile
+        const long long o_end = a.n_in * C::L;
+#pragma unroll
+        for (int i = 0; i < C::CPL; ++i) {
+            const int slot = 64 * i + lane;
+            const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
+            const f32x4 v = obuf[slot];
+            const long long o = o0 + 2 * (C::CPL * g2 + k2);     // two output samples per chunk
+            if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
+        }
+        // the next tile's output writes reuse the buffer only after these reads have returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (next >= a.n_tiles) break;
+        tile = next;
+    }
+}
+
+}  // namespace sxfir

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import sxxcvr_amd
-from sxxcvr_amd.resampler import DECIMATE, KERNEL_TILED
+from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE, KERNEL_TILED
 from gpu_util import assert_bit_exact, to_cpu, to_gpu
 
 pytestmark = pytest.mark.gpu
@@ -165,3 +165,28 @@ def test_cu_queue_variant_multichannel(oracle, monkeypatch, opt):
     got = np.concatenate(outs, axis=1)
     for c in range(nchan):
         assert_bit_exact(got[c], oracle.decim_f32(h, 4, xs[c], 2, 4), "CU queue variant %d channel %d" % (opt, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ipass,oversub", [("0", "4"), ("1", "1"), ("1", "16"), ("4", "4"), ("4", "1")])
+def test_x8_interpolator_forms_match_oracle(oracle, monkeypatch, ipass, oversub):
+    """x8, 256 taps: interp8_pass_kernel (scalar taps; two inputs per lane as shipped, or four) and interp_tile_kernel (taps in
+    VGPRs, SXFIR_IPASS=0) give the oracle's bits: streaming over three calls -- a first tile that takes its history from
+    the plan, interior tiles with the prefetch and its counted wait, a ragged last tile -- and several channels."""
+    import torch
+    for k in KNOBS + ("SXFIR_IPASS",):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_IPASS", ipass)
+    monkeypatch.setenv("SXFIR_OVERSUB", oversub)
+    h = sxxcvr_amd.design_lowpass(256, 8, 8.0, 8.0)
+    nchan, lens = 2, [256 * 300 + 77, 5, 256 * 64]
+    x = np.stack([oracle.synth_iq(0x51255, 30 + c, 0, sum(lens)) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, 8, nchan=nchan, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        outs.append(to_cpu(plan.process(to_gpu(np.ascontiguousarray(x[:, pos:pos + n])))))
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert_bit_exact(y[c], oracle.interp_f32(h, 8, x[c], 2), "x8 form %s channel %d" % (ipass, c))

@@ -31,6 +31,7 @@
 #   kb4q                /4 kernel: persistent workgroups with an LDS tile queue + nt loads against generations of short waves
 #   kb4f                /4 kernel: generations / dispatch order / nt mask around the shipped configuration
 #   kb4wide             /4 kernel: eight outputs per lane + nt loads against the shipped form
+#   ib8p                x8 interpolator: interp8_pass_kernel (scalar taps) against interp_tile_kernel, long visits
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
@@ -114,6 +115,10 @@ for S in "$@"; do
               KB_D=4 KB_ROUNDS=11 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
     kb4ab)    # wide (x) against round 3's form with nt loads (t2s): long runs (100 untimed + 200 timed launches per visit), 7 rounds, both orders
               KB_D=4 KB_ROUNDS=7 KB_ITERS=200 KB_SETTLE=100 timeout 1200 python3 tools/kbench.py x:16:0:0:0:0 t2s:16:0:0:0:0 wident16:16:0:0:0:0 wident32:16:0:0:0:0 widentp24:16:0:0:0:0 t2s:16:0:0:0:16 x:16:0:0:0:16 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    kb4wg)    # the shipped wide kernel: generations (oversub 8 / 16 / 32 / 64) and dispatch order, long visits
+              KB_D=4 KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 1200 python3 tools/kbench.py x:16:0:0:0:0 x:8:0:0:0:0 x:32:0:0:0:0 x:64:0:0:0:0 x:16:0:0:2:0 x:12:0:0:0:0 x:16:0:0:0:16 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    ib8p)     # x8: the scalar-tap pass kernel against the VGPR-tap tile kernel, generations, random and all-zero input
+              timeout 900 python3 tools/ibench2.py pass:4 tile:4 pass4:4 pass:8 pass:16 pass:2 tile:4 pass:4 >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:4 tile:4 pass4:4 pass:16 >> $LOG 2>&1; grep -v amdgpu.ids $LOG | grep "ms med\|checksum\|all-zero" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

@@ -17,7 +17,7 @@ tag, name = sys.argv[1], sys.argv[2]
 configs = sys.argv[3:] or ["2"]
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNELS = {"2": "decim4_", "3rx": "decim_dense_kernel<8", "3tx": "interp_tile_kernel<8", "5": "decim_dense_kernel<32",
+KERNELS = {"2": "decim4_", "3rx": "decim_dense_kernel<8", "3tx": "interp8_pass_kernel", "5": "decim_dense_kernel<32",
            "5h": "decim_multi_kernel<32"}
 BYTES = {"2": 10.0, "3rx": 9.0, "3tx": 9.0, "5": 8.25, "5h": 4.125}
 
