@@ -107,7 +107,13 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
     // the pass-major tap table: pass (c, p) at 64 * (2c + p), inside it (jj, rr) at 4 jj + rr
     const __attribute__((address_space(4))) f32x2 *tq = (const __attribute__((address_space(4))) f32x2 *)a.taps;
 
-    if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && lane < C::HIST) {
+    // Tile schedule: in pass i the G workgroups cover the G consecutive tiles [iG, (i+1)G), dealt so that the workgroups of
+    // one XCD (blockIdx % 8 shares an XCD; speed only) hold a contiguous block of the pass: a tile's 32-sample history is
+    // its neighbour's tail, and the re-read then finds it in that XCD's L2 (dealt round robin, every history re-read went
+    // to HBM: 1.028 x the algorithmic bytes, profiles/round4_3tx_summary.json of the first build)
+    const int G = a.n_groups;
+    const int first_tile = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (first_tile == (a.n_tiles - 1) % G && lane < C::HIST) {
         const long long s = a.n_in - C::HIST + lane;
         const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
         reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         return interior;
     };
 
-    int tile = blockIdx.x;
+    int tile = first_tile;
     if (tile >= a.n_tiles) return;
     stage(tile);
     bool counted = false;                                       // the staged tile's DMAs sit in front of CPL stores
