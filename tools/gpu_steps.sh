@@ -119,6 +119,8 @@ for S in "$@"; do
               KB_D=4 KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 1200 python3 tools/kbench.py x:16:0:0:0:0 x:8:0:0:0:0 x:32:0:0:0:0 x:64:0:0:0:0 x:16:0:0:2:0 x:12:0:0:0:0 x:16:0:0:0:16 >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
     ib8p)     # x8: the scalar-tap pass kernel against the VGPR-tap tile kernel, generations, random and all-zero input
               timeout 900 python3 tools/ibench2.py pass:4 tile:4 pass4:4 pass:8 pass:16 pass:2 tile:4 pass:4 >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:4 tile:4 pass4:4 pass:16 >> $LOG 2>&1; grep -v amdgpu.ids $LOG | grep "ms med\|checksum\|all-zero" ;;
+    kbdg)     # dense kernels (shipped nt mask): generations 4 / 8 / 16 / 32, long visits, /8 and /32
+              for D in 8 32; do KB_D=$D KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 900 python3 tools/kbench.py dense:8:0:0:0 dense:4:0:0:0 dense:16:0:0:0 dense:32:0:0:0 dense:6:0:0:0 dense:8:0:0:0:16 >> $LOG 2>&1; done; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;
