@@ -47,7 +47,7 @@ CONFIGS = {
               kernel="sxfir::decim4_wide_kernel<scalar taps, 8 outputs per lane>",
               name="128-tap polyphase decim-by-4, 1 ch CF32 streaming (BASELINE config 2)"),
     "3rx": dict(mode="decim", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=1.0,
-                kernel="sxfir::decim_dense_kernel<8>",
+                kernel="sxfir::decim_dense_kernel<8, scalar taps: tap subsets on the four waves>",
                 name="256-tap polyphase decim-by-8 RX, 1 ch CF32 streaming (BASELINE config 3, RX half)"),
     "3tx": dict(mode="interp", ntaps=256, ratio=8, fmt="CF32", bytes=8 + 8 / 8, flop=128, gain=8.0,
                 kernel="sxfir::interp8_pass_kernel<2 inputs per lane, scalar taps>",

@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include "sxfir_decim_multi.hip.h"
+#include "sxfir_decim_tile2.hip.h"       // pk_fma_s_lo / pk_fma_s_hi, rgrp_table
 
 namespace sxfir {
 
@@ -87,11 +88,21 @@ __device__ __forceinline__ float butterfly_add(float v)
 // to a group of four (one per wave) -- are plain too: an nt re-read that reaches the L2 first would stream through
 // without leaving the line for the neighbour's plain load, which then fetches it again (1.04 x the algorithmic bytes
 // measured on the /4 kernel).
-template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0>
+// SUBSET (/8, CF32; round 4): the scalar-tap form.  The four (row half p, column group c) tap subsets go to the four
+// WAVES of the workgroup instead of to lane bits: wave ww = 2c + p holds its subset's 64 taps in 32 SGPR pairs (a.taps is
+// then the subset-major table: subset s at 64 s, (jj, rr) at 4 jj + rr) and computes that subset's partial sum of ALL 512
+// outputs of the tile -- lane -> output group G (8 outputs), the same 46 window reads and 512 packed FMAs per lane, one
+// VGPR operand fewer per FMA.  The four partials of an output meet through LDS (the dead image): every wave writes its 512
+// partials, then wave ww sums the four of outputs [128 ww, 128 ww + 128) in the contract's tree, (p0 + p1) per column
+// group, then the column groups, and stores one kilobyte.  Lane -> G is the conflict-free map of the /4 scalar-tap kernel
+// (even groups in the first 16-lane service group of a half-wave, odd groups in the second), which keeps the lanes of a
+// service group on 16 different slots mod 16 with this image's one pad per 16 rows.
+template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0, bool SUBSET = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 decim_dense_kernel(const DecimMultiArgs a)
 {
     using C = DecimDense<D>;
+    static_assert(!SUBSET || (D == 8 && !S32IN && (ABL == 0 || ABL == 1)), "subset form: /8, CF32");
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
     const int tid = threadIdx.x;
@@ -99,9 +110,10 @@ decim_dense_kernel(const DecimMultiArgs a)
     const int ww = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = lane >> 5;
     // the lane maps of the header comment
-    const int p = b4;
-    const int c = D == 32 ? (b3 | (b0 << 1) | (b1 << 2)) : (D == 16 ? (b5 | (b3 << 1)) : b3);
-    const int G = D == 32 ? (b5 | (b2 << 1)) : (D == 16 ? (b0 | (b2 << 1) | (b1 << 2)) : (b5 | (b2 << 1) | (b0 << 2) | (b1 << 3)));
+    const int p = SUBSET ? (ww & 1) : b4;
+    const int c = SUBSET ? (ww >> 1) : (D == 32 ? (b3 | (b0 << 1) | (b1 << 2)) : (D == 16 ? (b5 | (b3 << 1)) : b3));
+    int G = D == 32 ? (b5 | (b2 << 1)) : (D == 16 ? (b0 | (b2 << 1) | (b1 << 2)) : (b5 | (b2 << 1) | (b0 << 2) | (b1 << 3)));
+    if constexpr (SUBSET) G = (int)((rgrp_table((lane & 31) >> 3) >> (5 * (lane & 7))) & 31u) + (lane & 32);
     const int ch = blockIdx.y;
 
     const char *in = reinterpret_cast<const char *>(a.in) + 8LL * a.in_stride * ch;
@@ -109,9 +121,19 @@ decim_dense_kernel(const DecimMultiArgs a)
     char *out = reinterpret_cast<char *>(a.out) + 8LL * a.out_stride * ch;
 
     // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16*p + jj) + 4c + rr
-    f32x2 hp[32];
+    f32x2 hp[SUBSET ? 1 : 32];
+    f32x2 hs[32];
+    if constexpr (SUBSET) {
+        const __attribute__((address_space(4))) f32x2 *tq = (const __attribute__((address_space(4))) f32x2 *)a.taps;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
+        for (int m = 0; m < 32; ++m) hs[m] = tq[32 * ww + m];
+        hp[0] = (f32x2){0.0f, 0.0f};
+    } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) hs[m] = (f32x2){0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < (SUBSET ? 0 : 32); ++k) {
         const float *t = a.taps + D * (16 * p + (k >> 1)) + 4 * c + 2 * (k & 1);
         float t0 = t[0], t1 = t[1];
         if constexpr (S32IN) {                        // a power of two commutes with the FMA
@@ -125,7 +147,7 @@ decim_dense_kernel(const DecimMultiArgs a)
     // slot = chunk + (pads before its row).  The window's three 8-row segments -- steps [0, 16), [16, 32),
     // [32, 46) -- each lie between two pad positions, so a segment has one base: win[r] = chunk 0 of the
     // window + pads before row 8u + 8r.
-    const int u = C::GW * ww + G - 2 * p + 2;
+    const int u = (SUBSET ? 0 : C::GW * ww) + G - 2 * p + 2;
     const f32x4 *win0 = lds + (C::CPR * 8 * u + C::CPR - 2 - 2 * c + (8 * u) / C::PADROWS);
     const f32x4 *win1 = win0 + ((8 * u + 8) / C::PADROWS - (8 * u) / C::PADROWS);
     const f32x4 *win2 = win0 + ((8 * u + 16) / C::PADROWS - (8 * u) / C::PADROWS);
@@ -227,8 +249,13 @@ decim_dense_kernel(const DecimMultiArgs a)
                 for (int i = 0; i < 8; ++i) {
                     const int kl = 4 * i + 63 - w;
                     if (kl >= 0 && kl < 64) {
-                        if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
-                        else pk_fma_lo(acc[i], hp[kl >> 1], x);
+                        if constexpr (SUBSET) {
+                            if (kl & 1) pk_fma_s_hi(acc[i], hs[kl >> 1], x);
+                            else pk_fma_s_lo(acc[i], hs[kl >> 1], x);
+                        } else {
+                            if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
+                            else pk_fma_lo(acc[i], hp[kl >> 1], x);
+                        }
                     }
                 }
             }
@@ -240,6 +267,38 @@ decim_dense_kernel(const DecimMultiArgs a)
         if constexpr (ABL == 3) asm volatile("" ::"v"(ai[0]), "v"(aq[7]));
         SXFIR_PHASE(3)
         __syncthreads();                                    // everyone is done reading this tile's image
+        if constexpr (SUBSET) {
+            // the four subsets' partials meet in the dead image: subset s at 256 s; chunk k (two outputs) of group G at slot
+            // 4G + (k ^ ((G >> 1) & 3)): the eight lanes a ds_write_b128 is served with hit eight different slots mod 8
+            // (unswizzled: 96 conflict cycles per wave and tile, measured), the read-back below is linear
+            if constexpr (ABL != 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[256 * ww + 4 * G + (k ^ ((G >> 1) & 3))] = (f32x4){acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y};
+            }
+            __syncthreads();
+            f32x4 y;
+            {
+                const f32x4 v0 = lds[64 * ww + lane], v1 = lds[256 + 64 * ww + lane], v2 = lds[512 + 64 * ww + lane],
+                            v3 = lds[768 + 64 * ww + lane];
+                // (p0 + p1) of column group 0, (p0 + p1) of column group 1, then the two: the contract's tree
+                f32x4 s01, s23;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s01[e] = __fadd_rn(v0[e], v1[e]); s23[e] = __fadd_rn(v2[e], v3[e]); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(s01[e], s23[e]);
+            }
+            __syncthreads();                                // the exchange area may be overwritten by the next DMA
+            if (tile + NG < a.n_tiles) stage(tile + NG);
+            // the slot this lane read holds chunk kq of group Gq: a permutation inside each 64-byte group, so the wave's
+            // store still covers one kilobyte of consecutive bytes
+            const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
+            const long long m = M0 + 8 * Gq + 2 * kq;
+            char *dst = out + 8 * m;
+            if (m + 2 <= a.n_out) __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(dst));
+            else if (m < a.n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(y.x, y.y);
+            continue;
+        }
         if (tile + NG < a.n_tiles) stage(tile + NG);
         SXFIR_PHASE(4)
 

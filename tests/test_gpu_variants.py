@@ -190,3 +190,27 @@ def test_x8_interpolator_forms_match_oracle(oracle, monkeypatch, ipass, oversub)
     y = np.concatenate(outs, axis=1)
     for c in range(nchan):
         assert_bit_exact(y[c], oracle.interp_f32(h, 8, x[c], 2), "x8 form %s channel %d" % (ipass, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset", ["1", "0"])
+@pytest.mark.parametrize("nchan,lens", [(1, [512 * 40 + 8 * 3, 8 * 5, 512 * 9]), (3, [512 * 7 + 8 * 77, 1 << 17])])
+def test_div8_forms_match_oracle(oracle, monkeypatch, nchan, lens, subset):
+    """/8, 256 taps, CF32: decim_dense_kernel<8, ..., SUBSET> (the shipped form: the four tap subsets on the four waves,
+    taps in SGPRs, partial sums exchanged through LDS) and the VGPR-tap form (SXFIR_DENSE_SUBSET=0) give the oracle's
+    bits: streaming over several calls with ragged tails and several channels."""
+    for k in KNOBS + ("SXFIR_DENSE_SUBSET",):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_DENSE_SUBSET", subset)
+    h = sxxcvr_amd.design_lowpass(256, 8)
+    total = sum(lens)
+    x = np.stack([oracle.synth_iq(0x51255, 40 + c, 0, 8 * total) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 8, nchan=nchan, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        outs.append(to_cpu(plan.process(to_gpu(np.ascontiguousarray(x[:, 8 * pos:8 * (pos + n)])))))
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert_bit_exact(y[c], oracle.decim_f32(h, 8, x[c], 2, 4), "/8 subset form, channel %d" % c)

@@ -121,6 +121,11 @@ for S in "$@"; do
               timeout 900 python3 tools/ibench2.py pass:4 tile:4 pass4:4 pass:8 pass:16 pass:2 tile:4 pass:4 >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:4 tile:4 pass4:4 pass:16 >> $LOG 2>&1; grep -v amdgpu.ids $LOG | grep "ms med\|checksum\|all-zero" ;;
     kbdg)     # dense kernels (shipped nt mask): generations 4 / 8 / 16 / 32, long visits, /8 and /32
               for D in 8 32; do KB_D=$D KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 900 python3 tools/kbench.py dense:8:0:0:0 dense:4:0:0:0 dense:16:0:0:0 dense:32:0:0:0 dense:6:0:0:0 dense:8:0:0:0:16 >> $LOG 2>&1; done; RC=$?; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped" ;;
+    kb8s)     # /8: the scalar-tap subset form against the shipped dense kernel, long visits; memory sides; all-zero input
+              KB_D=8 KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 900 python3 tools/kbench.py densev:8:0:0:0 dense:8:0:0:0 dense:4:0:0:0 dense:16:0:0:0 densev:8:0:0:0:16 dense:8:0:0:0:16 >> $LOG 2>&1; RC=$?
+              KB_ZERO=1 KB_D=8 KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py dense:8:0:0:0 subset:8:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped\|checksum\|all-zero" ;;
+    pmc8s)    # LDS / VALU counters of the /8 subset form against the shipped dense kernel
+              for V in 0 1; do SXFIR_DENSE_SUBSET=$V SXFIR_PROF=1 bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" 8 CF32 28 >> $LOG 2>&1; done; RC=$?; grep -v amdgpu.ids $LOG | tail -3 ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;
