@@ -827,6 +827,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1 and args.config != "2":
         raise SystemExit("the multi-GPU layout (BASELINE config 4) runs --config 2's filter")
+    if world > 1 and args.gather == "capi" and host_collectives:
+        raise SystemExit("--gather capi is RCCL itself (sxfir_comm_* over librccl): it needs one GPU per rank, not the gloo stand-in")
     dev = torch.device("cuda", gpu_index)
     cdev = torch.device("cpu") if host_collectives else dev
     backend_name = dist.get_backend() if world > 1 else None

@@ -120,9 +120,16 @@ int sxfir_comm_init_all(sxfir_comm **comms, int ndev, const int *devices)
     for (int i = 0; i < ndev; ++i) devs[i] = devices ? devices[i] : i;
     ncclComm_t c[64];
     RCCLCHECK(R, R->CommInitAll(c, ndev, devs));
+    for (int i = 0; i < ndev; ++i) comms[i] = new (std::nothrow) sxfir_comm{c[i], i, ndev, devs[i]};
     for (int i = 0; i < ndev; ++i) {
-        comms[i] = new (std::nothrow) sxfir_comm{c[i], i, ndev, devs[i]};
-        if (!comms[i]) return fail(SXFIR_ENOMEM, "out of memory");
+        if (comms[i]) continue;
+        // all or nothing: no half-initialised set of communicators is handed back
+        for (int k = 0; k < ndev; ++k) {
+            R->CommDestroy(c[k]);
+            delete comms[k];
+            comms[k] = nullptr;
+        }
+        return fail(SXFIR_ENOMEM, "out of memory");
     }
     return SXFIR_OK;
 }

@@ -158,6 +158,16 @@ def test_bench_two_ranks_gather_through_the_c_abi():
     assert g["overlapped"]["root_holds_own_channels"] is True and g["overlapped_value"] > 0
 
 
+def test_bench_refuses_the_c_abi_gather_over_the_gloo_stand_in():
+    """--gather capi is RCCL itself: with ranks sharing a GPU (the gloo stand-in) it must refuse, not hang in ncclCommInitRank."""
+    e = dict(os.environ, SXFIR_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gather", "capi"] + SMALL,
+                         capture_output=True, text=True, timeout=300, env=e)
+    assert run.returncode != 0 and "one GPU per rank" in (run.stdout + run.stderr)
+
+
 def test_bench_refuses_mismatched_world():
     e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True,
