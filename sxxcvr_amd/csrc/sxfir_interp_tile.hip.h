@@ -102,14 +102,19 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
     // window: samples q0 + 4g - 16p - 16 + w, w = 0..19  ->  LDS sample index (+32) 4g - 16p + 16 + w
     const f32x4 *win = lds + (2 * g - 8 * p + 8);
 
-    if (blockIdx.x == (unsigned)((a.n_tiles - 1) % a.n_groups) && lane < C::HIST) {
+    // Tiles are dealt XCD-blocked, as in interp8_pass_kernel: in pass i the G workgroups cover tiles [iG, (i+1)G), the
+    // workgroups of one XCD (blockIdx % 8; speed only) a contiguous block of them, so that a tile's 32-sample history --
+    // its neighbour's tail -- is found in that XCD's L2 (dealt round robin the re-reads went to HBM: 1.014 x the bytes)
+    const int NGR = a.n_groups;
+    const int first_tile = (NGR % 8 == 0) ? (int)(blockIdx.x % 8) * (NGR / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (first_tile == (a.n_tiles - 1) % NGR && lane < C::HIST) {
         const long long s = a.n_in - C::HIST + lane;
         const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
                                 : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
         reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
     }
 
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.n_groups) {
+    for (int tile = first_tile; tile < a.n_tiles; tile += a.n_groups) {
         const long long q0 = (long long)tile * C::TILE_IN;
         const bool interior = (q0 >= 32) && (q0 + C::TILE_IN <= a.n_in);
         // ---- stage samples [q0 - 32, q0 + TILE_IN) ----------------------------
