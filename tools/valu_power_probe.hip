@@ -106,16 +106,17 @@ int main() {
   CK(hipMemcpy(taps, h, 512, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int tiles = 256;                   // per wave and launch: one launch = the FIR work of one bench step
-  const char* names[12] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
+  const char* names[13] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
                           "VGPR taps + 47 ds_read_b128 per tile (first-generation kernel's mix)", "SGPR taps + 47 ds_read_b128 per tile",
                           "SGPR taps + 71 ds_read_b128 per tile (shipped scalar kernel's mix)", "SGPR taps + 39 ds_read_b128 per tile",
                           "VGPR taps + 71 ds_read_b128 per tile",
                           "VGPR taps + 46 ds_read_b128 per 512 FMAs (dense /32, /8 today)",
                           "SGPR taps + 76 ds_read_b128 per 512 FMAs (16 SGPR-tap passes over the /32 tile: 38 per 256)",
                           "VGPR taps + 20 ds_read_b128 per 512 FMAs (the interpolator today: 10 per 256)",
-                          "SGPR taps + 20 ds_read_b128 per 512 FMAs (the interpolator with in-lane (p, c) passes)"};
+                          "SGPR taps + 20 ds_read_b128 per 512 FMAs (the interpolator with in-lane (p, c) passes)",
+                          "VGPR taps + 31 ds_read_b128 per 512 FMAs (a dense /32 kernel with 16 outputs per lane: 62 per 1024)"};
   for (int rep = 0; rep < 2; ++rep)
-    for (int mode = 0; mode < 12; ++mode) {
+    for (int mode = 0; mode < 13; ++mode) {
       auto launch = [&] {
         switch (mode) {
           case 0: hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
@@ -129,7 +130,8 @@ int main() {
           case 8: hipLaunchKernelGGL((probe<0, 46>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 9: hipLaunchKernelGGL((probe<1, 76>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 10: hipLaunchKernelGGL((probe<0, 20>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
-          default: hipLaunchKernelGGL((probe<1, 20>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 11: hipLaunchKernelGGL((probe<1, 20>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          default: hipLaunchKernelGGL((probe<0, 31>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
         }
       };
       for (int i = 0; i < 300; ++i) launch();          // ~100 ms: let the clocks settle on this load
