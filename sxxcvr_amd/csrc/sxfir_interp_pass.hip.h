@@ -136,8 +136,8 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
                 if (QI == 4 && i == 1) glds16<2>(src, lds + 64 * i);
                 else glds16(src, lds + 64 * i);
             } else {
-                // edge tiles (first / last of a call): through registers; a DMA-free tile still issues NLOAD vector memory
-                // operations... it does not: the counted wait below is only used when the staged tile was interior
+                // edge tiles (first / last of a call): through registers and plain LDS writes; stage() then returns false
+                // and the caller waits with vmcnt(0) instead of the counted form, which presumes NLOAD DMA instructions
                 float2 v0, v1;
                 const long long last = a.n_in - 1;
                 if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
