@@ -40,6 +40,10 @@ def load_sxfir(profiling=False):
     elif _sxfir is not None:
         return _sxfir
     path = os.path.join(LIBDIR, "libsxfir_prof.so" if profiling else "libsxfir.so")
+    if profiling and os.environ.get("SXFIR_PROF_LIB"):
+        # tools only (tools/prev_lib.sh): a profiling library built from another commit, for before / after timings
+        # on the same box; the product library's path is never taken from the environment
+        path = os.environ["SXFIR_PROF_LIB"]
     if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build the HIP extension first (python -m sxxcvr_amd.build). "

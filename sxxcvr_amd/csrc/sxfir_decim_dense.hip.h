@@ -117,7 +117,6 @@ decim_dense_kernel(const DecimMultiArgs a)
     const int ch = blockIdx.y;
 
     const char *in = reinterpret_cast<const char *>(a.in) + 8LL * a.in_stride * ch;
-    const char *hist = reinterpret_cast<const char *>(a.hist) + 8LL * a.hist_stride * ch;
     char *out = reinterpret_cast<char *>(a.out) + 8LL * a.out_stride * ch;
 
     // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16*p + jj) + 4c + rr
@@ -153,16 +152,33 @@ decim_dense_kernel(const DecimMultiArgs a)
     const f32x4 *win2 = win0 + ((8 * u + 16) / C::PADROWS - (8 * u) / C::PADROWS);
 
     const int NG = a.n_groups;
+    // 32-bit tile bounds instead of 64-bit sample arithmetic per tile: tiles [1, tile_hi] lie wholly inside this call's
+    // input (tile 0 reaches into the history), tiles below n_full store all TILE_OUT outputs
+    constexpr int LOG_T = C::TILE_OUT == 512 ? 9 : (C::TILE_OUT == 256 ? 8 : 7);
+    constexpr int LOG_D = D == 32 ? 5 : (D == 16 ? 4 : 3);
+    static_assert((1 << LOG_T) == C::TILE_OUT && (1 << LOG_D) == D, "powers of two");
+    const long long q_hi = a.n_in > 0 ? ((a.n_in - 1) >> LOG_D) + 1 - C::TILE_OUT : -1;
+    const int tile_hi = q_hi < 0 ? -1 : (int)(q_hi >> LOG_T);
+    const int n_full = (int)(a.n_out >> LOG_T);
     const int first_tile = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     // fused history carry-over (as decim_multi_kernel): the tail of (hist ++ in) becomes the next history
     if (first_tile == (a.n_tiles - 1) % NG && ww == C::W - 1) {
         char *ho = reinterpret_cast<char *>(a.hist_out) + 8LL * a.hist_stride * ch;
         for (int j = lane; j < C::NT; j += 64) {
             const long long s = a.n_in - C::NT + j;
-            const char *src = s >= 0 ? in + 8 * s : hist + 8 * (s + C::NT);
+            const char *src = s >= 0 ? in + 8 * s : reinterpret_cast<const char *>(a.hist) + 8LL * a.hist_stride * ch + 8 * (s + C::NT);
             reinterpret_cast<float2 *>(ho)[j] = *reinterpret_cast<const float2 *>(src);
         }
     }
+
+    // the kernel arguments as they lie in the kernarg segment, through a pointer the compiler cannot see through: a load
+    // from it stays where it is written (the rare paths of the tile loop)
+    auto rare_args = [&]() __attribute__((always_inline)) {
+        const __attribute__((address_space(4))) DecimMultiArgs *ap =
+            (const __attribute__((address_space(4))) DecimMultiArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        return ap;
+    };
 
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, tk = 0;
     if constexpr (ABL == 3) tk = __builtin_amdgcn_s_memtime();
@@ -181,7 +197,7 @@ decim_dense_kernel(const DecimMultiArgs a)
     auto stage = [&](int tile) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         const long long s_first = D * (M0 - 31) - (D - 1);               // first sample of the image
-        const bool interior = s_first >= 0 && D * (M0 + C::TILE_OUT - 1) <= a.n_in - 1;
+        const bool interior = tile >= 1 && tile <= tile_hi;
         const char *base = in + 8 * s_first + 1024 * ww;
         if constexpr (ABL == 2) return;
         if (interior) {
@@ -193,7 +209,9 @@ decim_dense_kernel(const DecimMultiArgs a)
                 asm volatile("" : "+s"(bi));          // ... and the instruction's own base stays a scalar
                 const int i = ww + 4 * i0;
                 // the image's last instruction is only partly inside it
-                if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES)) {
+                // (all but a wave's last instruction lie inside it whatever the wave: decided at compile time)
+                static_assert(4 * (C::NIW - 2) + C::W - 1 < C::NI - 1, "only i0 = NIW - 1 can reach the end of the image");
+                if (i0 < C::NIW - 1 || i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES)) {
                     static_assert(C::TILE_OUT / C::RPI == 32, "the halo rows start at DMA instruction 32");
                     constexpr int FIRST_NT = NTLD == 2 ? (31 / C::RPI + 4) / 4 : 0;   // i0 below this: the halo re-read, plain
                     if (NTLD && i0 >= FIRST_NT && i0 < 8) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));   // i = ww + 4 i0 < 32
@@ -201,8 +219,11 @@ decim_dense_kernel(const DecimMultiArgs a)
                 }
             }
         } else {
-            // edge tiles (first / last of a call): through registers, sample by sample
-            const long long last = a.n_in - 1;
+            // edge tiles (first / last of a call): through registers, sample by sample.  What only they need is read
+            // from the kernel arguments here, not kept in registers across the tile loop.
+            const auto *ap = rare_args();
+            const long long last = ap->n_in - 1;
+            const char *hist = reinterpret_cast<const char *>(ap->hist) + 8LL * ap->hist_stride * ch;
 #pragma nounroll
             for (int i0 = 0; i0 < C::NIW; ++i0) {
                 const int i = ww + 4 * i0;
@@ -295,8 +316,13 @@ decim_dense_kernel(const DecimMultiArgs a)
             const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
             const long long m = M0 + 8 * Gq + 2 * kq;
             char *dst = out + 8 * m;
-            if (m + 2 <= a.n_out) __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(dst));
-            else if (m < a.n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(y.x, y.y);
+            if (tile < n_full) {
+                __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(dst));
+            } else {
+                const long long n_out = rare_args()->n_out;     // the call's last tile
+                if (m + 2 <= n_out) __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(dst));
+                else if (m < n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(y.x, y.y);
+            }
             continue;
         }
         if (tile + NG < a.n_tiles) stage(tile + NG);
@@ -326,8 +352,13 @@ decim_dense_kernel(const DecimMultiArgs a)
             const long long m = mg + 2 * b5;
             if (b3 == 0) {
                 char *dst = out + 8 * m;
-                if (m + 2 <= a.n_out) __builtin_nontemporal_store((f32x4){si[0], sq[0], si[1], sq[1]}, reinterpret_cast<f32x4 *>(dst));
-                else if (m < a.n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(si[0], sq[0]);
+                if (tile < n_full) {
+                    __builtin_nontemporal_store((f32x4){si[0], sq[0], si[1], sq[1]}, reinterpret_cast<f32x4 *>(dst));
+                } else {
+                    const long long n_out = rare_args()->n_out;
+                    if (m + 2 <= n_out) __builtin_nontemporal_store((f32x4){si[0], sq[0], si[1], sq[1]}, reinterpret_cast<f32x4 *>(dst));
+                    else if (m < n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(si[0], sq[0]);
+                }
             }
         } else {
             // column groups by butterflies: /32: c0 = bit 3, c1 = bit 0, c2 = bit 1; /8: c0 = bit 3
@@ -357,8 +388,13 @@ decim_dense_kernel(const DecimMultiArgs a)
                 const float s0 = sel ? ri[2] : ri[0], s1 = sel ? rq[2] : rq[0];
                 const float s2 = sel ? ri[3] : ri[1], s3 = sel ? rq[3] : rq[1];
                 char *dst = out + 8 * m;
-                if (m + 2 <= a.n_out) __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
-                else if (m < a.n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(s0, s1);
+                if (tile < n_full) {
+                    __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
+                } else {
+                    const long long n_out = rare_args()->n_out;
+                    if (m + 2 <= n_out) __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
+                    else if (m < n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(s0, s1);
+                }
             }
         }
         if constexpr (ABL == 3) ph[0] += 1;

@@ -121,23 +121,33 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
 
     // HBM -> LDS for one tile: samples [q0 - 32, q0 + 256).  The first and the last 16 chunks are shared with the
     // neighbouring tiles (plain loads), the 112 in between are this tile's alone (instruction 1 entirely: non-temporal).
+    // 32-bit tile bounds instead of 64-bit sample arithmetic per tile: tiles below n_full have all their TILE_IN inputs
+    // (and store all their outputs), of those all but tile 0 have their history inside this call's input
+    static_assert(C::TILE_IN >= C::HIST && (C::TILE_IN & (C::TILE_IN - 1)) == 0, "tile 0 is the only one that reaches into the history");
+    const int n_full = (int)(a.n_in / C::TILE_IN);
     auto stage = [&](int tile) __attribute__((always_inline)) {
         const long long q0 = (long long)tile * C::TILE_IN;
-        const bool interior = (q0 >= 32) && (q0 + C::TILE_IN <= a.n_in);
+        const bool interior = tile >= 1 && tile < n_full;
+        if (interior) {
 #pragma unroll
-        for (int i = 0; i < C::NLOAD; ++i) {
-            unsigned cc = 64 * i + lane;
-            cc = cc < (unsigned)C::CHUNKS ? cc : (unsigned)C::CHUNKS - 1u;
-            asm volatile("" : "+v"(cc));
-            const long long s = q0 - 32 + 2 * (long long)cc;
-            if (interior) {
+            for (int i = 0; i < C::NLOAD; ++i) {
+                unsigned cc = 64 * i + lane;
+                cc = cc < (unsigned)C::CHUNKS ? cc : (unsigned)C::CHUNKS - 1u;
+                asm volatile("" : "+v"(cc));
                 const char *src = reinterpret_cast<const char *>(in + 2 * (q0 - 32)) + 16u * cc;
                 // chunks 16 .. CHUNKS - 17 are this tile's alone: with QI = 4 that is all of instruction 1 (non-temporal)
                 if (QI == 4 && i == 1) glds16<2>(src, lds + 64 * i);
                 else glds16(src, lds + 64 * i);
-            } else {
-                // edge tiles (first / last of a call): through registers and plain LDS writes; stage() then returns false
-                // and the caller waits with vmcnt(0) instead of the counted form, which presumes NLOAD DMA instructions
+            }
+        } else {
+            // edge tiles (first / last of a call): through registers and plain LDS writes; stage() then returns false
+            // and the caller waits with vmcnt(0) instead of the counted form, which presumes NLOAD DMA instructions
+#pragma unroll
+            for (int i = 0; i < C::NLOAD; ++i) {
+                unsigned cc = 64 * i + lane;
+                cc = cc < (unsigned)C::CHUNKS ? cc : (unsigned)C::CHUNKS - 1u;
+                asm volatile("" : "+v"(cc));
+                const long long s = q0 - 32 + 2 * (long long)cc;
                 float2 v0, v1;
                 const long long last = a.n_in - 1;
                 if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
@@ -218,14 +228,28 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         // slot holds (a permutation inside the 256-byte row): four whole rows per instruction.  Always sixteen store
         // instructions per tile (lanes past the end of the call sit theirs out): the counted wait relies on it.
         const long long o0 = q0 * C::L;                         // first output sample of the tile
-        const long long o_end = a.n_in * C::L;
+        if (tile < n_full) {
+            // all CPL reads in flight, then CPL stores back to back (decided per wave, not per lane and store)
+            f32x4 v[C::CPL];
 #pragma unroll
-        for (int i = 0; i < C::CPL; ++i) {
-            const int slot = 64 * i + lane;
-            const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
-            const f32x4 v = obuf[slot];
-            const long long o = o0 + 2 * (C::CPL * g2 + k2);     // two output samples per chunk
-            if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
+            for (int i = 0; i < C::CPL; ++i) v[i] = obuf[64 * i + lane];
+#pragma unroll
+            for (int i = 0; i < C::CPL; ++i) {
+                const int slot = 64 * i + lane;
+                const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
+                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(out + 2 * (o0 + 2 * (C::CPL * g2 + k2))));
+            }
+        } else {
+            // the call's last tile (no counted wait follows it: the wave ends here)
+            const long long o_end = a.n_in * C::L;
+#pragma unroll
+            for (int i = 0; i < C::CPL; ++i) {
+                const int slot = 64 * i + lane;
+                const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
+                const f32x4 v = obuf[slot];
+                const long long o = o0 + 2 * (C::CPL * g2 + k2);     // two output samples per chunk
+                if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
+            }
         }
         // the next tile's output writes reuse the buffer only after these reads have returned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -35,6 +35,8 @@
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
+#   ibprev              x8 interpolator: the same before / after for interp8_pass_kernel
+#   kbprev:D[,variant[,fmt]]  the previous commit's profiling library (tools/prev_lib.sh) against this tree's, alternating processes
 # Every step's exit status is recorded (rc=N in its log and on stdout); the script exits non-zero if any step
 # failed or was unknown, so `gpurun -- 'bash tools/gpu_steps.sh ...'` reports a failing GPU suite.
 set -u -o pipefail
@@ -126,6 +128,20 @@ for S in "$@"; do
               KB_ZERO=1 KB_D=8 KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py dense:8:0:0:0 subset:8:0:0:0 >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped\|checksum\|all-zero" ;;
     pmc8s)    # LDS / VALU counters of the /8 subset form against the shipped dense kernel
               for V in 0 1; do SXFIR_DENSE_SUBSET=$V SXFIR_PROF=1 bash tools/pmc_pass.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" 8 CF32 28 >> $LOG 2>&1; done; RC=$?; grep -v amdgpu.ids $LOG | tail -3 ;;
+    kbprev)   # before / after on one box: the profiling library of another commit (tools/prev_lib.sh) against this tree's, alternating
+              # processes, long visits.  kbprev:D[,variant[,fmt]]  (variant default "dense:8:0:0:0")
+              IFS=, read -r PD PV PF <<< "$ARG"; PD=${PD:-8}; PV=${PV:-dense:8:0:0:0}; PF=${PF:-CF32}
+              echo "# previous = $(cat sxxcvr_amd/lib/prev/REV)" >> $LOG
+              for R in 1 2 3; do
+                echo "# previous" >> $LOG; SXFIR_PROF_LIB=$PWD/sxxcvr_amd/lib/prev/libsxfir_prof.so KB_FMT=$PF KB_D=$PD KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py $PV >> $LOG 2>&1 || RC=$?
+                echo "# this tree" >> $LOG; KB_FMT=$PF KB_D=$PD KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py $PV >> $LOG 2>&1 || RC=$?
+              done; grep -v "amdgpu.ids" $LOG | grep "^#\|ms med\|skipped" ;;
+    ibprev)   # x8 interpolator, previous commit's profiling library against this tree's (as kbprev)
+              echo "# previous = $(cat sxxcvr_amd/lib/prev/REV)" >> $LOG
+              for R in 1 2 3; do
+                echo "# previous" >> $LOG; SXFIR_PROF_LIB=$PWD/sxxcvr_amd/lib/prev/libsxfir_prof.so KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:8 >> $LOG 2>&1 || RC=$?
+                echo "# this tree" >> $LOG; KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:8 >> $LOG 2>&1 || RC=$?
+              done; grep -v "amdgpu.ids" $LOG | grep "^#\|ms med\|skipped" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;
