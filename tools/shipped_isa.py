@@ -62,7 +62,8 @@ def kernels(lib=None):
                   "global_load_lds_dwordx4": cnt(r"global_load_lds_dwordx4$"),
                   "global_load_lds_dwordx4_nt": len(re.findall(r"global_load_lds_dwordx4[^\n]*\bnt\b", body)),
                   "s_barrier": cnt(r"s_barrier$"), "v_mfma": cnt(r"v_mfma"), "dpp_or_permlane": len(re.findall(r"_dpp|v_permlane", body)),
-                  "s_load_dwordx16": cnt(r"s_load_dwordx16$")})
+                  "s_load_dwordx16": cnt(r"s_load_dwordx16$"), "instructions": len(ops),
+                  "valu": cnt(r"v_"), "sgpr_spill_lane_ops": cnt(r"v_(read|write)lane_b32$")})
         fm = re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], (s\[\d+:\d+\]), (v\[\d+:\d+\])", body)
         if len(fm) > 1:
             r["scalar_tap_fmas"] = len(fm)
@@ -78,9 +79,9 @@ if __name__ == "__main__":
     if "--json" in sys.argv:
         print(json.dumps(rows, indent=1))
     else:
-        print("%-5s %-5s %-6s %-7s %-6s %-5s %-8s %-5s %-5s %-6s kernel" % ("VGPR", "SGPR", "LDS", "scratch", "pkfma", "ds128", "dma(nt)", "barr", "mfma", "xshare"))
+        print("%-5s %-5s %-6s %-7s %-6s %-5s %-8s %-5s %-5s %-6s %-6s %-5s %-5s kernel" % ("VGPR", "SGPR", "LDS", "scratch", "pkfma", "ds128", "dma(nt)", "barr", "mfma", "xshare", "instr", "valu", "spill"))
         for r in sorted(rows, key=lambda r: r["name"]):
-            print("%-5d %-5d %-6d %-7d %-6d %-5d %-8s %-5d %-5d %-6s %s" % (
+            print("%-5d %-5d %-6d %-7d %-6d %-5d %-8s %-5d %-5d %-6s %-6d %-5d %-5d %s" % (
                 r["vgpr"], r["sgpr"], r["lds_bytes"], r["scratch_bytes"], r["v_pk_fma_f32"], r["ds_read_b128"],
                 "%d(%d)" % (r["global_load_lds_dwordx4"], r["global_load_lds_dwordx4_nt"]), r["s_barrier"], r["v_mfma"],
-                r.get("adjacent_fmas_sharing_sample_pair", "-"), r["name"]))
+                r.get("adjacent_fmas_sharing_sample_pair", "-"), r["instructions"], r["valu"], r["sgpr_spill_lane_ops"], r["name"]))
