@@ -53,7 +53,7 @@ CONFIGS = {
                 kernel="sxfir::interp8_pass_kernel<2 inputs per lane, scalar taps>",
                 name="256-tap polyphase interp-by-8 TX, 1 ch CF32 streaming (BASELINE config 3, TX half)"),
     "3": dict(mode="duplex", ntaps=256, ratio=8, fmt="CF32", bytes=9.0, flop=128, gain=1.0,
-              kernel="sxfir::decim_dense_kernel<8> + sxfir::interp_tile_kernel<8> on two streams",
+              kernel="sxfir::decim_dense_kernel<8> + sxfir::interp8_pass_kernel<2> on two streams",
               name="full-duplex 256-tap decim-8 RX + interp-8 TX (read+writeStream), timestamp-latency check "
                    "(BASELINE config 3)"),
     "5": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF32", bytes=8 + 8 / 32, flop=128, gain=1.0,
