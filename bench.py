@@ -123,6 +123,7 @@ class BoardSampler:
         self.gpu_index, self.period = gpu_index, period_s
         self.samples, self.cap_w, self.source, self.error = [], None, None, None
         self._stop = threading.Event()
+        self._ready = threading.Event()          # telemetry opened (or given up on): the sampled loop may start
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _open(self):
@@ -174,7 +175,10 @@ class BoardSampler:
         return read
 
     def _run(self):
-        read = self._open()
+        try:
+            read = self._open()
+        finally:
+            self._ready.set()
         if read is None:
             return
         while not self._stop.is_set():
@@ -185,8 +189,11 @@ class BoardSampler:
                 return
             self._stop.wait(self.period)
 
-    def start(self):
+    def start(self, wait_s=20.0):
+        # the first amdsmi_init() on a fresh box can take longer than the sampled loop runs (a driver-style run once
+        # came back with "no samples"): wait until the telemetry is open, bounded
         self._thread.start()
+        self._ready.wait(wait_s)
 
     def stop(self):
         self._stop.set()

@@ -126,6 +126,7 @@ struct sxfir_plan {
     int wide_nb;           // (profiling) its LDS read-ahead depth: 0 = default
     bool wide_nt;          // (profiling) "wident...": with non-temporal staging loads
     bool wide_pin;         // (profiling) "widentp...": and the FMA issue order pinned (volatile asm)
+    int wide_pol;          // (profiling) SXFIR_WIDE_POL: cache policy of its nt loads (low byte) and stores (next byte)
     int occ_wide;
     int compute_units;
     float *taps_dev;
@@ -288,6 +289,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->wide = false;
     p->wide_nt = false;
     p->wide_pin = false;
+    p->wide_pol = 0;
     p->wide_nb = 0;
     p->occ_wide = 8;
     p->occ_multi = 2;
@@ -414,6 +416,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                 p->wide_nt = strncmp(v, "wident", 6) == 0;
                 p->wide_pin = strncmp(v, "widentp", 7) == 0;
                 p->wide_nb = atoi(v + (p->wide_pin ? 7 : (p->wide_nt ? 6 : 4)));
+                // "widepol<hex>": the shipped build (wident24) with another cache policy (sxfir_decim_wide.hip.h, POL)
+                if (strncmp(v, "widepol", 7) == 0) {
+                    p->wide_nt = true;
+                    p->wide_nb = 24;
+                    p->wide_pol = (int)strtol(v + 7, nullptr, 16);
+                }
             }
             // "pair": decim4_pair_kernel (sxfir_decim_pair.hip.h)
             if (strncmp(v, "pair", 4) == 0 && ntaps == 128) {

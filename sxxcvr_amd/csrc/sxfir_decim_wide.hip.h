@@ -112,7 +112,19 @@ __device__ __forceinline__ void fir_wide_steps(std::integer_sequence<int, Cs...>
 // ticks, XCC_ID | HW_ID << 8).
 // NTL (round 4): DMA instructions 1..16 -- the rows no other tile reads -- are non-temporal loads; 0 (the re-read of the
 // previous tile's last kilobyte) and 17, 18 (this tile's last kilobyte, the next tile's halo) stay plain.
-template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false>
+// POL (profiling: which cache policy costs the least energy per byte at the power cap): low byte = policy bits OR-ed into
+// the nt staging loads (1 = sc0, 16 = sc1), next byte = the stores: 0 nt (shipped), 1 plain, 2 sc0 sc1, 3 sc0 sc1 nt, 4 sc1.
+template <int STP>
+__device__ __forceinline__ void store16_policy(f32x4 v, f32x4 *dst)
+{
+    if constexpr (STP == 0) __builtin_nontemporal_store(v, dst);
+    else if constexpr (STP == 1) *dst = v;
+    else if constexpr (STP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+    else if constexpr (STP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+
+template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false, int POL = 0>
 __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
 {
     using C = DecimWide;
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
                 unsigned bo = boff[j];
                 asm volatile("" : "+v"(bo));             // 32-bit offset next to its use (see stage_tile)
                 if (j < C::NI - 1 || lane < C::LASTL) {
-                    if (NTL && j >= 1 && j <= 16) glds16<2>(src + bo, img + 64 * j);
+                    if (NTL && j >= 1 && j <= 16) glds16<2 | (POL & 0xFF)>(src + bo, img + 64 * j);
                     else glds16(src + bo, img + 64 * j);
                 }
             }
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 v = img[68 * k + lane + (lane >> 4)];
-                __builtin_nontemporal_store(v, dst + 64 * k + lane);
+                store16_policy<(POL >> 8)>(v, dst + 64 * k + lane);
             }
         } else {
             // ragged last tile of the call: element by element, straight from the registers

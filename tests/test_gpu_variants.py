@@ -37,6 +37,9 @@ KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SX
     {"SXFIR_TILE_VARIANT": "wident12"},
     {"SXFIR_TILE_VARIANT": "wident32", "SXFIR_OVERSUB": "5"},
     {"SXFIR_TILE_VARIANT": "widentp24"},
+    {"SXFIR_TILE_VARIANT": "widepol200"},
+    {"SXFIR_TILE_VARIANT": "widepol310", "SXFIR_OVERSUB": "5"},
+    {"SXFIR_TILE_VARIANT": "widepol11"},
     {"SXFIR_TILE_VARIANT": "t2s"},                                   # round 3's shipped form, now the A/B partner
     {"SXFIR_TILE_VARIANT": "t2s", "SXFIR_OVERSUB": "3"},
     {"SXFIR_TILE_VARIANT": "t2:1:525376"},                           # ... and its option-bit spelling, nt loads

@@ -35,6 +35,7 @@
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
+#   kb4pol              /4 shipped kernel against the same build with other cache policies (sc0 / sc1 / nt) on loads and stores
 #   ibprev              x8 interpolator: the same before / after for interp8_pass_kernel
 #   kbprev:D[,variant[,fmt]]  the previous commit's profiling library (tools/prev_lib.sh) against this tree's, alternating processes
 # Every step's exit status is recorded (rc=N in its log and on stdout); the script exits non-zero if any step
@@ -142,6 +143,11 @@ for S in "$@"; do
                 echo "# previous" >> $LOG; SXFIR_PROF_LIB=$PWD/sxxcvr_amd/lib/prev/libsxfir_prof.so KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:8 >> $LOG 2>&1 || RC=$?
                 echo "# this tree" >> $LOG; KB_ROUNDS=3 timeout 600 python3 tools/ibench2.py pass:8 >> $LOG 2>&1 || RC=$?
               done; grep -v "amdgpu.ids" $LOG | grep "^#\|ms med\|skipped" ;;
+    kb4pol)   # /4 shipped kernel (x) against the same build with other cache policies on its nt loads / its stores (widepol<hex>:
+              # low byte OR-ed into the loads' policy bits: 1 sc0, 10 sc1; next byte the stores: 1 plain, 2 sc0 sc1, 3 sc0 sc1 nt, 4 sc1)
+              V="x:16:0:0:0:0 widepol100:16:0:0:0:0 widepol200:16:0:0:0:0 widepol300:16:0:0:0:0 widepol400:16:0:0:0:0 widepol10:16:0:0:0:0 widepol11:16:0:0:0:0 widepol1:16:0:0:0:0 widepol310:16:0:0:0:0 widepol210:16:0:0:0:0 x:16:0:0:0:16"
+              KB_D=4 KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 1500 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
+              KB_ZERO=1 KB_D=4 KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped\|DIFFERENT" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;
