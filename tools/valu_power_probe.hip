@@ -28,7 +28,9 @@ __device__ __forceinline__ void pks_hi(f2& acc, const f2& h, const f2& x) {
 
 // MODE 0: VGPR taps, 1: SGPR taps, 2: scalar fmac with SGPR taps; READS = ds_read_b128 per 512 packed FMAs (their
 // values are only kept alive, no extra VALU work)
-template <int MODE, int READS = 0>
+// DPPS = v_mov_b32_dpp per 512 packed FMAs (DPPK 0: wave_shl:1, 1: row_shl:1): what moving window samples between
+// neighbouring lanes' registers would cost instead of re-reading them from LDS
+template <int MODE, int READS = 0, int DPPS = 0, int DPPK = 0>
 __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, float* __restrict__ out, int tiles,
                                              unsigned long long* stamps) {
   __shared__ f4 lds[640 * 4];
@@ -54,6 +56,9 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
   for (int i = 0; i < 4; ++i) x[i] = (f2){0.37f + 0.011f * lane + i, -0.59f + 0.013f * lane - i};
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   const f4* win = img + (lane & 31) * 17;
+  float d[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = 0.125f * lane + i;
   for (int t = 0; t < tiles; ++t) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {          // 8 x 64 = 512 packed FMAs
@@ -64,6 +69,13 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
             const f4 v = win[(r * 9 + q) % 60 + ((r * 9 + q) % 60) / 16];
             asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
           }
+        }
+      }
+      if (DPPS > 0) {
+#pragma unroll
+        for (int q = 0; q < DPPS / 8; ++q) {
+          if (DPPK == 0) asm volatile("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+          else asm volatile("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
         }
       }
 #pragma unroll
@@ -90,6 +102,8 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
   float s = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += d[i];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s + hv[0].x;
   if (lane == 0) {
     stamps[2 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6))] = c1 - c0;
@@ -106,7 +120,7 @@ int main() {
   CK(hipMemcpy(taps, h, 512, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int tiles = 256;                   // per wave and launch: one launch = the FIR work of one bench step
-  const char* names[13] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
+  const char* names[17] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
                           "VGPR taps + 47 ds_read_b128 per tile (first-generation kernel's mix)", "SGPR taps + 47 ds_read_b128 per tile",
                           "SGPR taps + 71 ds_read_b128 per tile (shipped scalar kernel's mix)", "SGPR taps + 39 ds_read_b128 per tile",
                           "VGPR taps + 71 ds_read_b128 per tile",
@@ -114,9 +128,13 @@ int main() {
                           "SGPR taps + 76 ds_read_b128 per 512 FMAs (16 SGPR-tap passes over the /32 tile: 38 per 256)",
                           "VGPR taps + 20 ds_read_b128 per 512 FMAs (the interpolator today: 10 per 256)",
                           "SGPR taps + 20 ds_read_b128 per 512 FMAs (the interpolator with in-lane (p, c) passes)",
-                          "VGPR taps + 31 ds_read_b128 per 512 FMAs (a dense /32 kernel with 16 outputs per lane: 62 per 1024)"};
+                          "VGPR taps + 31 ds_read_b128 per 512 FMAs (a dense /32 kernel with 16 outputs per lane: 62 per 1024)",
+                          "SGPR taps + 8 ds_read_b128 + 128 v_mov_b32_dpp wave_shl:1 per 512 FMAs (the /4 kernel sharing its window between lanes' registers)",
+                          "SGPR taps + 8 ds_read_b128 + 128 v_mov_b32_dpp row_shl:1 per 512 FMAs",
+                          "SGPR taps + 128 v_mov_b32_dpp wave_shl:1 per 512 FMAs, no LDS reads",
+                          "SGPR taps + 24 ds_read_b128 per 512 FMAs (16 outputs per lane at /4)"};
   for (int rep = 0; rep < 2; ++rep)
-    for (int mode = 0; mode < 13; ++mode) {
+    for (int mode = 0; mode < 17; ++mode) {
       auto launch = [&] {
         switch (mode) {
           case 0: hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
@@ -131,7 +149,11 @@ int main() {
           case 9: hipLaunchKernelGGL((probe<1, 76>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 10: hipLaunchKernelGGL((probe<0, 20>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 11: hipLaunchKernelGGL((probe<1, 20>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
-          default: hipLaunchKernelGGL((probe<0, 31>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 12: hipLaunchKernelGGL((probe<0, 31>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 13: hipLaunchKernelGGL((probe<1, 8, 128, 0>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 14: hipLaunchKernelGGL((probe<1, 8, 128, 1>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 15: hipLaunchKernelGGL((probe<1, 0, 128, 0>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          default: hipLaunchKernelGGL((probe<1, 24>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
         }
       };
       for (int i = 0; i < 300; ++i) launch();          // ~100 ms: let the clocks settle on this load
