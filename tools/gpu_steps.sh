@@ -148,6 +148,9 @@ for S in "$@"; do
               V="x:16:0:0:0:0 widepol100:16:0:0:0:0 widepol200:16:0:0:0:0 widepol300:16:0:0:0:0 widepol400:16:0:0:0:0 widepol10:16:0:0:0:0 widepol11:16:0:0:0:0 widepol1:16:0:0:0:0 widepol310:16:0:0:0:0 widepol210:16:0:0:0:0 x:16:0:0:0:16"
               KB_D=4 KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 1500 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
               KB_ZERO=1 KB_D=4 KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped\|DIFFERENT" ;;
+    psplit4w) # power of the shipped /4 kernel, its memory side alone (nt loads) and round 3's form, beside the plain streams (mempower)
+              PS_FORMS="wide whole=wident24:0,wide memory side=wident8:1,t2s whole=t2s:0,t2s memory side=t2.1.525376:1" timeout 300 python3 tools/power_split.py 4 >> $LOG 2>&1; RC=$?
+              timeout 300 python3 tools/mempower.py >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

@@ -22,9 +22,19 @@ taps = sxxcvr_amd.design_lowpass(32 * D, D)
 st = torch.cuda.current_stream().cuda_stream
 forms = [("whole kernel", 0), ("memory side alone", 1), ("arithmetic alone", 2)]
 if D == 4:
+    # PS_FORMS="label=variant:ablate,..." overrides (round 4: the shipped wide kernel and its memory side)
     os.environ["SXFIR_TILE_VARIANT"] = "t2:1:1088"
     forms = forms[:2] + [("arithmetic alone", 2)]
+custom = os.environ.get("PS_FORMS")
+if custom:
+    forms = []
+    for item in custom.split(","):
+        label, spec = item.split("=")
+        v, abl = spec.rsplit(":", 1)
+        forms.append((label, (v, int(abl))))
 for label, abl in forms:
+    if isinstance(abl, tuple):
+        os.environ["SXFIR_TILE_VARIANT"], abl = abl[0].replace(".", ":"), abl[1]
     os.environ["SXFIR_ABLATE"] = str(abl)
     try:
         plan = sxxcvr_amd.Resampler(DECIMATE, taps, D, profiling=True)
