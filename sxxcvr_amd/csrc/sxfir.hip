@@ -907,7 +907,7 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
                        (p->nchan == 1 || out_stride % 2 == 0);
     if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
         return fail(SXFIR_EUNSUPPORTED, "tiled interpolator needs a 16-byte aligned output and even strides");
-    if (tiled && p->ipass && !key) {
+    if (tiled && p->ipass) {
         // x8, 256 taps, CF32: the scalar-tap form, tiles of 128 inputs (two per lane), four (phase group, row half) passes per tile
         sxfir::InterpTileArgs t;
         t.in = (const float *)in_dev;
@@ -928,13 +928,17 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.n_tiles = (int)n_tiles;
         t.n_groups = (int)groups;
         t.thr2 = p->thr2;
-        t.key_counter = nullptr;
-        t.key_lo = t.key_hi = 0;
+        t.key_counter = key ? key->counter : nullptr;
+        t.key_lo = key ? key->lo : 0;
+        t.key_hi = key ? key->hi : 0;
+        const dim3 pgrid((unsigned)groups, (unsigned)p->nchan);
 #ifdef SXFIR_PROFILING
-        if (p->ipass_qi == 4) hipLaunchKernelGGL(sxfir::interp8_pass_kernel<4>, dim3((unsigned)groups, (unsigned)p->nchan), dim3(64), 0, st, t);
+        if (p->ipass_qi == 4 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true>), pgrid, dim3(64), 0, st, t);
+        else if (p->ipass_qi == 4) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4>), pgrid, dim3(64), 0, st, t);
         else
 #endif
-        hipLaunchKernelGGL(sxfir::interp8_pass_kernel<2>, dim3((unsigned)groups, (unsigned)p->nchan), dim3(64), 0, st, t);
+        if (key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true>), pgrid, dim3(64), 0, st, t);
+        else hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2>), pgrid, dim3(64), 0, st, t);
         HIPCHECK(hipGetLastError());
         *history_done = true;
         return SXFIR_OK;

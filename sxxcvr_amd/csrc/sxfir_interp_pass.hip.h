@@ -29,7 +29,8 @@
 // QI = 2 halves the tile: 8 KiB of outputs + a 1.3 KiB image = 10 KB of LDS and 125 VGPRs, i.e. 16 waves per CU, eight
 // stores per wave and tile, 17 window reads per 512 FMAs (still fewer than the VGPR-tap kernel's 20): structure 0.39-0.41
 // ms on zeros, **9.6 % less time than interp_tile_kernel on random IQ** (0.4636 against 0.5124 ms on the same box).  That
-// form ships for CF32 x8; wire-word output, the keying count and the other ratios keep interp_tile_kernel.
+// form ships for CF32 x8, with or without the keying count (KEYED); wire-word output and the other ratios keep
+// interp_tile_kernel.
 //
 // Numeric contract: partial_p = fmaf chain from +0.0f over j DESCENDING in [16p, 16p+16); y = P0 + P1 --
 // the same chains in the same order as interp_tile_kernel, so the outputs are bit-identical.
@@ -92,7 +93,11 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
     (interp_pass_step<QI, Ts>(win[Ts], hs, acc), ...);
 }
 
-template <int QI>
+// KEYED: the transmitter-keying count of the call's input (convert_tx_buffer's rule, SoapySX.cpp:132-133) rides along as in
+// interp_tile_kernel: a lane's own QI inputs are the last QI samples of the window it has just read, so the count costs two
+// products, a sum and a ballot per sample and one atomic per wave and tile.  The range and the threshold are read from the
+// kernel arguments where they are used (the kernel has no scalar registers to spare).
+template <int QI, bool KEYED = false>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {
     using C = InterpPass8<QI>;
@@ -184,6 +189,30 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             for (int t = 0; t < C::NWU; ++t) win[t] = wp[t];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (KEYED) {
+            if (ch == 0) {
+                const __attribute__((address_space(4))) InterpTileArgs *ap =
+                    (const __attribute__((address_space(4))) InterpTileArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ap));
+                const long long key_lo = ap->key_lo, key_hi = ap->key_hi;      // key_hi <= n_in (checked by sxfir_interpolate_keyed)
+                if (q0 < key_hi && q0 + C::TILE_IN > key_lo) {
+                    const float thr2 = ap->thr2;
+                    unsigned total = 0;
+#pragma unroll
+                    for (int e = 0; e < QI; ++e) {
+                        // sample q0 + QI lane + e = window sample 32 + e: half (e & 1) of chunk 16 + e / 2
+                        const f32x4 v = win[16 + e / 2];
+                        const float fi = (e & 1) ? v.z : v.x, fq = (e & 1) ? v.w : v.y;
+                        const long long sidx = q0 + QI * lane + e;
+                        // the rule as the reference's source states it: both products and the sum rounded once each
+                        const bool k = sidx >= key_lo && sidx < key_hi &&
+                                       __fadd_rn(__fmul_rn(fi, fi), __fmul_rn(fq, fq)) >= thr2;
+                        total += (unsigned)__builtin_popcountll(__ballot(k));
+                    }
+                    if (lane == 0 && total) atomicAdd(ap->key_counter, (unsigned long long)total);
+                }
+            }
+        }
         // the image is free: fetch the next tile behind the arithmetic of this one
         const int next = tile + a.n_groups;
         counted = false;

@@ -147,7 +147,8 @@ def test_tiled_interpolator_bit_exact(oracle, L, n_in):
 @pytest.mark.parametrize("L,fmt,nchan,n_in,generic", [(8, "CF32", 1, 5000, False), (8, "S32", 1, 64 * 50 + 7, False),
                                                       (4, "CF32", 2, 1 << 15, False), (16, "CF32", 1, 4099, False),
                                                       (32, "S32", 3, 3333, False), (8, "CF32", 1, 3001, True),
-                                                      (4, "CF32", 1, 1, False), (8, "CF32", 1, 1 << 18, False)])
+                                                      (4, "CF32", 1, 1, False), (8, "CF32", 1, 1 << 18, False),
+                                                      (8, "CF32", 2, 4097, False), (8, "CF32", 1, 127, False), (8, "CF32", 3, 128 * 9, False)])
 def test_interpolator_takes_the_keying_count_in_the_same_pass(oracle, L, fmt, nchan, n_in, generic):
     """sxfir_interpolate_keyed: outputs bit-identical to sxfir_interpolate, and the counter grows by the number of
     channel-0 samples inside the given range whose I word carries the keying bits in the oracle's convert_tx_buffer
