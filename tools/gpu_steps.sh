@@ -35,6 +35,7 @@
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
+#   psplit4w            socket power of the shipped /4 kernel, its memory side alone, round 3's form, and plain streams
 #   kb4pol              /4 shipped kernel against the same build with other cache policies (sc0 / sc1 / nt) on loads and stores
 #   ibprev              x8 interpolator: the same before / after for interp8_pass_kernel
 #   kbprev:D[,variant[,fmt]]  the previous commit's profiling library (tools/prev_lib.sh) against this tree's, alternating processes
