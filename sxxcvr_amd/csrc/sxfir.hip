@@ -102,7 +102,7 @@ struct sxfir_plan {
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
     int dense_nt;          // profiling build, SXFIR_DENSE_NT = 1 / 0: decim_dense_kernel with nt / plain staging loads at every ratio
     int dense_nt_set;      // ... and whether the knob was given at all
-    bool dense_subset;     // /8 CF32: the scalar-tap form of decim_dense_kernel (tap subsets on the four waves)
+    bool dense_subset;     // /8, CF32 or S32 words: the scalar-tap form of decim_dense_kernel (tap subsets on the four waves)
     bool dense32;          // decim_dense_kernel (ratio 8 / 16 / 32, 32 taps per phase, CF32 / S32): the linear-image form
     int multi_waves;       // waves per workgroup of the multi kernel
     int multi_ps;          // lanes that share the 32 tap rows of one output (2 or 4) in the multi kernel
@@ -277,7 +277,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the multi-column kernel
     p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && fmt != SXFIR_CF16;
     // /8 CF32: the scalar-tap form of the dense kernel (tap subsets on the four waves, round 4: 4.4-5 % less time)
-    p->dense_subset = p->dense32 && ratio == 8 && fmt == SXFIR_CF32;
+    p->dense_subset = p->dense32 && ratio == 8 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32);
     p->t2_wpg = p->t2_opt = 0;
     p->dense_nt = 0;
     p->dense_nt_set = 0;
@@ -348,7 +348,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const void *k = nullptr;
         if (p->dense32) {
             const bool w = fmt == SXFIR_S32;
-            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, 2> : (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true>)
+            k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, 2, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true>)
                 : ratio == 16 ? (w ? (const void *)sxfir::decim_dense_kernel<16, 0, true, 2> : (const void *)sxfir::decim_dense_kernel<16, 0, false, 2>)
                               : (w ? (const void *)sxfir::decim_dense_kernel<32, 0, true, 2> : (const void *)sxfir::decim_dense_kernel<32, 0, false, 2>);
 #ifdef SXFIR_PROFILING
@@ -466,13 +466,14 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     for (int k = 0; k < 64; ++k) p->taps_k[k] = k < ntaps ? (fmt == SXFIR_S32 ? taps[k] * 4.656612873077393e-10f : taps[k]) : 0.0f;
     if (e == hipSuccess) {
         std::vector<float> scaled(taps, taps + ntaps);
-        if (mode == SXFIR_DECIMATE && ratio == 8 && ntaps == 256 && fmt == SXFIR_CF32) {
+        if (mode == SXFIR_DECIMATE && ratio == 8 && ntaps == 256 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
             // /8 scalar-tap form (decim_dense_kernel<8, ..., SUBSET>): subset s = 2c + p at 64 s, (jj, rr) at 4 jj + rr
             for (int c = 0; c < 2; ++c)
                 for (int ph = 0; ph < 2; ++ph)
                     for (int jj = 0; jj < 16; ++jj)
                         for (int rr = 0; rr < 4; ++rr)
-                            scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] = taps[8 * (16 * ph + jj) + 4 * c + rr];
+                            scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] =
+                                taps[8 * (16 * ph + jj) + 4 * c + rr] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);   // 2^-31: exact
         } else if (mode == SXFIR_INTERPOLATE && p->itile_capable && ratio == 8) {
             for (int c = 0; c < 2; ++c)
                 for (int ph = 0; ph < 2; ++ph)
@@ -683,12 +684,6 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             // measured in round 4 (profiles/round4h_kbench_both_halos_plain.txt: whole kernel -0.9 % at /32, -2.8 % at /8
             // and /16 against plain loads; with only the next tile's halo plain /32 lost 1.4 %)
 #define SXFIR_DENSE_LAUNCH(DD, AA, SS, NN) hipLaunchKernelGGL((sxfir::decim_dense_kernel<DD, AA, SS, NN>), grid, dim3(256), 0, st, a)
-#define SXFIR_DENSE_BY_RATIO(AA, SS) \
-    do { \
-        if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, AA, SS, 2); \
-        else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, AA, SS, 2); \
-        else SXFIR_DENSE_LAUNCH(32, AA, SS, 2); \
-    } while (0)
 #ifdef SXFIR_PROFILING
             if (const int pr = prof_launch_dense(p, a, grid, st, groups, W)) {       // ablations, stamps, nt-load A/B
                 if (pr < 0) return pr;
@@ -698,14 +693,17 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
 #endif
             if (p->dense_subset) {
                 a.taps = p->taps_scaled_dev;                      // the subset-major tap table
-                hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 2, true>), grid, dim3(256), 0, st, a);
-            } else if (p->fmt == SXFIR_S32) SXFIR_DENSE_BY_RATIO(0, true);
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, true, 2, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 2, true>), grid, dim3(256), 0, st, a);
+            }
 #ifdef SXFIR_PROFILING
-            else if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, 0, false, 2);      // the VGPR-tap form at /8 CF32: A/B partner only
+            else if (p->ratio == 8 && p->fmt == SXFIR_S32) SXFIR_DENSE_LAUNCH(8, 0, true, 2);   // the VGPR-tap forms at /8: A/B partners only
+            else if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, 0, false, 2);
 #endif
+            else if (p->fmt == SXFIR_S32 && p->ratio == 16) SXFIR_DENSE_LAUNCH(16, 0, true, 2);
+            else if (p->fmt == SXFIR_S32) SXFIR_DENSE_LAUNCH(32, 0, true, 2);
             else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, 0, false, 2);
             else SXFIR_DENSE_LAUNCH(32, 0, false, 2);
-#undef SXFIR_DENSE_BY_RATIO
 #undef SXFIR_DENSE_LAUNCH
             HIPCHECK(hipGetLastError());
             *history_done = true;

@@ -88,7 +88,7 @@ __device__ __forceinline__ float butterfly_add(float v)
 // to a group of four (one per wave) -- are plain too: an nt re-read that reaches the L2 first would stream through
 // without leaving the line for the neighbour's plain load, which then fetches it again (1.04 x the algorithmic bytes
 // measured on the /4 kernel).
-// SUBSET (/8, CF32; round 4): the scalar-tap form.  The four (row half p, column group c) tap subsets go to the four
+// SUBSET (/8, CF32 or S32 wire words; round 4): the scalar-tap form.  The four (row half p, column group c) tap subsets go to the four
 // WAVES of the workgroup instead of to lane bits: wave ww = 2c + p holds its subset's 64 taps in 32 SGPR pairs (a.taps is
 // then the subset-major table: subset s at 64 s, (jj, rr) at 4 jj + rr) and computes that subset's partial sum of ALL 512
 // outputs of the tile -- lane -> output group G (8 outputs), the same 46 window reads and 512 packed FMAs per lane, one
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 decim_dense_kernel(const DecimMultiArgs a)
 {
     using C = DecimDense<D>;
-    static_assert(!SUBSET || (D == 8 && !S32IN && (ABL == 0 || ABL == 1)), "subset form: /8, CF32");
+    static_assert(!SUBSET || (D == 8 && (ABL == 0 || (ABL == 1 && !S32IN))), "subset form: /8 (CF32 or S32 wire words: the table then holds the taps times 2^-31)");
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
     const int tid = threadIdx.x;

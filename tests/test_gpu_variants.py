@@ -217,3 +217,32 @@ def test_div8_forms_match_oracle(oracle, monkeypatch, nchan, lens, subset):
     y = np.concatenate(outs, axis=1)
     for c in range(nchan):
         assert_bit_exact(y[c], oracle.decim_f32(h, 8, x[c], 2, 4), "/8 subset form, channel %d" % c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset", ["1", "0"])
+@pytest.mark.parametrize("nchan,lens", [(1, [512 * 12 + 8 * 3, 8 * 5, 512 * 9]), (2, [512 * 7 + 8 * 77, 1 << 16])])
+def test_div8_forms_on_wire_words_match_oracle(oracle, monkeypatch, nchan, lens, subset):
+    """/8, 256 taps, S32_LE wire words (convert_rx_buffer, SX.cpp:103-112, inside the kernel): the scalar-tap form (taps
+    times 2^-31 in SGPRs, shipped) and the VGPR-tap form give the bits of oracle conversion + oracle FIR; several calls
+    with ragged tails, several channels, extreme words at the start."""
+    import torch
+    for k in KNOBS + ("SXFIR_DENSE_SUBSET",):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_DENSE_SUBSET", subset)
+    h = sxxcvr_amd.design_lowpass(256, 8)
+    total = sum(lens)
+    rng = np.random.default_rng(77 + nchan)
+    words = rng.integers(-2 ** 31, 2 ** 31, size=(nchan, 8 * total, 2), dtype=np.int64).astype(np.int32)
+    words[:, :3, :] = np.array([[2 ** 31 - 1, -2 ** 31], [1, -1], [0, 0x7FFFFF80]], dtype=np.int32)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 8, nchan=nchan, fmt="S32", profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        blk = torch.from_numpy(np.ascontiguousarray(words[:, 8 * pos:8 * (pos + n)])).cuda()
+        outs.append(to_cpu(plan.process(blk if nchan > 1 else blk[0])).reshape(nchan, -1))
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        ref = oracle.decim_f32(h, 8, oracle.convert_rx(words[c].ravel()), 2, 4)
+        assert_bit_exact(y[c], ref, "/8 on wire words, subset %s, channel %d" % (subset, c))

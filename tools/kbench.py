@@ -22,15 +22,16 @@ for spec in (sys.argv[1:] or ["sb:1:0", "db:1:0"]):
     configs.append((v, int(ov), int(occ), int(f[3]) if len(f) > 3 else 0, int(f[4]) if len(f) > 4 else 0, int(f[5]) if len(f) > 5 else 0))
 
 n = (1 << log2n) // nchan
-dt = torch.complex64 if FMT == "CF32" else torch.int32
+# CF32 and S32 wire words: 8 bytes per sample in (the decimators always write CF32); CF16: 4 bytes in and out
+dt = torch.int32 if FMT == "CF16" else torch.complex64
 x = torch.empty((nchan, n), dtype=dt, device="cuda")
 sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=FMT)
 if os.environ.get("KB_ZERO") == "1":                 # all-zero input: no toggling in the FMA datapath, the clock stays free of the power cap
     x.zero_()
     print("# all-zero input (KB_ZERO=1): the kernel's structure without the power cap")
 yoff = int(os.environ.get("KB_YOFF", "0"))          # output buffer displaced by this many bytes (HBM channel phase probe)
-ybase = torch.empty(nchan * (n // D) * (8 if FMT == "CF32" else 4) + yoff + 64, dtype=torch.uint8, device="cuda")
-y = ybase[yoff:yoff + nchan * (n // D) * (8 if FMT == "CF32" else 4)].view(dt).view(nchan, n // D)
+ybase = torch.empty(nchan * (n // D) * (4 if FMT == "CF16" else 8) + yoff + 64, dtype=torch.uint8, device="cuda")
+y = ybase[yoff:yoff + nchan * (n // D) * (4 if FMT == "CF16" else 8)].view(dt).view(nchan, n // D)
 taps = sxxcvr_amd.design_lowpass(32 * D, D)
 plans = []
 for v, ov, occ, abl, sched, pad in configs:
@@ -71,7 +72,7 @@ for r in range(rounds):
         res[c].append(ms)
         if r == 0:
             torch.cuda.synchronize()
-            chk = (torch.view_as_real(y) if FMT == "CF32" else y).view(torch.int32).sum(dtype=torch.int64).item()
+            chk = (y if FMT == "CF16" else torch.view_as_real(y)).view(torch.int32).sum(dtype=torch.int64).item()
             if ref is None: ref = chk
             print("config", c, "checksum", "same" if chk == ref else "DIFFERENT")
 import ctypes as C
@@ -122,6 +123,6 @@ for c, p in zip(configs, plans):
                 " ".join("%d:%.1f" % (k, life[simd == k].mean()) for k in sorted(set(simd)))))
 for c in configs:
     a = np.array(res[c])
-    gbs = (8.0 + 8.0 / D) * (1.0 if FMT == "CF32" else 0.5) * (1 << log2n) / (a * 1e-3) / 1e9
+    gbs = (8.0 + 8.0 / D) * (0.5 if FMT == "CF16" else 1.0) * (1 << log2n) / (a * 1e-3) / 1e9
     print("%-24s ms med %.4f min %.4f max %.4f | GB/s med %.0f best %.0f | frac of 8TB/s %.3f" % (
         "%s:%d:%d:%d:%d:%d" % c, np.median(a), a.min(), a.max(), np.median(gbs), gbs.max(), np.median(gbs) / 8000))
