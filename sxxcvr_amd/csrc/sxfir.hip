@@ -298,7 +298,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // interpolator is flat between 2 and 16 (tools/ibench.py)
     if (p->multi_capable) p->oversub = 8;
     if (p->itile_capable) p->oversub = 4;
-    if (p->itile_capable && ratio == 8 && fmt == SXFIR_CF32) {
+    if (p->itile_capable && ratio == 8 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
         p->ipass = true;
         p->oversub = 8;                                 // measured (tools/ibench2.py): 4 / 8 / 16 generations within 0.3 %
         int nbi = 0;
@@ -931,11 +931,14 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.key_hi = key ? key->hi : 0;
         const dim3 pgrid((unsigned)groups, (unsigned)p->nchan);
 #ifdef SXFIR_PROFILING
-        if (p->ipass_qi == 4 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true>), pgrid, dim3(64), 0, st, t);
+        if (p->ipass_qi == 4 && p->fmt == SXFIR_S32) return fail(SXFIR_EUNSUPPORTED, "four inputs per lane: CF32 only");
+        else if (p->ipass_qi == 4 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true>), pgrid, dim3(64), 0, st, t);
         else if (p->ipass_qi == 4) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4>), pgrid, dim3(64), 0, st, t);
         else
 #endif
-        if (key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true>), pgrid, dim3(64), 0, st, t);
+        if (p->fmt == SXFIR_S32 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true, true>), pgrid, dim3(64), 0, st, t);
+        else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, false, true>), pgrid, dim3(64), 0, st, t);
+        else if (key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true>), pgrid, dim3(64), 0, st, t);
         else hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2>), pgrid, dim3(64), 0, st, t);
         HIPCHECK(hipGetLastError());
         *history_done = true;
@@ -968,28 +971,44 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         if (key && p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true, true>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
             case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true, true>), grid, dim3(64), 0, st, t); break;
             default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true, true>), grid, dim3(64), 0, st, t); break;
             }
         } else if (key) {
             switch (p->ratio) {
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, false, true>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, false, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
             case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, true>), grid, dim3(64), 0, st, t); break;
             default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, false, true>), grid, dim3(64), 0, st, t); break;
             }
         } else if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
             case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true>), grid, dim3(64), 0, st, t); break;
             default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true>), grid, dim3(64), 0, st, t); break;
             }
         } else {
             switch (p->ratio) {
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
             case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, st, t); break;
             default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, st, t); break;
             }

@@ -97,7 +97,9 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
 // interp_tile_kernel: a lane's own QI inputs are the last QI samples of the window it has just read, so the count costs two
 // products, a sum and a ballot per sample and one atomic per wave and tile.  The range and the threshold are read from the
 // kernel arguments where they are used (the kernel has no scalar registers to spare).
-template <int QI, bool KEYED = false>
+// S32OUT: outputs leave as S32_LE I2S wire words with the keying bits (convert_tx_buffer, SoapySX.cpp:116-137), converted
+// between the transposition buffer and the store as in interp_tile_kernel.
+template <int QI, bool KEYED = false, bool S32OUT = false>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {
     using C = InterpPass8<QI>;
@@ -163,6 +165,14 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             }
         }
         return interior;
+    };
+
+    // the keying threshold, read from the kernel arguments where it is used (no scalar register held across the tile loop)
+    auto tx_threshold = [&]() __attribute__((always_inline)) {
+        const __attribute__((address_space(4))) InterpTileArgs *ap =
+            (const __attribute__((address_space(4))) InterpTileArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        return ap->thr2;
     };
 
     int tile = first_tile;
@@ -262,6 +272,14 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             f32x4 v[C::CPL];
 #pragma unroll
             for (int i = 0; i < C::CPL; ++i) v[i] = obuf[64 * i + lane];
+            if constexpr (S32OUT) {
+                const float thr2 = tx_threshold();
+#pragma unroll
+                for (int i = 0; i < C::CPL; ++i) {
+                    const int2 w0 = tx_words(v[i].x, v[i].y, thr2), w1 = tx_words(v[i].z, v[i].w, thr2);
+                    v[i] = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
+                }
+            }
 #pragma unroll
             for (int i = 0; i < C::CPL; ++i) {
                 const int slot = 64 * i + lane;
@@ -275,7 +293,12 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             for (int i = 0; i < C::CPL; ++i) {
                 const int slot = 64 * i + lane;
                 const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
-                const f32x4 v = obuf[slot];
+                f32x4 v = obuf[slot];
+                if constexpr (S32OUT) {
+                    const float thr2 = tx_threshold();
+                    const int2 w0 = tx_words(v.x, v.y, thr2), w1 = tx_words(v.z, v.w, thr2);
+                    v = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
+                }
                 const long long o = o0 + 2 * (C::CPL * g2 + k2);     // two output samples per chunk
                 if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
             }

@@ -246,3 +246,43 @@ def test_div8_forms_on_wire_words_match_oracle(oracle, monkeypatch, nchan, lens,
     for c in range(nchan):
         ref = oracle.decim_f32(h, 8, oracle.convert_rx(words[c].ravel()), 2, 4)
         assert_bit_exact(y[c], ref, "/8 on wire words, subset %s, channel %d" % (subset, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ipass", ["1", "0"])
+def test_x8_interpolator_forms_to_wire_words_match_oracle(oracle, monkeypatch, ipass):
+    """x8 to S32_LE wire words with the keying bits (convert_tx_buffer, SX.cpp:116-137): interp8_pass_kernel<2, KEYED, S32OUT>
+    (shipped) and interp_tile_kernel<8, S32OUT> (SXFIR_IPASS=0) give the oracle's words -- clipping samples, samples under the
+    keying threshold, three calls with a ragged tail, two channels -- and the keying count of the input rides along."""
+    import torch
+    for k in KNOBS + ("SXFIR_IPASS",):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_IPASS", ipass)
+    h = sxxcvr_amd.design_lowpass(256, 8, 8.0, 8.0)
+    nchan, lens = 2, [128 * 41 + 77, 5, 128 * 64]
+    x = np.stack([(oracle.synth_iq(0x51255, 50 + c, 0, sum(lens)) * np.float32(1.3)).astype(np.complex64) for c in range(nchan)])
+    x[:, 300:900] *= np.float32(1e-4)
+    thr2 = np.float32(1e-3) * np.float32(1e-3)
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, 8, nchan=nchan, fmt="S32", profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    plan.set_tx_threshold(float(thr2))
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    outs, pos, want_count = [], 0, 0
+    keyed_in = (oracle.convert_tx(x[0], thr2).reshape(-1, 2)[:, 0] & 3) == 3
+    for n in lens:
+        blk = to_gpu(np.ascontiguousarray(x[:, pos:pos + n]))
+        out = torch.empty((nchan, 8 * n, 2), dtype=torch.int32, device="cuda")
+        got = plan.interpolate_keyed_ptr(blk.data_ptr(), n, n, out.data_ptr(), 8 * n, 0, n, counter.data_ptr(), st)
+        assert got == 8 * n
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy().reshape(nchan, -1))
+        want_count += int(keyed_in[pos:pos + n].sum())
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        want = oracle.convert_tx(oracle.interp_f32(h, 8, x[c], 2), thr2)
+        assert np.array_equal(y[c], want), "x8 to wire words, form %s, channel %d" % (ipass, c)
+        keyed = (want[0::2] & 3) == 3
+        assert keyed.any() and (~keyed).any()
+    assert int(counter.item()) == want_count

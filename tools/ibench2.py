@@ -21,7 +21,7 @@ for k, sp in enumerate(specs):
     kern, ov = sp.split(":")
     os.environ["SXFIR_IPASS"] = {"pass": "1", "pass4": "4"}.get(kern, "0")      # pass: the shipped form (two inputs per lane); pass4: four
     os.environ["SXFIR_OVERSUB"] = ov
-    plans.append(sxxcvr_amd.Resampler(INTERPOLATE, taps, L, profiling=True))
+    plans.append(sxxcvr_amd.Resampler(INTERPOLATE, taps, L, fmt=os.environ.get("KB_FMT", "CF32"), profiling=True))   # KB_FMT=S32: wire-word output (same 8 bytes per sample)
 st = torch.cuda.current_stream().cuda_stream
 res, ref = [[] for _ in specs], None
 for r in range(rounds):
