@@ -214,6 +214,16 @@ __device__ __forceinline__ void pk_fma_s_hi(f32x2 &acc, const f32x2 &hpair, cons
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
 }
+// the first FMA of a chain: acc = fmaf(tap, x, +0.0f) with the zero as an inline constant, so no register is cleared first
+// (a cleared register costs a v_mov_b64 per chain and tile: 0.6 of a packed FMA's energy each, profiles/round4z9_price_list.txt)
+__device__ __forceinline__ void pk_fma_s_lo_first(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(acc) : "s"(hpair), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_s_hi_first(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "s"(hpair), "v"(x));
+}
 
 // FIR arithmetic of one tile for a symmetric 128-tap filter, taps hs[m] = {h[2m], h[2m+1]}, m < 32, in SGPRs.
 // Lane l computes outputs 4l..4l+3 of the tile: output i meets tap k at window sample u = 4i + 128 - k

@@ -54,7 +54,8 @@ struct DecimWide {
 // constant, so the taps stay in SGPRs.
 // PIN: the packed FMAs as volatile asm, i.e. issued in source order -- all (up to sixteen) FMAs of a sample pair back to
 // back; left to the machine scheduler only 0.28 of adjacent FMAs share their sample pair in the CF32 build
-template <bool S32IN, int CIDX, int NB, bool PIN = false>
+// FIRST0: a chain's first FMA takes +0 as an inline constant instead of a cleared accumulator register
+template <bool S32IN, int CIDX, int NB, bool PIN = false, bool FIRST0 = true>
 __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB], const f32x2 (&hs)[32], f32x2 (&a1)[8],
                                               f32x2 (&a0)[8])
 {
@@ -77,6 +78,7 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
                 if (kl >= 0 && kl < 64) {
                     const int j = 63 - kl;               // h[64 + kl] == h[63 - kl]
                     if constexpr (PIN) { if (j & 1) pk_fma_sv_hi(a1[i], hs[j >> 1], x); else pk_fma_sv_lo(a1[i], hs[j >> 1], x); }
+                    else if (FIRST0 && kl == 63) pk_fma_s_lo_first(a1[i], hs[j >> 1], x);       // the chain's first tap (j = 0): from +0
                     else if (j & 1) pk_fma_s_hi(a1[i], hs[j >> 1], x);
                     else pk_fma_s_lo(a1[i], hs[j >> 1], x);
                 }
@@ -89,6 +91,7 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
                 const int kl = 4 * i + 64 - w0;
                 if (kl >= 0 && kl < 64) {
                     if constexpr (PIN) { if (kl & 1) pk_fma_sv_hi(a0[i], hs[kl >> 1], x); else pk_fma_sv_lo(a0[i], hs[kl >> 1], x); }
+                    else if (FIRST0 && kl == 63) pk_fma_s_hi_first(a0[i], hs[kl >> 1], x);      // the chain's first tap: from +0
                     else if (kl & 1) pk_fma_s_hi(a0[i], hs[kl >> 1], x);
                     else pk_fma_s_lo(a0[i], hs[kl >> 1], x);
                 }
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
             const char *src = reinterpret_cast<const char *>(reinterpret_cast<const f32x4 *>(in) + c0);
 #pragma unroll
             for (int j = 0; j < C::NI; ++j) {
-                unsigned bo = boff[j];
-                asm volatile("" : "+v"(bo));             // 32-bit offset next to its use (see stage_tile)
+                asm volatile("" : "+v"(boff[j]));        // 32-bit offset next to its use (see stage_tile); in place: no copy
+                const unsigned bo = boff[j];
                 if (j < C::NI - 1 || lane < C::LASTL) {
                     if (NTL && j >= 1 && j <= 16) glds16<2 | (POL & 0xFF)>(src + bo, img + 64 * j);
                     else glds16(src + bo, img + 64 * j);
@@ -233,8 +236,10 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
         SXFIR_WIDE_PHASE(2)
 
         f32x2 a1[8], a0[8];
+        if constexpr (ABL == 1 || PIN) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a1[i] = a0[i] = (f32x2){0.0f, 0.0f};
+            for (int i = 0; i < 8; ++i) a1[i] = a0[i] = (f32x2){0.0f, 0.0f};
+        }
         if constexpr (ABL == 1) {
             const f32x4 v0 = win[0], v1 = win[17];
             a0[0] = (f32x2){v0.x + hs[0].x, v0.y};

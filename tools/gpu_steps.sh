@@ -35,6 +35,7 @@
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
+#   prices[:seconds]    tools/price_list.py: dynamic energy per launch of the arithmetic probe's mixes -> nJ per extra instruction
 #   psplit4w            socket power of the shipped /4 kernel, its memory side alone, round 3's form, and plain streams
 #   kb4pol              /4 shipped kernel against the same build with other cache policies (sc0 / sc1 / nt) on loads and stores
 #   ibprev              x8 interpolator: the same before / after for interp8_pass_kernel
@@ -88,7 +89,7 @@ for S in "$@"; do
     kb4w)     # waves per CU capped through LDS padding (8 per CU, 32 generations) against 16 per CU, with and without nt loads; whole kernel and memory side; then the same on an all-zero input
               V="t2.1.1088:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.1088:32:0:0:0:10600 t2.1.66624:32:0:0:0:10600 t2.1.66624:64:0:0:0:10600 t2.1.1088:16:0:1:0:0 t2.1.66624:16:0:1:0:0 t2.1.1088:32:0:1:0:10600 t2.1.66624:32:0:1:0:10600 t2.1.66624:64:0:1:0:0"
               KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
-    valu)     hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe >> $LOG 2>&1; RC=$?; tail -17 $LOG ;;
+    valu)     hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe >> $LOG 2>&1; RC=$?; tail -22 $LOG ;;
     kb4x)     # one tile per wave (64 generations) with nt loads, taps by value, deferred stores, 12 waves per CU, pinned FMA order: whole kernel, then memory sides, then all-zero input
               V="x:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.66624:32:0:0:0:0 t2.1.66624:64:0:0:0:0 t2.1.67136:64:0:0:0:0 t2.1.67136:16:0:0:0:0 t2.1.66625:16:0:0:0:0 t2.1.66624:21:0:0:0:3840 t2.1.132160:16:0:0:0:0 t2.1.197696:16:0:0:0:0"
               KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?
@@ -152,6 +153,8 @@ for S in "$@"; do
     psplit4w) # power of the shipped /4 kernel, its memory side alone (nt loads) and round 3's form, beside the plain streams (mempower)
               PS_FORMS="wide whole=wident24:0,wide memory side=wident8:1,t2s whole=t2s:0,t2s memory side=t2.1.525376:1" timeout 300 python3 tools/power_split.py 4 >> $LOG 2>&1; RC=$?
               timeout 300 python3 tools/mempower.py >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | tail -12 ;;
+    prices)   # instruction price list at the cap: the probe's mixes one at a time with the board's power sampled beside them
+              hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 600 python3 tools/price_list.py /tmp/valu_power_probe ${ARG:-2.5} >> $LOG 2>&1; RC=$?; grep -v amdgpu.ids $LOG | tail -16 ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

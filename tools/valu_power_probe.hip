@@ -74,8 +74,15 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
       if (DPPS > 0) {
 #pragma unroll
         for (int q = 0; q < DPPS / 8; ++q) {
+          // DPPK: which extra instruction -- 0 wave_shl:1 move, 1 row_shl:1 move, 2 v_cvt_f32_i32, 3 v_mov_b32, 4 v_pk_add_f32,
+          // 5 ds_write_b128, 6 v_cndmask_b32 (price list for design decisions: time at the cap per 128 extra instructions)
           if (DPPK == 0) asm volatile("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
-          else asm volatile("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+          else if (DPPK == 1) asm volatile("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+          else if (DPPK == 2) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+          else if (DPPK == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+          else if (DPPK == 4) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[q & 7]) : "v"(x[q & 3]));
+          else if (DPPK == 5) { if ((q & 7) == 0) img[640 - 64 + lane] = (f4){d[0], d[1], d[2], d[3]}; }
+          else asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]), "v"(d[(q + 5) & 7]) : );
         }
       }
 #pragma unroll
@@ -111,7 +118,11 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
   }
 }
 
-int main() {
+// valu_power_probe                  every mix twice, time and in-kernel clock (the round 2-4 tables)
+// valu_power_probe <mix> <seconds>   one mix back to back for that long (tools/price_list.py samples the board's power beside it)
+int main(int argc, char** argv) {
+  const int only = argc > 2 ? atoi(argv[1]) : -1;
+  const double run_s = argc > 2 ? atof(argv[2]) : 0.0;
   const int blocks = 1024;                 // 4 workgroups of 4 waves per CU = 4 waves per SIMD
   float* taps; float* out; unsigned long long* stamps;
   CK(hipMalloc(&taps, 512)); CK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CK(hipMalloc(&stamps, (size_t)blocks * 4 * 16));
@@ -120,7 +131,7 @@ int main() {
   CK(hipMemcpy(taps, h, 512, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int tiles = 256;                   // per wave and launch: one launch = the FIR work of one bench step
-  const char* names[17] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
+  const char* names[22] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
                           "VGPR taps + 47 ds_read_b128 per tile (first-generation kernel's mix)", "SGPR taps + 47 ds_read_b128 per tile",
                           "SGPR taps + 71 ds_read_b128 per tile (shipped scalar kernel's mix)", "SGPR taps + 39 ds_read_b128 per tile",
                           "VGPR taps + 71 ds_read_b128 per tile",
@@ -132,9 +143,12 @@ int main() {
                           "SGPR taps + 8 ds_read_b128 + 128 v_mov_b32_dpp wave_shl:1 per 512 FMAs (the /4 kernel sharing its window between lanes' registers)",
                           "SGPR taps + 8 ds_read_b128 + 128 v_mov_b32_dpp row_shl:1 per 512 FMAs",
                           "SGPR taps + 128 v_mov_b32_dpp wave_shl:1 per 512 FMAs, no LDS reads",
-                          "SGPR taps + 24 ds_read_b128 per 512 FMAs (16 outputs per lane at /4)"};
-  for (int rep = 0; rep < 2; ++rep)
-    for (int mode = 0; mode < 17; ++mode) {
+                          "SGPR taps + 24 ds_read_b128 per 512 FMAs (16 outputs per lane at /4)",
+                          "SGPR taps + 128 v_cvt_f32_i32 per 512 FMAs", "SGPR taps + 128 v_mov_b32 per 512 FMAs",
+                          "SGPR taps + 128 v_pk_add_f32 per 512 FMAs", "SGPR taps + 16 ds_write_b128 per 512 FMAs",
+                          "SGPR taps + 128 v_cndmask_b32 per 512 FMAs"};
+  for (int rep = 0; rep < (only >= 0 ? 1 : 2); ++rep)
+    for (int mode = (only >= 0 ? only : 0); mode < (only >= 0 ? only + 1 : 22); ++mode) {
       auto launch = [&] {
         switch (mode) {
           case 0: hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
@@ -153,10 +167,19 @@ int main() {
           case 13: hipLaunchKernelGGL((probe<1, 8, 128, 0>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 14: hipLaunchKernelGGL((probe<1, 8, 128, 1>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 15: hipLaunchKernelGGL((probe<1, 0, 128, 0>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
-          default: hipLaunchKernelGGL((probe<1, 24>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 16: hipLaunchKernelGGL((probe<1, 24>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 17: hipLaunchKernelGGL((probe<1, 0, 128, 2>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 18: hipLaunchKernelGGL((probe<1, 0, 128, 3>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 19: hipLaunchKernelGGL((probe<1, 0, 128, 4>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 20: hipLaunchKernelGGL((probe<1, 0, 128, 5>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          default: hipLaunchKernelGGL((probe<1, 0, 128, 6>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
         }
       };
       for (int i = 0; i < 300; ++i) launch();          // ~100 ms: let the clocks settle on this load
+      if (only >= 0) {                                 // keep the load up while the board is sampled
+        const int n = (int)(run_s / 1.2e-3);
+        for (int i = 0; i < n; ++i) { launch(); if (i % 64 == 63) CK(hipStreamSynchronize(0)); }
+      }
       CK(hipEventRecord(e0, 0));
       for (int i = 0; i < 50; ++i) launch();
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
