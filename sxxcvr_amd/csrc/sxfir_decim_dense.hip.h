@@ -254,8 +254,10 @@ decim_dense_kernel(const DecimMultiArgs a)
 
         // ---- compute: window sample w meets output i at local tap kl = 4*i + 63 - w
         f32x2 acc[8];
+        if constexpr (ABL == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = (f32x2){0.0f, 0.0f};
+            for (int i = 0; i < 8; ++i) acc[i] = (f32x2){0.0f, 0.0f};
+        }
         if constexpr (ABL != 1)
 #pragma unroll
         for (int t = 0; t < C::WCH; ++t) {
@@ -270,11 +272,14 @@ decim_dense_kernel(const DecimMultiArgs a)
                 for (int i = 0; i < 8; ++i) {
                     const int kl = 4 * i + 63 - w;
                     if (kl >= 0 && kl < 64) {
+                        // kl = 63 (w = 4i) is a chain's first tap: from an inline +0, no cleared register
                         if constexpr (SUBSET) {
-                            if (kl & 1) pk_fma_s_hi(acc[i], hs[kl >> 1], x);
+                            if (kl == 63) pk_fma_s_hi_first(acc[i], hs[kl >> 1], x);
+                            else if (kl & 1) pk_fma_s_hi(acc[i], hs[kl >> 1], x);
                             else pk_fma_s_lo(acc[i], hs[kl >> 1], x);
                         } else {
-                            if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
+                            if (kl == 63) pk_fma_hi_first(acc[i], hp[kl >> 1], x);
+                            else if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
                             else pk_fma_lo(acc[i], hp[kl >> 1], x);
                         }
                     }

@@ -219,6 +219,11 @@ __device__ __forceinline__ void pk_fma_hi(f32x2 &acc, const f32x2 &hpair, const 
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(hpair), "v"(x));
 }
+// a chain's first FMA: acc = fmaf(tap, x, +0.0f), the zero as an inline constant (no register cleared first)
+__device__ __forceinline__ void pk_fma_hi_first(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "v"(hpair), "v"(x));
+}
 
 template <int NT, bool S32IN = false>
 __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,

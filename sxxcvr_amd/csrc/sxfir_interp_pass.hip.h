@@ -78,7 +78,10 @@ __device__ __forceinline__ void interp_pass_step(const f32x4 &v, const f32x2 (&h
             if (jj >= 0 && jj < 16) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    if (rr & 1) pk_fma_s_hi(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
+                    // jj = 15 is a chain's first tap (w ascends, jj descends): from an inline +0, no cleared register
+                    if (jj == 15 && (rr & 1)) pk_fma_s_hi_first(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
+                    else if (jj == 15) pk_fma_s_lo_first(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
+                    else if (rr & 1) pk_fma_s_hi(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
                     else pk_fma_s_lo(acc[qi][rr], hs[(4 * jj + rr) >> 1], x);
                 }
             }
@@ -240,11 +243,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
                 f32x4 wv[C::NW];
 #pragma unroll
                 for (int t = 0; t < C::NW; ++t) wv[t] = win[8 - 8 * p + t];
-                f32x2 acc[QI][4];
-#pragma unroll
-                for (int qi = 0; qi < QI; ++qi)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) acc[qi][rr] = (f32x2){0.0f, 0.0f};
+                f32x2 acc[QI][4];                               // every chain's first FMA (tap row 15) writes it
                 interp_pass_steps<QI>(std::make_integer_sequence<int, C::NW>{}, wv, hs, acc);
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi)
