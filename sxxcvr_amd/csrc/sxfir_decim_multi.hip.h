@@ -272,8 +272,10 @@ decim_multi_kernel(const DecimMultiArgs a)
         // (two v_cvt_f32_f16, SDWA picks the half) into the pair the packed FMAs take.
         constexpr int SPC = HALF ? 4 : 2;                  // samples per 16-byte chunk
         f32x2 acc[8];
+        if constexpr (ABL == 1 || ABL == 4) {              // (no FIR in these builds: the chains' first FMAs are absent)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = (f32x2){0.0f, 0.0f};
+            for (int i = 0; i < 8; ++i) acc[i] = (f32x2){0.0f, 0.0f};
+        }
         if constexpr (ABL != 1 && ABL != 4)
 #pragma unroll
         for (int t = 0; t < C::WCH; ++t) {
@@ -293,7 +295,9 @@ decim_multi_kernel(const DecimMultiArgs a)
                 for (int i = 0; i < 8; ++i) {
                     const int kl = 4 * i + C::TPL - 1 - w;
                     if (kl >= 0 && kl < C::TPL) {
-                        if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
+                        // kl = TPL - 1 (w = 4i) is a chain's first tap: from an inline +0, no cleared register
+                        if (kl == C::TPL - 1) pk_fma_hi_first(acc[i], hp[kl >> 1], x);
+                        else if (kl & 1) pk_fma_hi(acc[i], hp[kl >> 1], x);
                         else pk_fma_lo(acc[i], hp[kl >> 1], x);
                     }
                 }

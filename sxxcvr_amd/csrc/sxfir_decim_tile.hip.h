@@ -224,6 +224,10 @@ __device__ __forceinline__ void pk_fma_hi_first(f32x2 &acc, const f32x2 &hpair, 
 {
     asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "v"(hpair), "v"(x));
 }
+__device__ __forceinline__ void pk_fma_lo_first(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(acc) : "v"(hpair), "v"(x));
+}
 
 template <int NT, bool S32IN = false>
 __device__ __forceinline__ void compute_tile_pk(const DecimTileCtx<NT> &c, int tile, const f32x4 *win,

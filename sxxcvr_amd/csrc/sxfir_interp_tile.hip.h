@@ -166,11 +166,7 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
         const f32x4 *wk = win + kt * (C::QT / 2);
         // ---- compute: window sample w meets input qi at row jj = qi + 16 - w.  The I and Q FMAs of a
         // (tap, sample) pair are one v_pk_fma_f32 (sxfir_decim_tile.hip.h: same bits, less power).
-        f32x2 acc[4][4];
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) acc[qi][rr] = (f32x2){0.0f, 0.0f};
+        f32x2 acc[4][4];                                    // every chain's first FMA (tap row 15) writes it: from an inline +0
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             const f32x4 v = wk[t];
@@ -184,7 +180,9 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
                     if (jj >= 0 && jj < 16) {
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
-                            if (rr & 1) pk_fma_hi(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
+                            if (jj == 15 && (rr & 1)) pk_fma_hi_first(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
+                            else if (jj == 15) pk_fma_lo_first(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
+                            else if (rr & 1) pk_fma_hi(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
                             else pk_fma_lo(acc[qi][rr], hp[(4 * jj + rr) >> 1], x);
                         }
                     }
