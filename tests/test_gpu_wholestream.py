@@ -169,3 +169,58 @@ def test_whole_stream_decimator_cf16_config5(fast_oracle):
     compared = _compare_blocks(got, ref, "config 5 CF16")
     assert compared == n // ratio
     print("config 5 CF16: %d outputs compared bit for bit" % compared)
+
+
+@pytest.mark.parametrize("name,ntaps,ratio", [("/4 on wire words", 128, 4), ("/8 on wire words (scalar-tap subset form)", 256, 8),
+                                               ("/32 on wire words", 1024, 32)])
+def test_whole_stream_decimators_on_wire_words(fast_oracle, name, ntaps, ratio):
+    """Row f-3 at stream length: 2^26 S32_LE wire-word samples of the synthetic source through the decimators that convert
+    them on load (convert_rx_buffer, SX.cpp:103-112), EVERY output against oracle conversion + oracle FIR."""
+    import torch
+    _enough_memory(6)
+    orc = fast_oracle
+    n = 1 << 26
+    threads = orc.max_threads()
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio)
+    words = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    sxxcvr_amd.synth_fill(torch.view_as_complex(words.view(torch.float32)), SEED, 2, 0, fmt="S32")
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio, fmt="S32")
+    plan.set_kernel(KERNEL_TILED)
+    y = plan.process(words)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().view(np.uint64)
+    w = words.cpu().numpy()
+    del words
+    xs = np.empty(n, dtype=np.complex64)
+    orc.convert_rx_into(w.ravel(), xs.view(np.float32), threads)
+    ref = orc.decim_f32(h, ratio, xs, *plan.contract, threads=threads).view(np.uint64)
+    compared = _compare_blocks(got, ref, name)
+    assert compared == n // ratio
+    print("%s: %d outputs compared bit for bit" % (name, compared))
+
+
+def test_whole_stream_interpolator_to_wire_words(fast_oracle):
+    """x8 to S32_LE wire words with the keying bits (convert_tx_buffer, SX.cpp:116-137) through interp8_pass_kernel<2, ., S32OUT>:
+    2^26 output words pairs, every one against oracle FIR + oracle conversion; the input clips in places and falls under the
+    keying threshold in others."""
+    import torch
+    _enough_memory(6)
+    orc = fast_oracle
+    ratio, ntaps = 8, 256
+    n_in = (1 << 26) // ratio
+    threads = orc.max_threads()
+    h = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, float(ratio))
+    xs = (orc.synth_iq_mt(SEED, 3, 0, n_in, threads) * np.float32(1.3)).astype(np.complex64)
+    xs[n_in // 5:n_in // 4] *= np.float32(1e-4)
+    thr2 = np.float32(1e-3) * np.float32(1e-3)
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, ratio, fmt="S32")
+    plan.set_kernel(KERNEL_TILED)
+    plan.set_tx_threshold(float(thr2))
+    y = plan.process(torch.from_numpy(xs).cuda())
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().reshape(-1, 2).view(np.uint64).ravel()
+    ref = orc.convert_tx(orc.interp_f32_mt(h, ratio, xs, plan.contract[0], threads=threads), thr2).reshape(-1, 2).view(np.uint64).ravel()
+    compared = _compare_blocks(got, ref, "x8 to wire words")
+    assert compared == 1 << 26
+    keyed = (ref & np.uint64(3)) == 3
+    assert keyed.any() and (~keyed).any()
