@@ -97,11 +97,16 @@ __device__ __forceinline__ float butterfly_add(float v)
 // group, then the column groups, and stores one kilobyte.  Lane -> G is the conflict-free map of the /4 scalar-tap kernel
 // (even groups in the first 16-lane service group of a half-wave, odd groups in the second), which keeps the lanes of a
 // service group on 16 different slots mod 16 with this image's one pad per 16 rows.
-template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0, bool SUBSET = false>
+// HC (halo carry; round 4): a workgroup walks a RUN of consecutive tiles instead of every NG-th one, and the image's last 31 rows --
+// the next tile's halo -- are copied inside LDS to its first 31 instead of being fetched again: at /32 the halo is 31 rows of a
+// 159-row image, a fifth of everything that moves from L2 into LDS.  Each wave copies exactly the chunks its own DMA instructions
+// (32 + ww + 4k) are about to overwrite -- read, then its DMAs, then the writes: program order inside the wave, no barrier added.
+template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0, bool SUBSET = false, bool HC = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 decim_dense_kernel(const DecimMultiArgs a)
 {
     using C = DecimDense<D>;
+    static_assert(!(HC && SUBSET), "halo carry: the VGPR-tap forms");
     static_assert(!SUBSET || (D == 8 && (ABL == 0 || (ABL == 1 && !S32IN))), "subset form: /8 (CF32 or S32 wire words: the table then holds the taps times 2^-31)");
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
@@ -160,9 +165,14 @@ decim_dense_kernel(const DecimMultiArgs a)
     const long long q_hi = a.n_in > 0 ? ((a.n_in - 1) >> LOG_D) + 1 - C::TILE_OUT : -1;
     const int tile_hi = q_hi < 0 ? -1 : (int)(q_hi >> LOG_T);
     const int n_full = (int)(a.n_out >> LOG_T);
-    const int first_tile = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int wg = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    // tiles of this workgroup: every NG-th from wg on, or (HC) the run [wg K, wg K + K)
+    const int run_len = HC ? (a.n_tiles + NG - 1) / NG : 1;
+    const int first_tile = HC ? wg * run_len : wg;
+    const int end_tile = HC ? (first_tile + run_len < a.n_tiles ? first_tile + run_len : a.n_tiles) : a.n_tiles;
+    const int tile_step = HC ? 1 : NG;
     // fused history carry-over (as decim_multi_kernel): the tail of (hist ++ in) becomes the next history
-    if (first_tile == (a.n_tiles - 1) % NG && ww == C::W - 1) {
+    if ((HC ? (first_tile <= a.n_tiles - 1 && a.n_tiles - 1 < end_tile) : first_tile == (a.n_tiles - 1) % NG) && ww == C::W - 1) {
         char *ho = reinterpret_cast<char *>(a.hist_out) + 8LL * a.hist_stride * ch;
         for (int j = lane; j < C::NT; j += 64) {
             const long long s = a.n_in - C::NT + j;
@@ -194,13 +204,29 @@ decim_dense_kernel(const DecimMultiArgs a)
     // of four instructions (PER_I = 0), /16 and /8 one after every instruction (PER_I = 1).
     constexpr int PER_I = C::dma_slot(1) - 64;
     static_assert(C::dma_slot(7) == C::dma_slot(4) + 3 * (64 + PER_I), "pads inside a group of four instructions are uniform");
-    auto stage = [&](int tile) __attribute__((always_inline)) {
+    // carry (HC): the image holds tile - 1: its rows TILE_OUT .. TILE_OUT + 30 are this tile's rows 0 .. 30
+    constexpr int HALO_INSTR = 31 / C::RPI;                              // DMA instructions that hold halo rows only
+    constexpr int CARRY_SHIFT = 64 * 32 + C::TILE_OUT / C::PADROWS;      // slots between a halo row's two places
+    static_assert(C::TILE_OUT % C::PADROWS == 0, "the pads before a row and before the row TILE_OUT above it differ by a constant");
+    auto stage = [&](int tile, bool carry, bool last_of_run) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         const long long s_first = D * (M0 - 31) - (D - 1);               // first sample of the image
         const bool interior = tile >= 1 && tile <= tile_hi;
         const char *base = in + 8 * s_first + 1024 * ww;
         if constexpr (ABL == 2) return;
         if (interior) {
+            f32x4 hv[C::NIW - 8];
+            if constexpr (HC) {
+                if (carry) {
+#pragma unroll
+                    for (int k = 0; k < C::NIW - 8; ++k) {
+                        const int i = 32 + ww + 4 * k;
+                        if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES))
+                            hv[k] = lds[(64 + PER_I) * ww + C::dma_slot(4 * (8 + k)) + lane];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before this wave's DMAs overwrite them
+                }
+            }
 #pragma unroll
             for (int i0 = 0; i0 < C::NIW; ++i0) {
                 unsigned lo = 16u * lane;
@@ -214,8 +240,28 @@ decim_dense_kernel(const DecimMultiArgs a)
                 if (i0 < C::NIW - 1 || i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES)) {
                     static_assert(C::TILE_OUT / C::RPI == 32, "the halo rows start at DMA instruction 32");
                     constexpr int FIRST_NT = NTLD == 2 ? (31 / C::RPI + 4) / 4 : 0;   // i0 below this: the halo re-read, plain
-                    if (NTLD && i0 >= FIRST_NT && i0 < 8) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));   // i = ww + 4 i0 < 32
-                    else glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
+                    if constexpr (HC) {
+                        // carried tiles skip the instructions that hold halo rows only; nobody else reads a run's rows, so every
+                        // load is non-temporal but the run's last 31 rows (the next run's halo) and a run's first halo
+                        if (4 * i0 + C::W - 1 < HALO_INSTR) { if (carry) continue; }
+                        else if (4 * i0 < HALO_INSTR) { if (carry && i < HALO_INSTR) continue; }
+                        const bool plain = i0 >= 8 ? last_of_run : (!carry && i0 < FIRST_NT);
+                        if (NTLD && !plain) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
+                        else glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
+                    } else {
+                        if (NTLD && i0 >= FIRST_NT && i0 < 8) glds16<2>(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));   // i = ww + 4 i0 < 32
+                        else glds16(bi + lo, lds + ((64 + PER_I) * ww + C::dma_slot(4 * i0)));
+                    }
+                }
+            }
+            if constexpr (HC) {
+                if (carry) {
+#pragma unroll
+                    for (int k = 0; k < C::NIW - 8; ++k) {
+                        const int i = 32 + ww + 4 * k;
+                        if (i < C::NI - 1 || (i == C::NI - 1 && lane < C::LAST_LANES))
+                            lds[(64 + PER_I) * ww + C::dma_slot(4 * (8 + k)) + lane - CARRY_SHIFT] = hv[k];
+                    }
                 }
             }
         } else {
@@ -244,8 +290,8 @@ decim_dense_kernel(const DecimMultiArgs a)
         }
     };
 
-    if (first_tile < a.n_tiles) stage(first_tile);
-    for (int tile = first_tile; tile < a.n_tiles; tile += NG) {
+    if (first_tile < end_tile) stage(first_tile, false, first_tile + tile_step >= end_tile);
+    for (int tile = first_tile; tile < end_tile; tile += tile_step) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         SXFIR_PHASE(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMAs landed ...
@@ -315,7 +361,7 @@ decim_dense_kernel(const DecimMultiArgs a)
                 for (int e = 0; e < 4; ++e) y[e] = __fadd_rn(s01[e], s23[e]);
             }
             __syncthreads();                                // the exchange area may be overwritten by the next DMA
-            if (tile + NG < a.n_tiles) stage(tile + NG);
+            if (tile + NG < a.n_tiles) stage(tile + NG, false, false);
             // the slot this lane read holds chunk kq of group Gq: a permutation inside each 64-byte group, so the wave's
             // store still covers one kilobyte of consecutive bytes
             const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
@@ -330,7 +376,7 @@ decim_dense_kernel(const DecimMultiArgs a)
             }
             continue;
         }
-        if (tile + NG < a.n_tiles) stage(tile + NG);
+        if (tile + tile_step < end_tile) stage(tile + tile_step, HC, tile + 2 * tile_step >= end_tile);
         SXFIR_PHASE(4)
 
         // ---- reduction in the order of the numeric contract.  p (lane bit 4): even 16-lane rows keep

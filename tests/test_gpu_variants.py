@@ -16,7 +16,7 @@ from gpu_util import assert_bit_exact, to_cpu, to_gpu
 pytestmark = pytest.mark.gpu
 
 KNOBS = ("SXFIR_TILE_VARIANT", "SXFIR_OVERSUB", "SXFIR_OCC", "SXFIR_ABLATE", "SXFIR_SCHED", "SXFIR_LDS_PAD", "SXFIR_DENSE_NT",
-         "SXFIR_DENSE", "SXFIR_MULTI_W", "SXFIR_MULTI_PS")
+         "SXFIR_DENSE", "SXFIR_MULTI_W", "SXFIR_MULTI_PS", "SXFIR_DENSE_HC")
 
 
 @pytest.mark.parametrize("env", [
@@ -286,3 +286,28 @@ def test_x8_interpolator_forms_to_wire_words_match_oracle(oracle, monkeypatch, i
         keyed = (want[0::2] & 3) == 3
         assert keyed.any() and (~keyed).any()
     assert int(counter.item()) == want_count
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,oversub", [(32, "8"), (32, "1"), (32, "64"), (16, "8"), (16, "3")])
+def test_dense_halo_carry_matches_oracle(oracle, monkeypatch, D, oversub):
+    """decim_dense_kernel<D, ..., HC> (SXFIR_DENSE_HC=1): runs of consecutive tiles per workgroup, the next tile's halo copied inside
+    LDS instead of fetched again.  Streaming over several calls -- a first call whose tile 0 takes its halo from the plan's history,
+    long interior runs (carried tiles), a ragged last tile, a call shorter than one tile -- and several channels, against the oracle."""
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_DENSE_HC", "1")
+    monkeypatch.setenv("SXFIR_OVERSUB", oversub)
+    T = 128 if D == 32 else 256
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    nchan, lens = 2, [T * 700 + 6, 4, T * 64, T * 1500 + T // 2]      # even output counts: 16-byte aligned channel rows
+    x = np.stack([oracle.synth_iq(0x51255, 60 + c, 0, D * sum(lens)) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D, nchan=nchan, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        outs.append(to_cpu(plan.process(to_gpu(np.ascontiguousarray(x[:, D * pos:D * (pos + n)])))))
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert_bit_exact(y[c], oracle.decim_f32(h, D, x[c], 2, 4), "/%d halo carry, channel %d" % (D, c))

@@ -42,6 +42,7 @@ for v, ov, occ, abl, sched, pad in configs:
     os.environ.pop("SXFIR_DENSE_NT", None)
     # /8 CF32: "dense" / "x" = as shipped (the scalar-tap subset form), "densev" = the VGPR-tap form; "densent" etc. imply the VGPR form
     os.environ["SXFIR_DENSE_SUBSET"] = "0" if v in ("densev", "densent", "densepl", "densent2") else "1"
+    os.environ["SXFIR_DENSE_HC"] = "1" if v == "densehc" else "0"          # densehc: halo carry (/32, /16)
     if v in ("densent", "densepl", "densent2"): os.environ["SXFIR_DENSE_NT"] = {"densent": "1", "densepl": "0", "densent2": "2"}[v]   # densent2: both halos plain
     os.environ["SXFIR_DENSE"] = "0" if v[0] == "w" else "1"   # "dense" (or "x"): decim_dense_kernel at /8, /16, /32; "w4": the multi-column kernel
     if v[0] == "w":                                  # "w4": multi kernel, 4 waves per workgroup; "w8p4": 4-way row split
