@@ -35,6 +35,7 @@
 #   mb5[:filter]        tools/membench5.hip: the round-4 streaming sweep (shape x bytes in flight x cache policy)
 #   mb5pmc:filter       memory-side counters (TCC_EA0_*, TCP_PENDING_STALL, SQ_WAIT_INST_ANY ...) of the cases matching filter
 #   listpmc             rocprofv3 --list-avail (which counters this box exposes)
+#   kbq                 the shipped /4 and /32 kernels on IQ quantised to 1..16 fractional bits: time against operand entropy
 #   kbhc                dense /32, /16 with halo carry (runs of consecutive tiles, halo copied inside LDS) against the shipped form
 #   walls               every shipped kernel on random IQ, on zeros and its memory side alone (long visits, one box)
 #   prices[:seconds]    tools/price_list.py: dynamic energy per launch of the arithmetic probe's mixes -> nJ per extra instruction
@@ -171,6 +172,14 @@ for S in "$@"; do
                 KB_D=$D KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py dense:8:0:0:0 densehc:8:0:0:0 densehc:4:0:0:0 densehc:16:0:0:0 densehc:2:0:0:0 dense:8:0:0:0:16 >> $LOG 2>&1 || RC=$?
                 KB_ZERO=1 KB_D=$D KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py dense:8:0:0:0 densehc:8:0:0:0 dense:8:0:1:0 densehc:8:0:1:0 >> $LOG 2>&1 || RC=$?
               done; grep -v "amdgpu.ids" $LOG | grep "ms med\|skipped\|DIFFERENT\|all-zero" ;;
+    kbq)      # the shipped /4 (and /8, /32) kernel on the same IQ quantised to 1 / 4 / 8 / 12 / 16 fractional bits, on zeros and at full precision: time against operand entropy
+              for D in 4 32; do
+                V=$([ $D = 4 ] && echo x:16:0:0:0 || echo dense:8:0:0:0)
+                echo "## /$D" >> $LOG
+                KB_ZERO=1 KB_D=$D KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 300 python3 tools/kbench.py $V >> $LOG 2>&1 || RC=$?
+                for Q in 1 4 8 12 16; do KB_QBITS=$Q KB_D=$D KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 300 python3 tools/kbench.py $V >> $LOG 2>&1 || RC=$?; done
+                KB_D=$D KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 300 python3 tools/kbench.py $V >> $LOG 2>&1 || RC=$?
+              done; grep -v "amdgpu.ids" $LOG | grep "^##\|^# input\|all-zero\|ms med" ;;
     mb5)      hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && timeout 900 /tmp/membench5 "$ARG" >> $LOG 2>&1; RC=$?; grep -v "amdgpu.ids" $LOG | tail -150 ;;
     mb5pmc)   hipcc --offload-arch=gfx950 -O3 -w tools/membench5.hip -o /tmp/membench5 >> $LOG 2>&1 && bash tools/mb5_pmc.sh $OUT "$ARG" >> $LOG 2>&1; RC=$?; tail -60 $LOG ;;
     listpmc)  timeout 120 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1; RC=$?; grep -c . $OUT/list_avail.txt ;;

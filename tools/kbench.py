@@ -29,6 +29,11 @@ sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=FMT)
 if os.environ.get("KB_ZERO") == "1":                 # all-zero input: no toggling in the FMA datapath, the clock stays free of the power cap
     x.zero_()
     print("# all-zero input (KB_ZERO=1): the kernel's structure without the power cap")
+if os.environ.get("KB_QBITS"):                       # the same IQ quantised to q fractional bits: fewer toggling mantissa bits per FMA operand
+    q = float(1 << int(os.environ["KB_QBITS"]))
+    xr = torch.view_as_real(x)
+    xr.copy_(torch.round(xr * q) / q)
+    print("# input quantised to %s fractional bits (KB_QBITS)" % os.environ["KB_QBITS"])
 yoff = int(os.environ.get("KB_YOFF", "0"))          # output buffer displaced by this many bytes (HBM channel phase probe)
 ybase = torch.empty(nchan * (n // D) * (4 if FMT == "CF16" else 8) + yoff + 64, dtype=torch.uint8, device="cuda")
 y = ybase[yoff:yoff + nchan * (n // D) * (4 if FMT == "CF16" else 8)].view(dt).view(nchan, n // D)
