@@ -2,11 +2,15 @@
 """Generate the committed golden fixtures under tests/golden/.
 
 Nothing here imports the oracle or the product: every expected value comes
-from an INDEPENDENT route (numpy/scipy fp64, exact rational arithmetic, or
-hand evaluation of the reference's arithmetic), so the fixtures can pin the
-oracle.  The reference itself (tejeez/sxxcvr) has no tests, no vectors and no
-software FIR, and cannot be built in this image (SoapySDR + ALSA headers are
-absent), so none of these values come from a reference run.
+from an INDEPENDENT route (numpy/scipy fp64, exact rational arithmetic, hand
+evaluation of the reference's arithmetic, or the reference's own code), so the
+fixtures can pin the oracle.  The reference itself (tejeez/sxxcvr) has no
+tests, no vectors and no software FIR, and its translation unit as a whole
+cannot be built in this image (SoapySDR + ALSA headers are absent).  The one
+piece of per-sample arithmetic it owns CAN be compiled: convert_rx_buffer /
+convert_tx_buffer (SoapySX.cpp:103-137) -- convert_kat.npz holds the output of
+those two functions compiled from /root/reference (oracle/Makefile target
+`ref`; needs this container).  Everything else comes from the other routes.
 
 Run:  python tests/golden/make_golden.py      (rewrites the fixture files)
 """
@@ -121,16 +125,85 @@ def conv_tx_numpy(x, thr2):
     return v.astype(np.int64)
 
 
+REF_LIB = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libsxref_convert.so")
+
+
+def load_reference_converters():
+    """oracle/_ref/libsxref_convert.so: the reference's own convert_rx_buffer / convert_tx_buffer
+    (SoapySX/SoapySX.cpp:103-137), compiled from /root/reference by `make -C oracle ref` (container only; those
+    two functions need three standard headers and nothing else).  None when the reference is not here."""
+    import ctypes as C
+    import subprocess
+    odir = os.path.dirname(os.path.dirname(REF_LIB))
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", odir, "-s", "ref"])
+    if not os.path.exists(REF_LIB):
+        return None
+    lib = C.CDLL(REF_LIB)
+    sz, vp = C.c_size_t, C.c_void_p
+    lib.sxref_convert_rx_buffer.argtypes = [vp, sz, vp, sz, sz]
+    lib.sxref_convert_tx_buffer.argtypes = [vp, sz, vp, sz, sz, C.c_float]
+    lib.sxref_provenance.restype = C.c_char_p
+    return lib
+
+
+def savez_deterministic(path, **arrays):
+    """np.savez with fixed zip timestamps: the same arrays give the same bytes."""
+    import zipfile
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        for name, a in arrays.items():
+            info = zipfile.ZipInfo(name + ".npy", date_time=(1980, 1, 1, 0, 0, 0))
+            info.external_attr = 0o644 << 16
+            with z.open(info, "w", force_zip64=False) as f:
+                np.lib.format.write_array(f, np.asanyarray(a), allow_pickle=False)
+
+
 def make_conv():
+    """convert_kat.npz = inputs + what the REFERENCE's own compiled converters return for them (x86-64 build of
+    SoapySX.cpp:103-137), with one stated exception: rows of tx_in the C++ leaves undefined (a component that is
+    >= 1.0 after the clamp, or NaN: the float -> int32 conversion at :124-125 overflows) carry
+    the saturating definition (what the reference's AArch64 platform executes) from conv_tx_numpy instead, and
+    tx_defined marks them 0.  The numpy route is asserted equal to the reference on every defined row, so the
+    two routes pin each other."""
+    import ctypes as C
+    ref = load_reference_converters()
+    if ref is None:
+        print("convert_kat.npz / convert_hand.json kept as committed: /root/reference is not here, "
+              "and their expected values are the reference's own output")
+        return
     rng = np.random.default_rng(1255)
-    s32 = rng.integers(-(2 ** 31), 2 ** 31, size=512, dtype=np.int64).astype(np.int32)
-    s32[:6] = [2 ** 31 - 1, 0x7FFFFF80, -(2 ** 31), 1, 0, -1]
-    rx = (s32.astype(np.float32) * np.float32(2.0 ** -31)).astype(np.float32)
-    tx_in = (rng.uniform(-1.2, 1.2, size=256) + 1j * rng.uniform(-1.2, 1.2, size=256)).astype(np.complex64)
-    tx_in[:8] = [0.5 + 0j, -0.25 + 0j, 1.0 + 1.0j, -1.0 - 1.0j, 2.0 - 3.0j, 1e-4 + 1e-4j, 0j, 0.001 + 0j]
+    n = 1 << 15                                                         # complex samples: 2^16 words each way
+    s32 = rng.integers(-(2 ** 31), 2 ** 31, size=2 * n, dtype=np.int64).astype(np.int32)
+    s32[:8] = [2 ** 31 - 1, 0x7FFFFF80, -(2 ** 31), 1, 0, -1, 0x7FFFFFBF, 0x7FFFFFC0]     # SURVEY.md 8 a-3 edges, RNE tie
+    rx = np.empty(2 * n, dtype=np.float32)
+    # offsets exercised too: the second half is converted by a call with src_offset = dest_offset = n / 2
+    ref.sxref_convert_rx_buffer(s32.ctypes.data_as(C.c_void_p), 0, rx.ctypes.data_as(C.c_void_p), 0, n // 2)
+    ref.sxref_convert_rx_buffer(s32.ctypes.data_as(C.c_void_p), n // 2, rx.ctypes.data_as(C.c_void_p), n // 2, n - n // 2)
+    assert np.array_equal(rx, (s32.astype(np.float32) * np.float32(2.0 ** -31)).astype(np.float32)), \
+        "numpy route and the reference's convert_rx_buffer disagree"
+    tx_in = (rng.uniform(-1.2, 1.2, size=n) + 1j * rng.uniform(-1.2, 1.2, size=n)).astype(np.complex64)
+    # a tenth of the block around the keying threshold (|v| ~ 1e-3), where fi*fi + fq*fq >= thr2 decides bit 0-1
+    k = n // 10
+    tx_in[n - k:] = (rng.uniform(-1.5e-3, 1.5e-3, size=k) + 1j * rng.uniform(-1.5e-3, 1.5e-3, size=k)).astype(np.complex64)
+    below1 = float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+    edges = [0.5 + 0j, -0.25 + 0j, 1.0 + 1.0j, -1.0 - 1.0j, 2.0 - 3.0j, 1e-4 + 1e-4j, 0j, 0.001 + 0j,
+             complex(below1, -below1), complex(-1.2, 0.999), complex(0.0, 1.0), complex(np.nan, 0.5),
+             complex(6e-4, 8e-4), complex(float(np.float32(1e-3)), 0.0), complex(-0.0, 1e-3), complex(1e-30, -1e-30)]
+    tx_in[:len(edges)] = np.array(edges, dtype=np.complex64)
     thr = np.float32(1.0e-3)
     thr2 = np.float32(thr * thr)                          # SoapySX.cpp:767-773
-    tx = conv_tx_numpy(tx_in, thr2)
+    tx_ref = np.empty(2 * n, dtype=np.int32)
+    ref.sxref_convert_tx_buffer(tx_in.ctypes.data_as(C.c_void_p), 0, tx_ref.ctypes.data_as(C.c_void_p), 0, n // 2, thr2)
+    ref.sxref_convert_tx_buffer(tx_in.ctypes.data_as(C.c_void_p), n // 2, tx_ref.ctypes.data_as(C.c_void_p), n // 2,
+                                n - n // 2, thr2)
+    f = tx_in.view(np.float32)
+    comp_defined = ~(np.isnan(f) | (f >= np.float32(1.0)))            # per component: 2^31 * 1.0f does not fit int32
+    defined = comp_defined[0::2] & comp_defined[1::2]
+    sat = conv_tx_numpy(tx_in, thr2).astype(np.int32)
+    rows = np.repeat(defined, 2)
+    assert np.array_equal(sat[rows], tx_ref[rows]), "numpy route and the reference's convert_tx_buffer disagree"
+    tx = np.where(rows, tx_ref, sat).astype(np.int32)
+    prov = ref.sxref_provenance().decode() + "; g++ -O2 -ffp-contract=off, x86-64; via oracle/Makefile target ref"
     hand = {
         # SURVEY.md section 8 a-3: exactly ldexpf((float)x, -31)
         "rx": [[2 ** 31 - 1, 1.0], [0x7FFFFF80, float.fromhex("0x1.fffffep-1")], [-(2 ** 31), -1.0],
@@ -141,10 +214,25 @@ def make_conv():
                [1.0, 1.0, 0x7FFFFFFF, 0x7FFFFFFC], [-1.0, -1.0, -(2 ** 31) + 3, -(2 ** 31)],
                [1e-4, 1e-4, 214748 & ~3, 214748 & ~3]],
     }
-    np.savez(os.path.join(HERE, "convert_kat.npz"), s32=s32, rx=rx, tx_in=tx_in, tx=tx.astype(np.int32),
-             thr2=np.array([thr2], dtype=np.float32))
+    # the hand values of the defined rows are what the reference returns, too
+    for fi, fq, vi, vq in hand["tx"]:
+        if fi < 1.0 and fq < 1.0:
+            one = np.array([fi + 1j * fq], dtype=np.complex64)
+            o = np.empty(2, dtype=np.int32)
+            ref.sxref_convert_tx_buffer(one.ctypes.data_as(C.c_void_p), 0, o.ctypes.data_as(C.c_void_p), 0, 1, thr2)
+            assert (int(o[0]), int(o[1])) == (vi, vq), (fi, fq, o)
+    for sv, fv in hand["rx"]:
+        one = np.array([sv, sv], dtype=np.int32)
+        o = np.empty(2, dtype=np.float32)
+        ref.sxref_convert_rx_buffer(one.ctypes.data_as(C.c_void_p), 0, o.ctypes.data_as(C.c_void_p), 0, 1)
+        assert o[0] == np.float32(fv) and o[1] == np.float32(fv), (sv, o)
+    savez_deterministic(os.path.join(HERE, "convert_kat.npz"), s32=s32, rx=rx, tx_in=tx_in, tx=tx,
+                        tx_defined=defined.astype(np.uint8), thr2=np.array([thr2], dtype=np.float32),
+                        provenance=np.frombuffer(prov.encode(), dtype=np.uint8))
     with open(os.path.join(HERE, "convert_hand.json"), "w") as f:
         json.dump(hand, f)
+    print("convert_kat.npz: %d wire words / %d CF32 samples through the reference's converters (%s); "
+          "%d tx rows undefined in the C++ carry the saturating definition" % (s32.size, n, prov, int((~defined).sum())))
 
 
 # --------------------------------------------------------------------------

@@ -80,6 +80,8 @@ def test_s32_wire_converters(oracle, golden_dir):
                                                       s32.size // 2, None))
     _sync()
     assert_bit_exact(to_cpu(dst), oracle.convert_rx(s32), "convert_rx")
+    # ... and against the fixture itself: the output of the reference's compiled convert_rx_buffer (SoapySX.cpp:103-112)
+    assert np.array_equal(to_cpu(dst)[: kat["s32"].size // 2].view(np.uint32), kat["rx"].view(np.uint32))
     tx_in = np.concatenate([kat["tx_in"], (rng.uniform(-1.3, 1.3, 50000) + 1j * rng.uniform(-1.3, 1.3, 50000)),
                             [complex(np.nan, 0.5), complex(np.inf, -np.inf), 1 + 1j, -1 - 1j]]).astype(np.complex64)
     thr2 = float(kat["thr2"][0])
