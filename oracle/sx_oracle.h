@@ -14,13 +14,23 @@
  *    with respect to the reference.  They are pinned instead against an
  *    independent implementation (scipy.signal.upfirdn, fp64) by
  *    tests/golden/make_golden.py + tests/test_oracle_golden.py.
- *  - convert_rx / convert_tx / stream position rules: clean-room restatement
- *    of SoapySX.cpp:103-137 and :897-1085.  The reference has no automated
- *    tests, no golden vectors and cannot be built in this image (it needs the
- *    SoapySDR and ALSA development headers, both absent), so these are
- *    "parity unpinned" too; the known-answer values in tests/golden come from
- *    hand evaluation of the reference's arithmetic and from SURVEY.md's probe
- *    notes, not from a reference run made by this repo.
+ *  - convert_rx / convert_tx: restatement of SoapySX.cpp:103-137.  PINNED BY
+ *    THE REFERENCE: these two functions are the only part of the reference's
+ *    translation unit that compiles in this image (three standard headers),
+ *    and `make -C oracle ref` compiles them as they lie under /root/reference
+ *    into oracle/_ref/libsxref_convert.so.  tests/golden/convert_kat.npz is
+ *    that library's output (make_golden.py), and test_oracle_golden.py runs
+ *    the restatement against it on 2^20 fresh samples in the container.  Rows
+ *    the C++ leaves undefined (a component >= 1.0f or NaN overflows the
+ *    float -> int32 conversion at :124-125) follow the saturating definition
+ *    below; they are marked in the fixture (tx_defined).
+ *  - stream position rules: clean-room restatement of SoapySX.cpp:897-1085.
+ *    The reference has no automated tests and no golden vectors, and the rest
+ *    of its translation unit cannot be built in this image (it needs the
+ *    SoapySDR and ALSA development headers, both absent; no stand-ins are
+ *    written), so these stay "parity unpinned"; the known-answer traces in
+ *    tests/golden come from hand evaluation of the reference's arithmetic
+ *    and from SURVEY.md's probe notes, not from a reference run.
  *  - ticksToTimeNs / timeNsToTicks: third-party (SoapySDR lib/TimeC.cpp,
  *    version unpinned by the reference: find_package(SoapySDR CONFIG) without
  *    a version, SoapySX/CMakeLists.txt:45).  Restated from the published

@@ -1,0 +1,483 @@
+// Kernel dispatch of the C ABI: the launch tables of the decimators and interpolators (which kernel, which grid, which
+// tap table for a plan) and the streaming entry points sxfir_decimate / sxfir_interpolate / sxfir_interpolate_keyed
+// (launch, history carry-over, position commit).  Included by sxfir.hip after sxfir_plan.hip.h.
+#pragma once
+
+extern "C" {
+
+// Generic path: the next call's history goes to the plan's other buffer (the caller swaps the two).
+static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, hipStream_t st)
+{
+    const dim3 grid((unsigned)((p->hist_len + 255) / 256), (unsigned)p->nchan);
+    if (p->fmt != SXFIR_CF16)
+        hipLaunchKernelGGL(sxfir::history_kernel<float2>, grid, dim3(256), 0, st, (float2 *)p->hist_alt,
+                           (const float2 *)p->hist_dev, (const float2 *)in_dev, (long long)n_in, (long long)in_stride,
+                           (long long)p->hist_len, p->hist_len);
+    else
+        hipLaunchKernelGGL(sxfir::history_kernel<uint32_t>, grid, dim3(256), 0, st, (uint32_t *)p->hist_alt,
+                           (const uint32_t *)p->hist_dev, (const uint32_t *)in_dev, (long long)n_in,
+                           (long long)in_stride, (long long)p->hist_len, p->hist_len);
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+#ifdef SXFIR_PROFILING
+#include "sxfir_prof_dispatch.inc"   // the A/B variants' launch tables: 0 = not mine, 1 = launched, < 0 = error
+#endif
+
+// Launch only the resampling kernel (no history update, no position change).
+static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                        size_t out_stride, long long n_out, hipStream_t st, bool *history_done)
+{
+    *history_done = false;
+    const long long D = p->ratio;
+    const long long first = ((p->consumed + D - 1) / D) * D - p->consumed;
+    // LDS-DMA sources need no 16-byte alignment (verified on MI355X, tools/probe_unaligned.hip): only the
+    // output, written with 16-byte stores, must be aligned
+    bool tiled = p->tile_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
+                 ((uintptr_t)out_dev % 16 == 0) && (p->nchan == 1 || out_stride % 2 == 0);
+    const bool multi = p->multi_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
+                       ((uintptr_t)out_dev % 16 == 0) &&
+                       (p->nchan == 1 || out_stride % (p->fmt == SXFIR_CF16 ? 4 : 2) == 0);
+    if (multi) {
+        sxfir::DecimMultiArgs a;
+        a.in = in_dev;
+        a.hist = p->hist_dev;
+        a.hist_out = p->hist_alt;
+        a.out = out_dev;
+        a.taps = p->taps_dev;
+        a.n_in = (long long)n_in;
+        a.n_out = n_out;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hist_stride = p->hist_len;
+        const int W = p->multi_waves;
+        const int tile_out = W * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
+        const long long n_tiles = (n_out + tile_out - 1) / tile_out;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        long long groups = ((long long)p->compute_units * p->occ_multi * p->oversub) / p->nchan;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        a.n_tiles = (int)n_tiles;
+        a.n_groups = (int)groups;
+        dim3 grid((unsigned)groups, (unsigned)p->nchan);
+        a.stamps = nullptr;
+        if (p->dense32) {
+            // non-temporal staging loads for the image rows no other tile reads (NTLD = 2: both halos stay plain loads),
+            // measured in round 4 (profiles/round4h_kbench_both_halos_plain.txt: whole kernel -0.9 % at /32, -2.8 % at /8
+            // and /16 against plain loads; with only the next tile's halo plain /32 lost 1.4 %)
+#define SXFIR_DENSE_LAUNCH(DD, AA, SS, NN) hipLaunchKernelGGL((sxfir::decim_dense_kernel<DD, AA, SS, NN>), grid, dim3(256), 0, st, a)
+#ifdef SXFIR_PROFILING
+            if (const int pr = prof_launch_dense(p, a, grid, st, groups, W)) {       // ablations, stamps, nt-load A/B
+                if (pr < 0) return pr;
+                *history_done = true;
+                return SXFIR_OK;
+            }
+#endif
+            if (p->dense_subset) {
+                a.taps = p->taps_scaled_dev;                      // the subset-major tap table
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, true, 2, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 2, true>), grid, dim3(256), 0, st, a);
+            }
+#ifdef SXFIR_PROFILING
+            else if (p->ratio == 8 && p->fmt == SXFIR_S32) SXFIR_DENSE_LAUNCH(8, 0, true, 2);   // the VGPR-tap forms at /8: A/B partners only
+            else if (p->ratio == 8) SXFIR_DENSE_LAUNCH(8, 0, false, 2);
+#endif
+            else if (p->fmt == SXFIR_S32 && p->ratio == 16) SXFIR_DENSE_LAUNCH(16, 0, true, 2);
+            else if (p->fmt == SXFIR_S32) SXFIR_DENSE_LAUNCH(32, 0, true, 2);
+            else if (p->ratio == 16) SXFIR_DENSE_LAUNCH(16, 0, false, 2);
+            else SXFIR_DENSE_LAUNCH(32, 0, false, 2);
+#undef SXFIR_DENSE_LAUNCH
+            HIPCHECK(hipGetLastError());
+            *history_done = true;
+            return SXFIR_OK;
+        }
+#ifdef SXFIR_PROFILING
+        if (const int pr = prof_launch_multi(p, a, grid, st, groups, W)) {           // S32 words, ablations, stamps
+            if (pr < 0) return pr;
+            *history_done = true;
+            return SXFIR_OK;
+        }
+#endif
+        const int key = SXFIR_MULTI_KEY(p->ratio, W, p->fmt == SXFIR_CF16, p->multi_ps);
+        switch (key) {
+#define SXFIR_X(DD, WW, HH, PP) \
+        case SXFIR_MULTI_KEY(DD, WW, HH, PP): \
+            hipLaunchKernelGGL((sxfir::decim_multi_kernel<DD, WW, HH, 0, PP>), grid, dim3(64 * WW), 0, st, a); \
+            break;
+            SXFIR_MULTI_VARIANTS(SXFIR_X)
+#undef SXFIR_X
+        default: return fail(SXFIR_EUNSUPPORTED, "no multi kernel for ratio %d with %d waves (mode %d)", p->ratio, W, key);
+        }
+        HIPCHECK(hipGetLastError());
+        *history_done = true;
+        return SXFIR_OK;
+    }
+    if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
+        return fail(SXFIR_EUNSUPPORTED,
+                    "tiled kernel needs a 16-byte aligned output, an even output stride and a call that starts on "
+                    "an output boundary");
+    if (tiled) {
+        sxfir::DecimTileArgs a;
+        a.long_waves = a.long_tiles = a.long_w8 = a.short_w8 = 0;
+        a.in = (const float *)in_dev;
+        a.hist = (const float *)p->hist_dev;
+        a.hist_out = (float *)p->hist_alt;
+        a.out = (float *)out_dev;
+        *history_done = true;      // caller swaps hist_dev / hist_alt when it commits the call
+        a.taps = p->taps_dev;
+        a.taps_scaled = p->taps_scaled_dev;
+        memcpy(a.taps_k, p->taps_k, sizeof(a.taps_k));
+        a.n_in = (long long)n_in;
+        a.n_out = n_out;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hist_stride = p->hist_len;
+        int tile_out = 256;
+#ifdef SXFIR_PROFILING
+        if (p->sgpr_r && p->ntaps == 128) tile_out = 64 * p->sgpr_r;
+#endif
+        const long long n_tiles = (n_out + tile_out - 1) / tile_out;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        a.n_tiles = (int)n_tiles;
+        a.sched = p->sched;
+        a.stamps = nullptr;
+#ifdef SXFIR_PROFILING
+        if (const int pr = prof_launch_tile_variant(p, a, n_out, n_tiles, st)) return pr < 0 ? pr : SXFIR_OK;   // pair / wide / tile2 variants
+#endif
+        if (p->wide8 && p->sched != 1) {
+            // 128 symmetric taps: decim4_wide_kernel, tiles of 512 outputs, one wave (= one workgroup) per tile and pass;
+            // G = CUs x 8 resident waves x 16 generations waves per launch, strided XCD-blocked passes
+            const long long n_tiles2 = (n_out + 511) / 512;
+            long long G = ((long long)p->compute_units * p->occ_wide * p->oversub) / p->nchan;
+            if (G < 1) G = 1;
+            if (G > n_tiles2) G = n_tiles2;
+            a.n_tiles = (int)n_tiles2;
+            a.n_waves = (int)G;
+            a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
+            a.run_base = a.run_extra = 0;
+            {
+                const int t = (int)((n_tiles2 - 1) % G);
+                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+            }
+            dim3 grid((unsigned)G, (unsigned)p->nchan);
+            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
+            HIPCHECK(hipGetLastError());
+            return SXFIR_OK;
+        }
+        // Short-lived waves in generations: W = CUs * resident waves * oversub waves per launch, each covering
+        // n_tiles / W tiles in strided, XCD-blocked passes (sxfir_decim_tile.hip.h).
+        const bool dbuf = p->tile_dbuf;
+        long long per_chan = ((long long)p->compute_units * (dbuf ? p->occ_db : p->occ_sb) * p->oversub) / p->nchan;
+        if (per_chan < 1) per_chan = 1;
+        if (per_chan > n_tiles) per_chan = n_tiles;
+        a.n_waves = (int)per_chan;
+        {
+            const int W = (int)per_chan, last = (int)n_tiles - 1;
+            a.w8 = (W % 8 == 0) ? W / 8 : 0;
+            a.run_base = (int)(n_tiles / W);
+            a.run_extra = (int)(n_tiles % W);
+            if (p->sched == 1) {
+                a.hist_wave = a.run_base >= 1 ? W - 1 : last;           // owner of the last contiguous run
+            } else {
+                const int t = last % W;                                  // first tile of the owner's sequence
+                a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
+            }
+        }
+#ifdef SXFIR_PROFILING
+        prof_short_tail(p, a, n_tiles, &per_chan);                                    // SXFIR_SCHED=3
+#endif
+        dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
+#ifdef SXFIR_PROFILING
+        if (const int pr = prof_launch_tile_first_gen(p, a, grid, per_chan, dbuf, st)) return pr < 0 ? pr : SXFIR_OK;
+#endif
+#ifdef SXFIR_PROFILING
+        // "t2s": round 3's shipped form (with one wave per workgroup both kernels take the same schedule constants)
+        if (p->ntaps == 128 && p->symmetric && p->sched != 1) {
+            if (p->fmt == SXFIR_S32)
+                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED, 0, true>), grid, dim3(64), 0, st, a);
+            else
+                hipLaunchKernelGGL((sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>), grid, dim3(64), 0, st, a);
+        } else
+#endif
+        if (p->fmt == SXFIR_S32)
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false, 0, true>), grid, dim3(64), 0, st, a);
+        else if (p->ntaps == 128)
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<128, false>), grid, dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL((sxfir::decim4_tile_kernel<64, false>), grid, dim3(64), 0, st, a);
+    } else {
+        sxfir::GenericArgs a;
+        a.in = in_dev;
+        a.hist = p->hist_dev;
+        a.out = out_dev;
+        a.taps = p->taps_dev;
+        a.n_in = (long long)n_in;
+        a.n_out = n_out;
+        a.in_stride = (long long)in_stride;
+        a.out_stride = (long long)out_stride;
+        a.hist_stride = p->hist_len;
+        a.first = first;
+        a.ntaps = p->ntaps;
+        a.ratio = p->ratio;
+        a.hist_len = p->hist_len;
+        a.jsplit = p->jsplit;
+        a.cw = p->cw;
+        dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
+        a.thr2 = p->thr2;
+        if (p->fmt == SXFIR_CF32)
+            hipLaunchKernelGGL(sxfir::decim_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, st, a);
+        else if (p->fmt == SXFIR_CF16)
+            hipLaunchKernelGGL(sxfir::decim_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((sxfir::decim_generic_kernel<sxfir::S32, sxfir::CF32>), grid, dim3(256), 0, st, a);
+    }
+    HIPCHECK(hipGetLastError());
+    return SXFIR_OK;
+}
+
+static int check_io(const sxfir_plan *p, int mode, const void *in_dev, size_t n_in, size_t in_stride,
+                    const void *out_dev, size_t out_stride, long long n_out)
+{
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (p->mode != mode) return fail(SXFIR_EINVAL, "plan was created for the other direction");
+    if ((n_in && !in_dev) || (n_out > 0 && !out_dev)) return fail(SXFIR_EINVAL, "NULL device buffer");
+    if (p->nchan > 1 && (in_stride < n_in || out_stride < (size_t)n_out))
+        return fail(SXFIR_EINVAL, "channel stride smaller than the block");
+    if ((uintptr_t)in_dev % sample_bytes(p->fmt) || (uintptr_t)out_dev % sample_bytes(p->fmt))
+        return fail(SXFIR_EINVAL, "buffers must be aligned to one complex sample");
+    return SXFIR_OK;
+}
+
+int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                   size_t out_stride, size_t *n_out_p, void *stream)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    const long long n_out = outputs_for(p, (long long)n_in);
+    int rc = check_io(p, SXFIR_DECIMATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+    if (rc) return rc;
+    if (n_in == 0) return SXFIR_OK;
+    HIPCHECK(hipSetDevice(p->device));
+    bool history_done = false;
+    if (n_out > 0) {
+        rc = launch_decim(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done);
+        if (rc) return rc;
+    }
+    if (!history_done) {
+        rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+        if (rc) return rc;
+    }
+    std::swap(p->hist_dev, p->hist_alt);
+    p->consumed += (long long)n_in;
+    p->produced += n_out;
+    if (n_out_p) *n_out_p = (size_t)n_out;
+    return SXFIR_OK;
+}
+
+// Launch only the interpolation kernel (no history swap, no position change).
+// key: count the input samples [lo, hi) of channel 0 that reach the plan's keying threshold into *counter
+struct KeyedRange { unsigned long long *counter; long long lo, hi; };
+static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                         size_t out_stride, long long n_out, hipStream_t st, bool *history_done,
+                         const KeyedRange *key = nullptr)
+{
+    *history_done = false;
+    const bool tiled = p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && ((uintptr_t)out_dev % 16 == 0) &&
+                       (p->nchan == 1 || out_stride % 2 == 0);
+    if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
+        return fail(SXFIR_EUNSUPPORTED, "tiled interpolator needs a 16-byte aligned output and even strides");
+    if (tiled && p->ipass) {
+        // x8, 256 taps, CF32: the scalar-tap form, tiles of 128 inputs (two per lane), four (phase group, row half) passes per tile
+        sxfir::InterpTileArgs t;
+        t.in = (const float *)in_dev;
+        t.hist = (const float *)p->hist_dev;
+        t.hist_out = (float *)p->hist_alt;
+        t.out = (float *)out_dev;
+        t.taps = p->taps_scaled_dev;                            // the pass-major table
+        t.n_in = (long long)n_in;
+        t.in_stride = (long long)in_stride;
+        t.out_stride = (long long)out_stride;
+        t.hist_stride = p->hist_len;
+        const int tile_in = 64 * p->ipass_qi;
+        const long long n_tiles = ((long long)n_in + tile_in - 1) / tile_in;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        long long groups = ((long long)p->compute_units * p->occ_ipass * p->oversub) / p->nchan;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        t.n_tiles = (int)n_tiles;
+        t.n_groups = (int)groups;
+        t.thr2 = p->thr2;
+        t.key_counter = key ? key->counter : nullptr;
+        t.key_lo = key ? key->lo : 0;
+        t.key_hi = key ? key->hi : 0;
+        const dim3 pgrid((unsigned)groups, (unsigned)p->nchan);
+#ifdef SXFIR_PROFILING
+        if (p->ipass_qi == 4 && p->fmt == SXFIR_S32) return fail(SXFIR_EUNSUPPORTED, "four inputs per lane: CF32 only");
+        else if (p->ipass_qi == 4 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true>), pgrid, dim3(64), 0, st, t);
+        else if (p->ipass_qi == 4) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4>), pgrid, dim3(64), 0, st, t);
+        else
+#endif
+        if (p->fmt == SXFIR_S32 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true, true>), pgrid, dim3(64), 0, st, t);
+        else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, false, true>), pgrid, dim3(64), 0, st, t);
+        else if (key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true>), pgrid, dim3(64), 0, st, t);
+        else hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2>), pgrid, dim3(64), 0, st, t);
+        HIPCHECK(hipGetLastError());
+        *history_done = true;
+        return SXFIR_OK;
+    }
+    if (tiled) {
+        sxfir::InterpTileArgs t;
+        t.in = (const float *)in_dev;
+        t.hist = (const float *)p->hist_dev;
+        t.hist_out = (float *)p->hist_alt;
+        t.out = (float *)out_dev;
+        t.taps = p->taps_dev;
+        t.n_in = (long long)n_in;
+        t.in_stride = (long long)in_stride;
+        t.out_stride = (long long)out_stride;
+        t.hist_stride = p->hist_len;
+        const int qt = 4 * 4 * (32 / (p->ratio / 4));          // InterpTile<L>::TILE_IN
+        const long long n_tiles = ((long long)n_in + qt - 1) / qt;
+        if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
+        long long groups = ((long long)p->compute_units * 16 * p->oversub) / p->nchan;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        t.n_tiles = (int)n_tiles;
+        t.n_groups = (int)groups;
+        t.thr2 = p->thr2;
+        t.key_counter = key ? key->counter : nullptr;
+        t.key_lo = key ? key->lo : 0;
+        t.key_hi = key ? key->hi : 0;
+        dim3 grid((unsigned)groups, (unsigned)p->nchan);
+        if (key && p->fmt == SXFIR_S32) {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true, true>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true, true>), grid, dim3(64), 0, st, t); break;
+            }
+        } else if (key) {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, false, true>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, false, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, false, true>), grid, dim3(64), 0, st, t); break;
+            }
+        } else if (p->fmt == SXFIR_S32) {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, true>), grid, dim3(64), 0, st, t); break;
+            }
+        } else {
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, st, t); break;
+#ifdef SXFIR_PROFILING
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, st, t); break;
+#else
+            case 8: return fail(SXFIR_EUNSUPPORTED, "x8 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, st, t); break;
+            }
+        }
+        HIPCHECK(hipGetLastError());
+        *history_done = true;
+        return SXFIR_OK;
+    }
+    sxfir::GenericArgs a;
+    a.in = in_dev;
+    a.hist = p->hist_dev;
+    a.out = out_dev;
+    a.taps = p->taps_dev;
+    a.n_in = (long long)n_in;
+    a.n_out = n_out;
+    a.in_stride = (long long)in_stride;
+    a.out_stride = (long long)out_stride;
+    a.hist_stride = p->hist_len;
+    a.first = 0;
+    a.ntaps = p->ntaps;
+    a.ratio = p->ratio;
+    a.hist_len = p->hist_len;
+    a.jsplit = p->jsplit;
+    a.cw = p->cw;
+    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
+    a.thr2 = p->thr2;
+    if (p->fmt == SXFIR_CF32)
+        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF32>, grid, dim3(256), 0, st, a);
+    else if (p->fmt == SXFIR_CF16)
+        hipLaunchKernelGGL(sxfir::interp_generic_kernel<sxfir::CF16>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((sxfir::interp_generic_kernel<sxfir::CF32, sxfir::S32>), grid, dim3(256), 0, st, a);
+    HIPCHECK(hipGetLastError());
+    if (key && key->hi > key->lo) {
+        // shapes the tiled kernel does not take: the count as a pass of its own (same rule, same counter)
+        const long long n = key->hi - key->lo;
+        unsigned g = (unsigned)std::min<long long>((n + 255) / 256, 256);
+        hipLaunchKernelGGL(sxfir::count_keyed_kernel, dim3(g), dim3(256), 0, st,
+                           reinterpret_cast<const float2 *>(in_dev) + key->lo, n, p->thr2, key->counter);
+        HIPCHECK(hipGetLastError());
+    }
+    return SXFIR_OK;
+}
+
+static int interpolate_impl(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                            size_t out_stride, size_t *n_out_p, void *stream, const KeyedRange *key)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    const long long n_out = outputs_for(p, (long long)n_in);
+    int rc = check_io(p, SXFIR_INTERPOLATE, in_dev, n_in, in_stride, out_dev, out_stride, n_out);
+    if (rc) return rc;
+    if (n_in == 0) return SXFIR_OK;
+    HIPCHECK(hipSetDevice(p->device));
+    bool history_done = false;
+    rc = launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done, key);
+    if (rc) return rc;
+    if (!history_done) {
+        rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+        if (rc) return rc;
+    }
+    std::swap(p->hist_dev, p->hist_alt);
+    p->consumed += (long long)n_in;
+    p->produced += n_out;
+    if (n_out_p) *n_out_p = (size_t)n_out;
+    return SXFIR_OK;
+}
+
+int sxfir_interpolate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                      size_t out_stride, size_t *n_out_p, void *stream)
+{
+    return interpolate_impl(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out_p, stream, nullptr);
+}
+
+int sxfir_interpolate_keyed(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
+                            size_t out_stride, size_t *n_out_p, size_t key_first, size_t key_count,
+                            unsigned long long *counter, void *stream)
+{
+    if (n_out_p) *n_out_p = 0;
+    if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
+    if (p->mode != SXFIR_INTERPOLATE) return fail(SXFIR_EINVAL, "not an interpolator plan");
+    if (p->fmt == SXFIR_CF16) return fail(SXFIR_EUNSUPPORTED, "the keying count is defined on CF32 input");
+    if (!counter || ((uintptr_t)counter & 7)) return fail(SXFIR_EINVAL, "counter must be an 8-byte aligned device word");
+    if (key_first > n_in || key_count > n_in - key_first) return fail(SXFIR_EINVAL, "keying range outside the block");
+    const KeyedRange key{counter, (long long)key_first, (long long)(key_first + key_count)};
+    return interpolate_impl(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out_p, stream, key_count ? &key : nullptr);
+}
+
+}  // extern "C"
