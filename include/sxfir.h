@@ -51,8 +51,10 @@ extern "C" {
  *    libsxfir.so into the profiling build (libsxfir_prof.so, include/sxfir_prof.h): a version-1 client that referenced
  *    them no longer links against the production library; every other version-1 entry point is unchanged.
  * 3: sxfir_set_position added (round 3); nothing removed or changed.
- * 4: sxfir_interpolate_keyed and the sxfir_comm_* gather over RCCL added (round 4); nothing removed or changed. */
-#define SXFIR_ABI_VERSION 4
+ * 4: sxfir_interpolate_keyed and the sxfir_comm_* gather over RCCL added (round 4); nothing removed or changed.
+ * 5: sxfir_device_pci_bus_id and sxfir_comm_query added (round 5); the sxfir_comm_* calls now leave the calling thread's
+ *    current GPU as they found it; nothing removed. */
+#define SXFIR_ABI_VERSION 5
 
 enum {
     SXFIR_OK = 0,
@@ -84,6 +86,9 @@ const char *sxfir_last_error(void);
 int sxfir_device_count(int *count);
 /* name: at least 64 bytes.  arch: at least 32 bytes (e.g. "gfx950"). */
 int sxfir_device_info(int device, char *name, char *arch, int *compute_units, size_t *hbm_bytes);
+/* PCI address of GPU `device` ("0000:05:00.0": domain:bus:device.function), bdf: at least 16 bytes.  What tells two
+ * ranks' GPUs apart on a node (bench.py records one per rank). */
+int sxfir_device_pci_bus_id(int device, char *bdf, size_t bdf_bytes);
 
 /* Build a resampler for `nchan` independent channels on GPU `device`
  * (-1 = the calling thread's current HIP device).
@@ -229,6 +234,10 @@ int sxfir_comm_init_rank(sxfir_comm **comm, const void *id, int nranks, int rank
 int sxfir_comm_init_all(sxfir_comm **comms, int ndev, const int *devices);
 int sxfir_comm_destroy(sxfir_comm *comm);
 int sxfir_comm_rank(const sxfir_comm *comm, int *rank, int *nranks, int *device);
+/* The same three numbers as RCCL itself reports them for the communicator (ncclCommUserRank, ncclCommCount,
+ * ncclCommCuDevice) rather than as they were passed in: what a benchmark line should carry.  Any pointer may be NULL.
+ * The sxfir_comm_* calls make the communicator's GPU current while they run and restore the caller's before returning. */
+int sxfir_comm_query(const sxfir_comm *comm, int *rank, int *nranks, int *device);
 /* Every rank contributes `bytes` bytes at send_dev; on the root, rank r's block lands at recv_dev +
  * r * recv_stride_bytes (recv_dev is ignored elsewhere; the root's own block is copied device-to-device on the
  * same stream unless send_dev already is its place in recv_dev).  chunk_bytes > 0 cuts the transfer into pieces of

@@ -57,6 +57,7 @@ def load_sxfir(profiling=False):
         "sxfir_last_error": (C.c_char_p, []),
         "sxfir_device_count": (ci, [P(ci)]),
         "sxfir_device_info": (ci, [ci, C.c_char_p, C.c_char_p, P(ci), P(sz)]),
+        "sxfir_device_pci_bus_id": (ci, [ci, C.c_char_p, sz]),
         "sxfir_create": (ci, [P(vp), ci, vp, ci, ci, ci, ci, ci]),
         "sxfir_destroy": (ci, [vp]),
         "sxfir_reset": (ci, [vp, vp]),
@@ -74,6 +75,7 @@ def load_sxfir(profiling=False):
         "sxfir_comm_init_all": (ci, [P(vp), ci, P(ci)]),
         "sxfir_comm_destroy": (ci, [vp]),
         "sxfir_comm_rank": (ci, [vp, P(ci), P(ci), P(ci)]),
+        "sxfir_comm_query": (ci, [vp, P(ci), P(ci), P(ci)]),
         "sxfir_comm_gather": (ci, [vp, vp, vp, sz, sz, ci, sz, vp]),
         "sxfir_comm_gather_all": (ci, [P(vp), ci, P(vp), vp, sz, sz, ci, sz, P(vp)]),
         "sxfir_interpolate_keyed": (ci, [vp, vp, sz, sz, vp, sz, P(sz), sz, sz, vp, vp]),

@@ -6,18 +6,62 @@
 // on the caller's HIP stream, in pieces, so that it queues behind the kernel that produced the block and the
 // root can consume a step's first channels while the rest are on the links.
 //
-// librccl is loaded on first use (dlopen), not linked: a single-GPU user of libsxfir.so never pays for it, and a
-// process that already carries another copy of RCCL (torch ships its own) keeps the two apart.
+// librccl is loaded on first use (dlopen), not linked, and not needed at compile time either: the handful of RCCL
+// prototypes used here are declared below (their ABI is NCCL's public one), so a single-GPU build of libsxfir.so
+// needs neither the RCCL headers nor the library.  dlopen by SONAME hands back the copy the process already has
+// (torch loads librccl too), so a process ends up with ONE RCCL, whoever asked first.
+//
+// Every entry point that has to make the communicator's GPU the calling thread's current device puts the previous
+// one back before it returns (DeviceScope): the caller's HIP context is left as it was found.
 //
 // Included at the end of sxfir.hip (shares its error helper); not a stand-alone translation unit.
 #pragma once
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 
+// NCCL's public C ABI, as far as this file uses it (nccl.h / rccl.h: ncclUniqueId is 128 opaque bytes, ncclComm_t an
+// opaque pointer, ncclSuccess = 0, ncclChar = 0)
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+enum { ncclSuccess = 0, ncclChar = 0 };
+ncclResult_t ncclGetUniqueId(ncclUniqueId *);
+ncclResult_t ncclCommInitRank(ncclComm_t *, int nranks, ncclUniqueId id, int rank);
+ncclResult_t ncclCommInitAll(ncclComm_t *, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclCommCount(const ncclComm_t, int *count);
+ncclResult_t ncclCommUserRank(const ncclComm_t, int *rank);
+ncclResult_t ncclCommCuDevice(const ncclComm_t, int *device);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void *, size_t count, ncclDataType_t, int peer, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void *, size_t count, ncclDataType_t, int peer, ncclComm_t, hipStream_t);
+const char *ncclGetErrorString(ncclResult_t);
+}
+
 namespace {
+
+// makes `device` current for the scope and restores what was current before
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceScope()
+    {
+        int now = -1;
+        if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 struct Rccl {
     void *handle = nullptr;
@@ -25,6 +69,9 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -51,6 +98,7 @@ const Rccl *rccl()
     r.NAME = reinterpret_cast<decltype(r.NAME)>(dlsym(r.handle, "nccl" #NAME)); \
     if (!r.NAME) { snprintf(r.why, sizeof(r.why), "librccl lacks nccl" #NAME); dlclose(r.handle); r.handle = nullptr; return; }
         SXFIR_SYM(GetUniqueId) SXFIR_SYM(CommInitRank) SXFIR_SYM(CommInitAll) SXFIR_SYM(CommDestroy)
+        SXFIR_SYM(CommCount) SXFIR_SYM(CommUserRank) SXFIR_SYM(CommCuDevice)
         SXFIR_SYM(GroupStart) SXFIR_SYM(GroupEnd) SXFIR_SYM(Send) SXFIR_SYM(Recv) SXFIR_SYM(GetErrorString)
 #undef SXFIR_SYM
     });
@@ -100,7 +148,8 @@ int sxfir_comm_init_rank(sxfir_comm **out, const void *id, int nranks, int rank,
     const Rccl *R;
     if (int rc = need_gpu_and_rccl(&R)) return rc;
     if (device < 0) HIPCHECK(hipGetDevice(&device));
-    HIPCHECK(hipSetDevice(device));
+    DeviceScope on(device);
+    HIPCHECK(on.err);
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     ncclComm_t c;
@@ -119,6 +168,9 @@ int sxfir_comm_init_all(sxfir_comm **comms, int ndev, const int *devices)
     int devs[64];
     for (int i = 0; i < ndev; ++i) devs[i] = devices ? devices[i] : i;
     ncclComm_t c[64];
+    int cur = 0;
+    HIPCHECK(hipGetDevice(&cur));
+    DeviceScope back(cur);                    // ncclCommInitAll visits every GPU: put the caller's back afterwards
     RCCLCHECK(R, R->CommInitAll(c, ndev, devs));
     for (int i = 0; i < ndev; ++i) comms[i] = new (std::nothrow) sxfir_comm{c[i], i, ndev, devs[i]};
     for (int i = 0; i < ndev; ++i) {
@@ -139,7 +191,7 @@ int sxfir_comm_destroy(sxfir_comm *c)
     if (!c) return SXFIR_OK;
     const Rccl *R = rccl();
     if (R) {
-        (void)hipSetDevice(c->device);
+        DeviceScope on(c->device);
         R->CommDestroy(c->comm);
     }
     delete c;
@@ -152,6 +204,18 @@ int sxfir_comm_rank(const sxfir_comm *c, int *rank, int *nranks, int *device)
     if (rank) *rank = c->rank;
     if (nranks) *nranks = c->nranks;
     if (device) *device = c->device;
+    return SXFIR_OK;
+}
+
+int sxfir_comm_query(const sxfir_comm *c, int *rank, int *nranks, int *device)
+{
+    if (!c) return fail(SXFIR_EINVAL, "comm is NULL");
+    const Rccl *R = rccl();
+    if (!R) return fail(SXFIR_EUNSUPPORTED, "librccl is not loaded");
+    int v = -1;
+    if (nranks) { RCCLCHECK(R, R->CommCount(c->comm, &v)); *nranks = v; }
+    if (rank) { RCCLCHECK(R, R->CommUserRank(c->comm, &v)); *rank = v; }
+    if (device) { RCCLCHECK(R, R->CommCuDevice(c->comm, &v)); *device = v; }
     return SXFIR_OK;
 }
 
@@ -184,7 +248,8 @@ int sxfir_comm_gather(sxfir_comm *c, const void *send_dev, void *recv_dev, size_
     if (bytes == 0) return SXFIR_OK;
     const Rccl *R = rccl();
     if (!R) return fail(SXFIR_EUNSUPPORTED, "librccl is not loaded");
-    HIPCHECK(hipSetDevice(c->device));
+    DeviceScope on(c->device);
+    HIPCHECK(on.err);
     const char *send = static_cast<const char *>(send_dev);
     char *recv = static_cast<char *>(recv_dev);
     const size_t piece = chunk_bytes ? chunk_bytes : bytes;
@@ -230,7 +295,8 @@ int sxfir_comm_gather_all(sxfir_comm *const *comms, int ndev, const void *const 
         }
         const char *own = static_cast<const char *>(send_dev[root]);
         if (recv + (size_t)root * recv_stride_bytes != own) {
-            HIPCHECK(hipSetDevice(comms[root]->device));
+            DeviceScope on(comms[root]->device);
+            HIPCHECK(on.err);
             HIPCHECK(hipMemcpyAsync(recv + (size_t)root * recv_stride_bytes + off, own + off, n, hipMemcpyDeviceToDevice,
                                     S(streams ? streams[root] : nullptr)));
         }

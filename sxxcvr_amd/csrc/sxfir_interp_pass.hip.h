@@ -29,8 +29,8 @@
 // QI = 2 halves the tile: 8 KiB of outputs + a 1.3 KiB image = 10 KB of LDS and 125 VGPRs, i.e. 16 waves per CU, eight
 // stores per wave and tile, 17 window reads per 512 FMAs (still fewer than the VGPR-tap kernel's 20): structure 0.39-0.41
 // ms on zeros, **9.6 % less time than interp_tile_kernel on random IQ** (0.4636 against 0.5124 ms on the same box).  That
-// form ships for CF32 x8, with or without the keying count (KEYED); wire-word output and the other ratios keep
-// interp_tile_kernel.
+// form ships for x8 with CF32 or S32 wire-word output (S32OUT: tx_word fused into the stores), with or without the
+// keying count (KEYED); the other ratios keep interp_tile_kernel (whose x8 instances exist in the profiling build only).
 //
 // Numeric contract: partial_p = fmaf chain from +0.0f over j DESCENDING in [16p, 16p+16); y = P0 + P1 --
 // the same chains in the same order as interp_tile_kernel, so the outputs are bit-identical.
@@ -102,7 +102,11 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
 // kernel arguments where they are used (the kernel has no scalar registers to spare).
 // S32OUT: outputs leave as S32_LE I2S wire words with the keying bits (convert_tx_buffer, SoapySX.cpp:116-137), converted
 // between the transposition buffer and the store as in interp_tile_kernel.
-template <int QI, bool KEYED = false, bool S32OUT = false>
+// COUNTED = false (profiling build only, SXFIR_IPASS_WAIT0=1): every wait for the staged image is s_waitcnt vmcnt(0)
+// instead of the counted form below -- slower, and free of the counted form's premises (exactly CPL stores behind the
+// next tile's DMAs, no other VMEM instruction between them); tests/test_gpu_variants.py holds the two bit-identical,
+// tests/test_abi.py::test_shipped_code_object checks the premises in the shipped disassembly.
+template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {
     using C = InterpPass8<QI>;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
     while (true) {
         // s_waitcnt vmcnt counts loads and stores together, in issue order: with the next tile's three DMAs issued
         // BEFORE this tile's sixteen stores, "at most 16 outstanding" means the DMAs have landed
-        if (counted) {
+        if (COUNTED && counted) {
             if constexpr (QI == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {

@@ -21,6 +21,15 @@ static int launch_history(sxfir_plan *p, const void *in_dev, size_t n_in, size_t
     return SXFIR_OK;
 }
 
+// A launch that hands taps_scaled_dev to a kernel states which layout that kernel reads; sxfir_create chose the layout
+// from the same plan flags, so a mismatch means the two sides were changed apart: refuse instead of filtering with
+// permuted taps.
+static int need_tap_table(const sxfir_plan *p, int layout, const char *kernel)
+{
+    if (p->tap_table == layout) return SXFIR_OK;
+    return fail(SXFIR_EUNSUPPORTED, "internal: %s reads tap table layout %d, the plan carries layout %d", kernel, layout, p->tap_table);
+}
+
 #ifdef SXFIR_PROFILING
 #include "sxfir_prof_dispatch.inc"   // the A/B variants' launch tables: 0 = not mine, 1 = launched, < 0 = error
 #endif
@@ -75,6 +84,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             }
 #endif
             if (p->dense_subset) {
+                if (int rc = need_tap_table(p, TAPS_SUBSET8, "decim_dense_kernel<8, SUBSET>")) return rc;
                 a.taps = p->taps_scaled_dev;                      // the subset-major tap table
                 if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, true, 2, true>), grid, dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 2, true>), grid, dim3(256), 0, st, a);
@@ -126,6 +136,8 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.out = (float *)out_dev;
         *history_done = true;      // caller swaps hist_dev / hist_alt when it commits the call
         a.taps = p->taps_dev;
+        if (p->fmt == SXFIR_S32)                               // only wire-word plans read it (S32IN ? a.taps_scaled : a.taps)
+            if (int rc = need_tap_table(p, TAPS_SCALED, "the /4 scalar-tap kernels on S32 words")) return rc;
         a.taps_scaled = p->taps_scaled_dev;
         memcpy(a.taps_k, p->taps_k, sizeof(a.taps_k));
         a.n_in = (long long)n_in;
@@ -281,7 +293,7 @@ int sxfir_decimate(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_str
 struct KeyedRange { unsigned long long *counter; long long lo, hi; };
 static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
                          size_t out_stride, long long n_out, hipStream_t st, bool *history_done,
-                         const KeyedRange *key = nullptr)
+                         const KeyedRange *key = nullptr, bool *key_pending = nullptr)
 {
     *history_done = false;
     const bool tiled = p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && ((uintptr_t)out_dev % 16 == 0) &&
@@ -295,6 +307,7 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.hist = (const float *)p->hist_dev;
         t.hist_out = (float *)p->hist_alt;
         t.out = (float *)out_dev;
+        if (int rc = need_tap_table(p, TAPS_PASS8, "interp8_pass_kernel")) return rc;
         t.taps = p->taps_scaled_dev;                            // the pass-major table
         t.n_in = (long long)n_in;
         t.in_stride = (long long)in_stride;
@@ -317,7 +330,12 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         if (p->ipass_qi == 4 && p->fmt == SXFIR_S32) return fail(SXFIR_EUNSUPPORTED, "four inputs per lane: CF32 only");
         else if (p->ipass_qi == 4 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true>), pgrid, dim3(64), 0, st, t);
         else if (p->ipass_qi == 4) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4>), pgrid, dim3(64), 0, st, t);
-        else
+        else if (p->ipass_wait0) {                          // SXFIR_IPASS_WAIT0=1: the vmcnt(0) form of every shipped instance
+            if (p->fmt == SXFIR_S32 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true, true, false>), pgrid, dim3(64), 0, st, t);
+            else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, false, true, false>), pgrid, dim3(64), 0, st, t);
+            else if (key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true, false, false>), pgrid, dim3(64), 0, st, t);
+            else hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, false, false, false>), pgrid, dim3(64), 0, st, t);
+        } else
 #endif
         if (p->fmt == SXFIR_S32 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, true, true>), pgrid, dim3(64), 0, st, t);
         else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, false, true>), pgrid, dim3(64), 0, st, t);
@@ -425,14 +443,21 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
     else
         hipLaunchKernelGGL((sxfir::interp_generic_kernel<sxfir::CF32, sxfir::S32>), grid, dim3(256), 0, st, a);
     HIPCHECK(hipGetLastError());
-    if (key && key->hi > key->lo) {
-        // shapes the tiled kernel does not take: the count as a pass of its own (same rule, same counter)
-        const long long n = key->hi - key->lo;
-        unsigned g = (unsigned)std::min<long long>((n + 255) / 256, 256);
-        hipLaunchKernelGGL(sxfir::count_keyed_kernel, dim3(g), dim3(256), 0, st,
-                           reinterpret_cast<const float2 *>(in_dev) + key->lo, n, p->thr2, key->counter);
-        HIPCHECK(hipGetLastError());
-    }
+    if (key && key->hi > key->lo && key_pending) *key_pending = true;    // counted by the caller once the call is certain to commit
+    return SXFIR_OK;
+}
+
+// Shapes the tiled kernels do not take: the keying count as a pass of its own (same rule, same counter).  Queued by
+// interpolate_impl AFTER the history launch has succeeded, with the position commit: a call that fails half way has not
+// touched the counter, so a caller that retries the block does not count it twice (on the tiled paths the count is part of
+// the one kernel launch).
+static int launch_keyed_count(sxfir_plan *p, const void *in_dev, const KeyedRange *key, hipStream_t st)
+{
+    const long long n = key->hi - key->lo;
+    unsigned g = (unsigned)std::min<long long>((n + 255) / 256, 256);
+    hipLaunchKernelGGL(sxfir::count_keyed_kernel, dim3(g), dim3(256), 0, st,
+                       reinterpret_cast<const float2 *>(in_dev) + key->lo, n, p->thr2, key->counter);
+    HIPCHECK(hipGetLastError());
     return SXFIR_OK;
 }
 
@@ -446,11 +471,15 @@ static int interpolate_impl(sxfir_plan *p, const void *in_dev, size_t n_in, size
     if (rc) return rc;
     if (n_in == 0) return SXFIR_OK;
     HIPCHECK(hipSetDevice(p->device));
-    bool history_done = false;
-    rc = launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done, key);
+    bool history_done = false, key_pending = false;
+    rc = launch_interp(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out, S(stream), &history_done, key, &key_pending);
     if (rc) return rc;
     if (!history_done) {
         rc = launch_history(p, in_dev, n_in, in_stride, S(stream));
+        if (rc) return rc;
+    }
+    if (key_pending) {
+        rc = launch_keyed_count(p, in_dev, key, S(stream));
         if (rc) return rc;
     }
     std::swap(p->hist_dev, p->hist_alt);

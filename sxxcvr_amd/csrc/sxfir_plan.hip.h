@@ -3,6 +3,8 @@
 // Included by sxfir.hip after the kernel headers; not a stand-alone translation unit.
 #pragma once
 
+enum TapTable { TAPS_SCALED = 0, TAPS_SUBSET8 = 1, TAPS_PASS8 = 2 };
+
 struct sxfir_plan {
     int mode, ntaps, ratio, nchan, fmt, device;
     int kernel;            // SXFIR_KERNEL_*
@@ -42,11 +44,15 @@ struct sxfir_plan {
     int occ_wide;
     int compute_units;
     float *taps_dev;
-    float *taps_scaled_dev;   // decimators: taps * 2^-31 (exact), the scalar-tap kernels on S32 wire words; x8 interpolators: the
-                              // pass-major tap table of interp8_pass_kernel (pass (c, p) at 64 (2c + p), (jj, rr) at 4 jj + rr)
+    float *taps_scaled_dev;   // the second tap table; its layout is one of TapTable, chosen from dense_subset / ipass in sxfir_create
+    int tap_table;            // TAPS_SCALED: taps * 2^-31 (exact) in tap order, for the /4 scalar-tap kernels on S32 wire words;
+                              // TAPS_SUBSET8: the subset-major table of decim_dense_kernel<8, ..., SUBSET> (times 2^-31 for S32 plans);
+                              // TAPS_PASS8: the pass-major table of interp8_pass_kernel (pass (c, p) at 64 (2c + p), (jj, rr) at 4 jj + rr).
+                              // Every launch that hands taps_scaled_dev to a kernel checks this first (need_tap_table).
     bool ipass;               // x8, 256 taps, CF32: interp8_pass_kernel (scalar taps, four passes per tile)
     int occ_ipass;
     int ipass_qi;             // inputs per lane of that kernel (2; profiling: 4)
+    bool ipass_wait0;         // (profiling) SXFIR_IPASS_WAIT0=1: its vmcnt(0) form (A/B partner of the counted wait)
     float taps_k[64];         // the first 64 taps (times 2^-31 for S32 plans) for kernels that take them by value
     bool symmetric;           // taps[k] == taps[ntaps-1-k] bit for bit (every linear-phase design)
     void *hist_dev;        // current history: nchan * hist_len samples
@@ -89,6 +95,17 @@ int sxfir_device_info(int device, char *name, char *arch, int *compute_units, si
     return SXFIR_OK;
 }
 
+int sxfir_device_pci_bus_id(int device, char *bdf, size_t bdf_bytes)
+{
+    if (!bdf || bdf_bytes < 16) return fail(SXFIR_EINVAL, "bdf needs at least 16 bytes");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(SXFIR_ENODEVICE, "no GPU visible");
+    if (device < 0) HIPCHECK(hipGetDevice(&device));
+    if (device >= n) return fail(SXFIR_EINVAL, "device %d of %d", device, n);
+    HIPCHECK(hipDeviceGetPCIBusId(bdf, (int)bdf_bytes, device));
+    return SXFIR_OK;
+}
+
 int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int ratio, int nchan, int fmt,
                  int device)
 {
@@ -128,6 +145,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->taps_dev = nullptr;
     p->taps_scaled_dev = nullptr;
     p->ipass = false;
+    p->ipass_wait0 = false;
     p->occ_ipass = 16;
     p->ipass_qi = 2;
     p->symmetric = true;
@@ -238,6 +256,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                 p->occ_ipass = nbi;
         }
     }
+    if (const char *v = getenv("SXFIR_IPASS_WAIT0")) p->ipass_wait0 = atoi(v) != 0;
     if (const char *v = getenv("SXFIR_DENSE_NT")) { p->dense_nt = atoi(v); p->dense_nt_set = 1; }
     if (const char *v = getenv("SXFIR_DENSE_HC")) p->dense_hc = atoi(v) != 0;
     if (const char *v = getenv("SXFIR_DENSE_SUBSET")) p->dense_subset = p->dense_subset && atoi(v) != 0;     // 0: the VGPR-tap form (A/B)
@@ -381,7 +400,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     for (int k = 0; k < 64; ++k) p->taps_k[k] = k < ntaps ? (fmt == SXFIR_S32 ? taps[k] * 4.656612873077393e-10f : taps[k]) : 0.0f;
     if (e == hipSuccess) {
         std::vector<float> scaled(taps, taps + ntaps);
-        if (mode == SXFIR_DECIMATE && ratio == 8 && ntaps == 256 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
+        // the layout follows the kernel the plan will launch (the same flags launch_decim / launch_interp branch on),
+        // not the shape: a plan whose /8 scalar-tap form was switched off (profiling knobs) keeps the plain table
+        p->tap_table = p->dense_subset ? TAPS_SUBSET8 : (mode == SXFIR_INTERPOLATE && p->ipass) ? TAPS_PASS8 : TAPS_SCALED;
+        if (p->tap_table == TAPS_SUBSET8) {
             // /8 scalar-tap form (decim_dense_kernel<8, ..., SUBSET>): subset s = 2c + p at 64 s, (jj, rr) at 4 jj + rr
             for (int c = 0; c < 2; ++c)
                 for (int ph = 0; ph < 2; ++ph)
@@ -389,7 +411,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                         for (int rr = 0; rr < 4; ++rr)
                             scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] =
                                 taps[8 * (16 * ph + jj) + 4 * c + rr] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);   // 2^-31: exact
-        } else if (mode == SXFIR_INTERPOLATE && p->itile_capable && ratio == 8) {
+        } else if (p->tap_table == TAPS_PASS8) {
             for (int c = 0; c < 2; ++c)
                 for (int ph = 0; ph < 2; ++ph)
                     for (int jj = 0; jj < 16; ++jj)

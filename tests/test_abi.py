@@ -27,7 +27,7 @@ def test_sxfir_exports_every_declared_symbol():
         assert hasattr(lib, n), "libsxfir.so does not export " + n
     # and the python binding declares a prototype for each of them
     assert set(names) <= set(lib._sx_signatures), set(names) - set(lib._sx_signatures)
-    assert lib.sxfir_abi_version() == 4
+    assert lib.sxfir_abi_version() == 5
 
 
 def test_time_arithmetic_matches_oracle(oracle):
@@ -144,3 +144,13 @@ def test_shipped_code_object():
         wire = r["name"].rstrip(">").endswith("true")            # <QI, KEYED, S32OUT>: the wire-word conversion holds more masks
         assert r["vgpr"] <= 128 and r["lds_bytes"] == 10240 and r["v_pk_fma_f32"] == 256, r
         assert r["sgpr_spill_lane_ops"] <= (40 if wire else 8), r
+        # the counted wait (s_waitcnt vmcnt(8), sxfir_interp_pass.hip.h): safe only if the tile loop issues the next tile's
+        # image DMAs, then exactly eight stores and nothing else that counts as VMEM -- no scratch access (checked above), no
+        # load, and the keying count's atomic in FRONT of the DMAs.  Read off the shipped disassembly:
+        cw = r["counted_wait"]
+        assert cw["n"] == 8 and cw["waits"] == 1, r
+        assert cw["dma_loads"] >= 2 and cw["atomics_after_first_dma"] == 0, r
+        assert cw["last_block_vmem"] == ["global_store_dwordx4"] * 8, r          # the full-tile path that loops back
+        assert cw["non_store_vmem_after_last_dma"] == [], r
+    keyed = [r for r in ip if "<2, true" in r["name"]]
+    assert len(keyed) == 2

@@ -171,14 +171,17 @@ def test_cu_queue_variant_multichannel(oracle, monkeypatch, opt):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ipass,oversub", [("0", "4"), ("1", "1"), ("1", "16"), ("4", "4"), ("4", "1")])
+@pytest.mark.parametrize("ipass,oversub", [("0", "4"), ("1", "1"), ("1", "16"), ("4", "4"), ("4", "1"), ("1w0", "1"), ("1w0", "16")])
 def test_x8_interpolator_forms_match_oracle(oracle, monkeypatch, ipass, oversub):
     """x8, 256 taps: interp8_pass_kernel (scalar taps; two inputs per lane as shipped, or four) and interp_tile_kernel (taps in
     VGPRs, SXFIR_IPASS=0) give the oracle's bits: streaming over three calls -- a first tile that takes its history from
     the plan, interior tiles with the prefetch and its counted wait, a ragged last tile -- and several channels."""
     import torch
-    for k in KNOBS + ("SXFIR_IPASS",):
+    for k in KNOBS + ("SXFIR_IPASS", "SXFIR_IPASS_WAIT0"):
         monkeypatch.delenv(k, raising=False)
+    if ipass.endswith("w0"):                # the vmcnt(0) build of the shipped form: the counted wait's A/B partner
+        ipass = ipass[:-2]
+        monkeypatch.setenv("SXFIR_IPASS_WAIT0", "1")
     monkeypatch.setenv("SXFIR_IPASS", ipass)
     monkeypatch.setenv("SXFIR_OVERSUB", oversub)
     h = sxxcvr_amd.design_lowpass(256, 8, 8.0, 8.0)
@@ -249,14 +252,17 @@ def test_div8_forms_on_wire_words_match_oracle(oracle, monkeypatch, nchan, lens,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ipass", ["1", "0"])
+@pytest.mark.parametrize("ipass", ["1", "0", "1w0"])
 def test_x8_interpolator_forms_to_wire_words_match_oracle(oracle, monkeypatch, ipass):
     """x8 to S32_LE wire words with the keying bits (convert_tx_buffer, SX.cpp:116-137): interp8_pass_kernel<2, KEYED, S32OUT>
     (shipped) and interp_tile_kernel<8, S32OUT> (SXFIR_IPASS=0) give the oracle's words -- clipping samples, samples under the
     keying threshold, three calls with a ragged tail, two channels -- and the keying count of the input rides along."""
     import torch
-    for k in KNOBS + ("SXFIR_IPASS",):
+    for k in KNOBS + ("SXFIR_IPASS", "SXFIR_IPASS_WAIT0"):
         monkeypatch.delenv(k, raising=False)
+    if ipass.endswith("w0"):                # <2, KEYED, S32OUT, COUNTED = false>
+        ipass = ipass[:-2]
+        monkeypatch.setenv("SXFIR_IPASS_WAIT0", "1")
     monkeypatch.setenv("SXFIR_IPASS", ipass)
     h = sxxcvr_amd.design_lowpass(256, 8, 8.0, 8.0)
     nchan, lens = 2, [128 * 41 + 77, 5, 128 * 64]

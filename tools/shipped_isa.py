@@ -68,8 +68,39 @@ def kernels(lib=None):
         if len(fm) > 1:
             r["scalar_tap_fmas"] = len(fm)
             r["adjacent_fmas_sharing_sample_pair"] = round(sum(1 for a, b in zip(fm, fm[1:]) if a[1] == b[1]) / (len(fm) - 1), 3)
+        # (the compiler emits vmcnt(N > 0) waits of its own elsewhere: those count its own loads; this one is hand-written)
+        cw = counted_wait(body) if "interp8_pass_kernel" in r["name"] else None
+        if cw:
+            r["counted_wait"] = cw
         rows.append(r)
     return rows
+
+
+def counted_wait(body):
+    """A kernel that waits with `s_waitcnt vmcnt(N)`, N > 0 (interp8_pass_kernel: the next tile's image DMAs are issued in
+    front of this tile's N stores, and "at most N outstanding" then means the DMAs have landed) relies on the exact VMEM
+    instruction sequence of its tile loop.  Returns what the disassembly says about it, in code order from that wait to
+    the end of the kernel (the loop body: window reads, [keying atomic], staging of the next tile, FMAs, stores, branch
+    back): the VMEM mnemonics, and the facts the wait presumes."""
+    lines = [l.split("//")[0].strip() for l in body.splitlines()]
+    lines = [l for l in lines if l]
+    w = [i for i, l in enumerate(lines) if re.match(r"s_waitcnt vmcnt\(([1-9]\d*)\)", l)]
+    if not w:
+        return None
+    n = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", lines[w[0]]).group(1))
+    tail = lines[w[0]:]
+    vm = [(i, l.split()[0]) for i, l in enumerate(tail) if re.match(r"(global|buffer|scratch|flat)_", l)]
+    dma = [i for i, o in vm if o.startswith("global_load_lds")]
+    atom = [i for i, o in vm if "atomic" in o]
+    # the last basic block: after the last conditional branch, up to the branch back to the loop head
+    back = max(i for i, l in enumerate(tail) if l.startswith("s_branch"))
+    cond = max(i for i, l in enumerate(tail[:back]) if l.startswith("s_cbranch"))
+    last_block = [o for i, o in vm if cond < i < back]
+    after_dma = [o for i, o in vm if dma and i > max(dma)]
+    return {"n": n, "waits": len(w), "dma_loads": len(dma),
+            "atomics_after_first_dma": sum(1 for i in atom if dma and i > min(dma)),
+            "last_block_vmem": last_block,
+            "non_store_vmem_after_last_dma": [o for o in after_dma if not o.startswith("global_store")]}
 
 
 if __name__ == "__main__":
