@@ -118,9 +118,9 @@ class BoardSampler:
     driver-run evidence for DESIGN.md's "the package power cap sets the clock": power at the cap and a GFX clock
     far under the 2.4 GHz the chip runs unloaded.  Never raises: a box without telemetry yields {"error": ...}."""
 
-    def __init__(self, gpu_index=0, period_s=0.02):
+    def __init__(self, gpu_index=0, period_s=0.02, bdf=None):
         import threading
-        self.gpu_index, self.period = gpu_index, period_s
+        self.gpu_index, self.period, self.bdf = gpu_index, period_s, bdf
         self.samples, self.cap_w, self.source, self.error = [], None, None, None
         self._stop = threading.Event()
         self._ready = threading.Event()          # telemetry opened (or given up on): the sampled loop may start
@@ -130,7 +130,17 @@ class BoardSampler:
         try:
             import amdsmi
             amdsmi.amdsmi_init()
-            h = amdsmi.amdsmi_get_processor_handles()[self.gpu_index]
+            handles = amdsmi.amdsmi_get_processor_handles()
+            h = handles[min(self.gpu_index, len(handles) - 1)]
+            if self.bdf:
+                # the HIP device index and the SMI's enumeration need not agree on a multi-GPU node: go by PCI address
+                for cand in handles:
+                    try:
+                        if str(amdsmi.amdsmi_get_gpu_device_bdf(cand)).lower() == self.bdf.lower():
+                            h = cand
+                            break
+                    except Exception:
+                        pass
             try:
                 cap = amdsmi.amdsmi_get_power_cap_info(h)["power_cap"]
                 self.cap_w = cap / 1e6 if cap > 100000 else float(cap)
@@ -183,7 +193,7 @@ class BoardSampler:
             return
         while not self._stop.is_set():
             try:
-                self.samples.append(read())
+                self.samples.append(read() + (time.perf_counter(),))
             except Exception as e:
                 self.error = "%s: %s" % (type(e).__name__, e)
                 return
@@ -194,6 +204,15 @@ class BoardSampler:
         # came back with "no samples"): wait until the telemetry is open, bounded
         self._thread.start()
         self._ready.wait(wait_s)
+
+    def window(self, t0, t1):
+        """Median socket power / GFX clock of the samples taken in [t0, t1] (time.perf_counter()), None without any."""
+        sel = [s for s in list(self.samples) if t0 <= s[2] <= t1]
+        if not sel:
+            return None
+        w = sorted(s[0] for s in sel)
+        f = sorted(s[1] for s in sel)
+        return {"power_w": round(w[len(w) // 2], 1), "gfx_mhz_smi": round(f[len(f) // 2], 0), "samples": len(sel)}
 
     def stop(self):
         self._stop.set()
@@ -308,11 +327,13 @@ def cpu_baseline(cfg, seconds_target=10.0):
     }
 
 
-def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc):
-    """Compare three windows of every local channel's output block (its start, one around the middle -- tile
-    seams of every kernel included --, its end) with the order-matched oracle.  history_from_block: the filter
-    entered this block with the block's own tail as history (steady-state streaming over the same buffer), else
-    with zero history (after a reset).  Returns (ok, outputs compared)."""
+def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc, base=0):
+    """Compare three windows of every channel of the output block y (its start, one around the middle -- tile
+    seams of every kernel included --, its end) with the order-matched oracle; y's channels are the synthetic
+    stream's channels first_channel, first_channel + 1, ... and the block's input is samples [base, base + n_in) of
+    each.  history_from_block: the filter entered this block with the block's own tail as history (steady-state
+    streaming over the same buffer), else with zero history (after a reset).  x is unused (the input is regenerated
+    on the host from the seed).  Returns (ok, outputs compared)."""
     import numpy as np
     ratio, ntaps, decim = cfg["ratio"], cfg["ntaps"], cfg["mode"] == "decim"
     h = orc.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
@@ -337,9 +358,12 @@ def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc):
             cnt = min(cnt, n_in - s0)
             if s0 < 0 and history_from_block:
                 # steady-state streaming over the same buffer: the samples before the block are its own tail
-                xw = np.concatenate([orc.synth_iq(SEED, ch, n_in + s0, -s0), orc.synth_iq(SEED, ch, 0, cnt + s0)])
+                xw = np.concatenate([orc.synth_iq(SEED, ch, base + n_in + s0, -s0), orc.synth_iq(SEED, ch, base, cnt + s0)])
+            elif s0 < 0:
+                # after a reset: zeros before the block
+                xw = np.concatenate([np.zeros(-s0, dtype=np.complex64), orc.synth_iq(SEED, ch, base, cnt + s0)])
             else:
-                xw = orc.synth_iq(SEED, ch, s0, cnt)                    # zeros before the start of the stream
+                xw = orc.synth_iq(SEED, ch, base + s0, cnt)
             if cfg["fmt"] == "CF16":
                 xw = orc.f16_to_f32(orc.f32_to_f16(xw.view(np.float32))).view(np.complex64)
             if decim:
@@ -425,10 +449,77 @@ def c_caller():
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps):
+def gpu_identity(gpu_index):
+    """What tells this rank's GPU from the others' on the node: PCI address, name, arch (C ABI, include/sxfir.h)."""
+    import ctypes as C
+    import sxxcvr_amd
+    lib = sxxcvr_amd.load_sxfir()
+    out = {"gpu_index": gpu_index}
+    bdf = C.create_string_buffer(32)
+    if lib.sxfir_device_pci_bus_id(gpu_index, bdf, 32) == 0:
+        out["pci_bus_id"] = bdf.value.decode()
+    name, arch, cus, hbm = C.create_string_buffer(64), C.create_string_buffer(32), C.c_int(), C.c_size_t()
+    if lib.sxfir_device_info(gpu_index, name, arch, C.byref(cus), C.byref(hbm)) == 0:
+        out.update(name=name.value.decode(), arch=arch.value.decode(), compute_units=cus.value)
+    return out
+
+
+class GatherCertifier:
+    """Makes a gather's result checkable by the line that times it.  Every rank states two 64-bit checksums per
+    channel of the block it is about to send (sxxcvr_amd.dist.block_checksums, computed on its GPU from the bits the
+    kernel wrote); the tables are all-gathered over the host-side control group; rank 0 recomputes them over the
+    gathered tensor -- every peer's block, channel by channel, in global channel order -- and compares the first channel
+    of every rank's block with the CPU oracle on top (the oracle ties the bits to the filter, the checksums tie every
+    other channel and sample to what its sender held).  A verified gather always carries a block of the stream that no
+    earlier gather carried (next_block), so a stale destination cannot pass.
+
+    SXFIR_BENCH_CORRUPT_RANK=r (test hook): rank r flips one bit of what it sends after stating its checksums."""
+
+    def __init__(self, cfg, plan, orc, world, rank, ctl, total_channels, nchan_local, n_in):
+        self.cfg, self.plan, self.orc = cfg, plan, orc
+        self.world, self.rank, self.ctl = world, rank, ctl
+        self.total, self.local, self.n_in = total_channels, nchan_local, n_in
+        c = os.environ.get("SXFIR_BENCH_CORRUPT_RANK")
+        self.corrupt = c is not None and c != "" and int(c) == rank
+
+    def state(self, block):
+        """Sender side, on the stream that produced `block`: the checksums of what is about to be sent (a device
+        tensor; exchanged later, off the timed path).  With the corrupt hook: then damage the block."""
+        import torch
+        import sxxcvr_amd.dist as sxdist
+        sums = sxdist.block_checksums(block)
+        if self.corrupt:
+            w = torch.view_as_real(block).view(torch.int64) if block.is_complex() else block.view(torch.int64)
+            w[w.shape[0] // 2, w.shape[1] // 3] ^= 1 << 20
+        return sums
+
+    def check(self, full, sums, base, history_from_block):
+        """Collective over the control group.  full: the gathered [total_channels, n_out] tensor on rank 0 (None
+        elsewhere); sums: this rank's state() of the block it sent.  Returns the record for the JSON line (rank 0)."""
+        import sxxcvr_amd.dist as sxdist
+        stated = sxdist.exchange_checksums(sums, self.total, group=self.ctl)
+        if self.rank != 0:
+            return None
+        bad = sxdist.check_gathered(full, stated)
+        ok_o, n_o = True, 0
+        for r in range(self.world):                        # the first channel of every rank's block against the oracle
+            ch = r * self.local
+            ok, n = verify(self.cfg, self.plan, None, full[ch:ch + 1], self.n_in, ch, history_from_block, self.orc, base=base)
+            ok_o, n_o = ok_o and ok, n_o + n
+        return {"verified": (not bad) and ok_o, "peer_blocks_checked": self.world - 1,
+                "channels_checksummed": self.total, "bad_channels": bad,
+                "oracle_outputs_on_first_channel_of_every_block": n_o, "oracle_ok": ok_o,
+                "stream_block": base // self.n_in,
+                "how": "per channel: sum and position-weighted sum of the 64-bit sample words mod 2^64, stated by the sender "
+                       "from its own output, all-gathered over the host-side group, recomputed by rank 0 over the gathered "
+                       "tensor; plus oracle windows on the first channel of every rank's block"}
+
+
+def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, steps, cert, next_block,
+                   step_into):
     """Exchange step of BASELINE config 4: RCCL gather of every rank's decimated output to rank 0 over xGMI,
-    timed after (and outside) the timed region; rank 0 checks that the gathered tensor holds every rank's
-    channels in global channel order."""
+    timed after (and outside) the timed region; then one more gather of a block of the stream no earlier gather
+    carried, certified by GatherCertifier (checksums of every peer block, oracle windows)."""
     import torch
     import torch.distributed as dist
     import sxxcvr_amd.dist as sxdist
@@ -458,14 +549,26 @@ def measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gp
         "value_with_gather": round(world * wide_per_gpu * 1.0 / (elapsed / steps + g) / 1e6, 1),
         "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part of value",
     }
+    # the certified gather: the stream's next block (zero history), stated by every sender, recomputed by the root
+    del full
+    base = next_block()
+    step_into(y)
+    sums = cert.state(y)
+    yg = y.cpu() if host_collectives else y
+    full = sxdist.gather_channels(yg, total_channels, dst=0)
+    torch.cuda.synchronize()
+    rec = cert.check(full, sums, base, False)
+    out["rccl_ranks"] = dist.get_world_size()                    # as the communicator reports it
     if dist.get_rank() == 0:
         local = y.shape[0]
         out["root_holds_own_channels"] = bool(torch.equal(full[:local].to(y.device), y))
         out["gathered_shape"] = list(full.shape)
+        out["check"] = rec
     return out
 
 
-def measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_per_gpu, elapsed, steps, step_into, psteps=6):
+def measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_per_gpu, elapsed, steps, step_into, cert,
+                        next_block, psteps=6):
     """--gather capi: the same exchange through the C ABI (sxfir_comm_* over librccl, include/sxfir.h), the way a
     C / C++ host would run it: no torch.distributed in the data path.  torch.distributed only carries the 128-byte
     communicator id from rank 0 to the others (any launcher's store would do) and the barriers of the timing.
@@ -491,6 +594,11 @@ def measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_pe
     raw = (C.c_ubyte * 128)(*ident.cpu().tolist())
     comm = C.c_void_p()
     ck(lib.sxfir_comm_init_rank(C.byref(comm), raw, world, rank, gpu_index), "sxfir_comm_init_rank")
+    q_rank, q_n, q_dev = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    ck(lib.sxfir_comm_query(comm, C.byref(q_rank), C.byref(q_n), C.byref(q_dev)), "sxfir_comm_query")
+    if (q_rank.value, q_n.value, q_dev.value) != (rank, world, gpu_index):
+        raise RuntimeError("RCCL reports rank %d of %d on GPU %d; this process is rank %d of %d on GPU %d"
+                           % (q_rank.value, q_n.value, q_dev.value, rank, world, gpu_index))
     peer_bytes = y.numel() * 8
     full = torch.empty((total_channels,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device) if rank == 0 else None
     recv = full.data_ptr() if rank == 0 else None
@@ -523,21 +631,35 @@ def measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_pe
         "value_with_gather": round(world * wide_per_gpu * 1.0 / (elapsed / steps + g) / 1e6, 1),
         "note": "gather of the decimated output is xGMI per-link bound (~153 GB/s per peer) and not part of value",
     }
+    out["rccl_ranks"] = q_n.value                                # ncclCommCount of the communicator the gather ran on
+    # the certified gather (serial form): the stream's next block, stated by every sender, recomputed by the root
+    base = next_block()
+    step_into(y)
+    sums = cert.state(y)
+    if rank == 0:
+        full.zero_()
+    gather(y, main_stream.cuda_stream)
+    torch.cuda.synchronize()
+    rec = cert.check(full, sums, base, False)
     if rank == 0:
         out["root_holds_own_channels"] = bool(torch.equal(full[: y.shape[0]], y))
         out["gathered_shape"] = list(full.shape)
+        out["check"] = rec
     # steady state: kernel of step s on the main stream into buffer s % 2; its gather on the side stream behind an
     # event; before a buffer is overwritten the main stream waits for the gather that last read it
     ybuf = [y, torch.empty_like(y)]
     produced = [torch.cuda.Event(), torch.cuda.Event()]
     gathered = [None, None]
+    stated = {}
 
-    def run(nsteps):
+    def run(nsteps, state_last=False):
         for s_ in range(nsteps):
             k = s_ % 2
             if gathered[k] is not None:
                 main_stream.wait_event(gathered[k])
             step_into(ybuf[k])
+            if state_last and s_ == nsteps - 1:
+                stated["sums"] = cert.state(ybuf[k])
             produced[k].record(main_stream)
             side.wait_event(produced[k])
             gather(ybuf[k], side.cuda_stream)
@@ -559,13 +681,21 @@ def measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_pe
     out["link_bound_frac"] = round(per_link / XGMI_LINK_GBS, 4)
     out["overlapped"] = {"steps": psteps, "ms_per_step": round(tp / psteps * 1e3, 3), "chunks_per_step": 4,
                          "GB/s_per_link": round(per_link, 2), "link_peak_GB/s": XGMI_LINK_GBS}
+    # the certified steady state: two more steps on the stream's next block; the second one's gather is checked
+    base = next_block()
     if rank == 0:
-        out["overlapped"]["root_holds_own_channels"] = bool(torch.equal(full[: y.shape[0]], ybuf[(psteps - 1) % 2]))
+        full.zero_()
+        torch.cuda.synchronize()
+    run(2, state_last=True)
+    rec = cert.check(full, stated["sums"], base, True)
+    if rank == 0:
+        out["overlapped"]["root_holds_own_channels"] = bool(torch.equal(full[: y.shape[0]], ybuf[1]))
+        out["overlapped"]["check"] = rec
     lib.sxfir_comm_destroy(comm)
     return out
 
 
-def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_into, psteps=6):
+def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_into, cert, next_block, psteps=6):
     """The same exchange in steady state; returns the keys to add to the line's "gather" object."""
     import torch
     import torch.distributed as dist
@@ -580,11 +710,15 @@ def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_
     ybuf = [y, torch.empty_like(y)]
     pipe = sxdist.GatherPipeline(total_channels, tuple(y.shape), y.dtype, y.device, dst=0, chunks=4, depth=depth)
 
-    def run(nsteps):
+    stated = {}
+
+    def run(nsteps, state_last=False):
         for s in range(nsteps):
             k = s % depth
             pipe.reuse(k)
             step_into(ybuf[k])
+            if state_last and s == nsteps - 1:
+                stated["sums"] = cert.state(ybuf[k])
             pipe.submit(k, ybuf[k])
         pipe.drain()
 
@@ -608,11 +742,20 @@ def measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_
         "how": "each step's output gathered in %d chunks (whole channels) behind its kernel and beside the next "
                "steps' kernels, two output buffers in turn; value = whole-job MS/s of that pipeline" % pipe.chunks,
     }
+    # the certified steady state: `depth` more steps on the stream's next block; the last one's gather is checked
+    base = next_block()
     if dist.get_rank() == 0:
-        last = (psteps - 1) % depth
+        for k in range(depth):
+            pipe.full[k].zero_()
+    torch.cuda.synchronize()
+    run(depth, state_last=True)
+    last = (depth - 1) % depth
+    rec = cert.check(pipe.slot(last), stated["sums"], base, depth > 1)
+    if dist.get_rank() == 0:
         out["overlapped"]["root_holds_own_channels"] = bool(
             torch.equal(pipe.slot(last)[: y.shape[0]].to(y.device), ybuf[last]))
         out["overlapped"]["gathered_shape"] = list(pipe.slot(last).shape)
+        out["overlapped"]["check"] = rec
     return out
 
 
@@ -798,6 +941,8 @@ def main():
     ap.add_argument("--gather", default="torch", choices=["torch", "capi"],
                     help="N > 1: the gather of the decimated output through torch.distributed (nccl = RCCL) or through the "
                          "C ABI (sxfir_comm_gather over librccl directly)")
+    ap.add_argument("--alone-seconds", type=float, default=0.6,
+                    help="N > 1: seconds each rank times its kernel alone (and then all together) for the in-job efficiency figure")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
@@ -839,6 +984,25 @@ def main():
     dev = torch.device("cuda", gpu_index)
     cdev = torch.device("cpu") if host_collectives else dev
     backend_name = dist.get_backend() if world > 1 else None
+    # Who is in the job, as the job itself reports it: the communicator's size (not the environment's WORLD_SIZE) and the
+    # PCI address of every rank's GPU, exchanged over a host-side control group (gloo).  The control group also carries
+    # the turn-taking barriers of the alone / together kernel timing and the checksum tables of the gather checks, so that
+    # the data-path communicator (nccl = RCCL) carries nothing but the data -- and a rank that waits its turn leaves its
+    # GPU idle (a barrier over RCCL would park a spinning kernel on it).
+    ident = gpu_identity(gpu_index)
+    ident["rank"] = rank
+    ctl, identities = None, [ident]
+    if world > 1:
+        ctl = dist.group.WORLD if host_collectives else dist.new_group(backend="gloo")
+        identities = [None] * world
+        dist.all_gather_object(identities, ident, group=ctl)
+        comm_ranks = dist.get_world_size()
+        if comm_ranks != world:
+            raise SystemExit("the communicator holds %d ranks, WORLD_SIZE says %d" % (comm_ranks, world))
+        distinct = len({i.get("pci_bus_id") for i in identities})
+        if not host_collectives and distinct != world:
+            raise SystemExit("%d ranks but %d distinct GPUs (%s): RCCL needs one GPU per rank"
+                             % (world, distinct, [i.get("pci_bus_id") for i in identities]))
 
     ratio, ntaps, decim = cfg["ratio"], cfg["ntaps"], cfg["mode"] == "decim"
     wide_per_gpu = 1 << args.log2_samples
@@ -883,6 +1047,42 @@ def main():
     torch.cuda.synchronize()
     if args.settle > 0:
         plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, args.settle, stream)
+        plan.reset()
+        torch.cuda.synchronize()
+
+    # N > 1: per-GPU efficiency measured INSIDE this job (a line from another box differs by the 4-6 % box spread):
+    # every rank times its kernel alone while the others idle (turns behind host-side barriers), then all ranks time it
+    # together.  Node-level power / thermal coupling is the only thing that can cost per-GPU efficiency on a path with
+    # no data-path collective, and this is what shows it.  Before any data-path collective; never part of `value`.
+    per_rank = None
+    if world > 1:
+        sampler = BoardSampler(gpu_index, 0.02, bdf=ident.get("pci_bus_id"))
+        sampler.start()
+
+        def timed_for(seconds):
+            t_a, ms = time.perf_counter(), []
+            plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, 20, stream)       # out of the idle state
+            t_b = time.perf_counter()
+            while time.perf_counter() - t_b < seconds or not ms:
+                ms.append(plan.time_passes_ptr(x.data_ptr(), n_in, xs, y.data_ptr(), ys, 50, stream))
+            return sum(ms) / len(ms), (t_b, time.perf_counter()), 50 * len(ms)
+
+        mine = {}
+        for turn in range(world):
+            dist.barrier(group=ctl)
+            if turn == rank:
+                mine["alone_ms"], w_alone, mine["alone_launches"] = timed_for(args.alone_seconds)
+        dist.barrier(group=ctl)
+        mine["together_ms"], w_tog, mine["together_launches"] = timed_for(args.alone_seconds)
+        dist.barrier(group=ctl)
+        sampler._stop.set()
+        for key, win in (("alone", w_alone), ("together", w_tog)):
+            st = sampler.window(*win)
+            mine["power_w_" + key] = st["power_w"] if st else None
+            mine["gfx_mhz_" + key] = st["gfx_mhz_smi"] if st else None
+        mine.update(rank=rank, gpu=ident.get("pci_bus_id"), gpu_index=gpu_index)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=ctl)
         plan.reset()
         torch.cuda.synchronize()
 
@@ -946,6 +1146,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         verified = bool(t.item() > 0.5)
     achieved = cfg["bytes"] * wide_per_gpu / (kernel_ms * 1e-3) / 1e9
+
+    def frac_of(ms):
+        return cfg["bytes"] * wide_per_gpu / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
     tflops = cfg["flop"] * wide_per_gpu / (kernel_ms * 1e-3) / 1e12
 
     def emit(gather):
@@ -991,8 +1195,15 @@ def main():
                 "narrowband_MS/s": round(value / ratio, 1),
                 "per_gpu_MS/s": round(value / world, 1),
                 "verified_outputs": cmp1 + cmp2,
-                "rccl_ranks": world if world > 1 else None,
+                "rccl_ranks": dist.get_world_size() if world > 1 else None,     # the communicator's own count
                 "backend": backend_name,
+                "gpus": [i.get("pci_bus_id") for i in identities],
+                "distinct_gpus": len({i.get("pci_bus_id") for i in identities}),
+                "gpu_name": ident.get("name"), "gpu_arch": ident.get("arch"),
+                # the host driver of this pool supports dmabuf IPC only: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's (and
+                # torch's) cross-process buffer sharing fails with "hipIpcGetMemHandle: invalid argument"; the image exports
+                # it, spawn_ranks sets it for its children if it is missing, and the line records what the ranks ran with
+                "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
             },
             "roofline": {
                 "bound": "hbm",
@@ -1011,6 +1222,13 @@ def main():
                 "kernel_ms_how": "HIP events on the launch stream around the K timed steps (one launch per step) / K",
                 "kernel_ms_back_to_back_loop": round(kernel_ms_loop, 4),
                 "kernel_ms_first_20": round(kernel_ms_first_20, 4),
+                # the four regimes of the same kernel on this box, as fractions of the 8 TB/s peak, read off one record:
+                # `frac` (the K timed steps, after the settle launches and the warm-up), the first 20 launches after 0.5 s
+                # of idle (what a bursty readStream caller sees), the back-to-back C loop right after the host-side oracle
+                # check (GPU idle for that long), and the one-second loop beside the telemetry sampling
+                "frac_cold_first_20": round(frac_of(kernel_ms_first_20), 4),
+                "frac_back_to_back_after_idle": round(frac_of(kernel_ms_loop), 4),
+                "frac_while_sampled": round(frac_of(kernel_ms_telemetry), 4) if kernel_ms_telemetry else None,
                 "kernel_ms_first_20_how": "the first 20 launches after 0.5 s of idle, before the settle launches: the "
                                           "clock transient a bursty caller sees; not part of value",
                 "board": dict(board, kernel_ms_while_sampled=(round(kernel_ms_telemetry, 4)
@@ -1027,8 +1245,29 @@ def main():
             line["roofline"]["note"] = ("CF16 storage halves the bytes but not the 128 flop per sample: this leg is "
                                         "bound by fp32 VALU throughput at the clock the power management allows; "
                                         "see roofline.valu")
+        if per_rank is not None:
+            # in-job efficiency: every rank's kernel alone (the others idle) against all ranks at once
+            ratios = sorted(r["alone_ms"] / r["together_ms"] for r in per_rank)
+            mean_alone = sum(r["alone_ms"] for r in per_rank) / world
+            mean_tog = sum(r["together_ms"] for r in per_rank) / world
+            for r in per_rank:
+                for k in ("alone_ms", "together_ms"):
+                    r[k] = round(r[k], 4)
+            line["per_rank"] = per_rank
+            line["efficiency_kernel_only"] = round(mean_alone / mean_tog, 4)
+            line["efficiency_per_rank"] = {"min": round(ratios[0], 4), "median": round(ratios[len(ratios) // 2], 4),
+                                           "max": round(ratios[-1], 4),
+                                           "how": "alone_ms / together_ms of each rank's kernel (same launches, same buffers): "
+                                                  "alone = the other ranks' GPUs idle, together = all ranks at once; "
+                                                  "efficiency_kernel_only = mean(alone) / mean(together)"}
         if gather is not None:
             line["gather"] = gather
+            checks = [c for c in (gather.get("check"), (gather.get("overlapped") or {}).get("check")) if c is not None]
+            line["gather_verified"] = all(c["verified"] for c in checks) if checks else None
+            if line["gather_verified"] is False:
+                # a peer block that is not what its sender held: the line must not say verified, and the job fails
+                line["verified"] = False
+                gather_failed["v"] = True
         if world == 1 and not args.no_through_device:
             try:
                 line["through_device"] = through_device()
@@ -1043,9 +1282,24 @@ def main():
     # not be able to take the line down with it: errors are recorded, and a watchdog prints the line without
     # the gather figures -- and ends the rank with a failure status -- if the collective does not come back.
     gather = None
+    gather_failed = {"v": False}
     if world > 1:
         import threading
         finished, stage = threading.Event(), {"name": "serial", "gather": None}
+        cert = GatherCertifier(cfg, plan, orc, world, rank, ctl, total_channels, nchan_local, n_in)
+        stream_block = [0]
+
+        def next_block():
+            """The rank's input becomes the next block of its channels' synthetic stream and the filter restarts (zero
+            history): what the following gather carries has never been gathered before.  Returns the block's first sample."""
+            stream_block[0] += 1
+            base = stream_block[0] * n_in
+            sxxcvr_amd.synth_fill(x, SEED, first_channel=lo, start=base, fmt=cfg["fmt"])
+            plan.reset()
+            return base
+
+        def step_into(out):
+            plan.process(x, out=out)
 
         def watchdog():
             if finished.wait(240.0):
@@ -1062,9 +1316,10 @@ def main():
         try:
             if args.gather == "capi":
                 gather = measure_gather_capi(world, rank, gpu_index, y, total_channels, cdev, wide_per_gpu, elapsed, args.steps,
-                                             lambda out: plan.process(x, out=out))
+                                             step_into, cert, next_block)
             else:
-                gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps)
+                gather = measure_gather(world, y, total_channels, host_collectives, cdev, wide_per_gpu, elapsed, args.steps,
+                                        cert, next_block, step_into)
         except Exception as e:
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
         finished.set()
@@ -1072,8 +1327,7 @@ def main():
             finished, stage["name"], stage["gather"] = threading.Event(), "overlapped", gather
             threading.Thread(target=watchdog, daemon=True).start()
             try:
-                gather.update(measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu,
-                                                       lambda out: plan.process(x, out=out)))
+                gather.update(measure_gather_pipelined(world, y, total_channels, cdev, wide_per_gpu, step_into, cert, next_block))
             except Exception as e:
                 gather["overlapped"] = {"error": "%s: %s" % (type(e).__name__, e)}
             finished.set()
@@ -1082,7 +1336,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if not verified:
+    if not verified or gather_failed["v"]:
         sys.exit(4)
 
 

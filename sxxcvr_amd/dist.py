@@ -86,6 +86,58 @@ def gather_channels(local, n_channels, dst=0, group=None, always_collective=Fals
     return torch.view_as_complex(out) if is_complex else out
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Certifying a gather: every rank states what it sent, the root recomputes it over what arrived
+# ------------------------------------------------------------------------------------------------------------
+def block_checksums(block):
+    """Per channel of a [channels, ...] block (complex64 samples, or any dtype whose row is a whole number of 64-bit
+    words): two 64-bit sums over the row's words w[i] taken as integers, mod 2^64 -- sum(w[i]) and the position-weighted
+    sum((2 i + 1) w[i]).  One flipped bit changes the first, two exchanged samples the second, a block that is another
+    channel's (or another step's) both.  Returns int64 [channels, 2] on the block's device; computed with the tensor
+    library's wrapping integer arithmetic, so a GPU and a host evaluation of the same bytes agree."""
+    import torch
+    w = torch.view_as_real(block) if block.is_complex() else block
+    w = w.contiguous().reshape(block.shape[0], -1)
+    if (w.shape[1] * w.element_size()) % 8:
+        raise ValueError("a channel's row must be a whole number of 64-bit words")
+    w = w.view(torch.int64)
+    weight = torch.arange(w.shape[1], device=w.device, dtype=torch.int64) * 2 + 1
+    out = torch.empty((w.shape[0], 2), dtype=torch.int64, device=w.device)
+    for c in range(w.shape[0]):                       # per channel: bounds the temporaries to one row
+        out[c, 0] = w[c].sum()
+        out[c, 1] = (w[c] * weight).sum()
+    return out
+
+
+def exchange_checksums(local_sums, n_channels, group=None):
+    """All-gather the ranks' [local_channels, 2] checksum tables into the [n_channels, 2] table of the whole job, in
+    global channel order (equal shards).  Host tensors in, host tensor out: 16 bytes per channel, over `group`
+    (bench.py hands its control group: gloo, so that the data-path communicator carries nothing but the data)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if n_channels % world:
+        raise ValueError("equal shards only (%d channels over %d ranks)" % (n_channels, world))
+    local = local_sums.detach().to("cpu", torch.int64).contiguous()
+    if tuple(local.shape) != (n_channels // world, 2):
+        raise ValueError("a rank states %s checksums, expected %s" % (tuple(local.shape), (n_channels // world, 2)))
+    if dist.get_backend(group) == "nccl":
+        raise ValueError("exchange_checksums wants a host-side group (gloo)")
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
+    return torch.cat(parts, dim=0)
+
+
+def check_gathered(full, stated, skip=()):
+    """Root side: recompute the checksums over the gathered [n_channels, ...] tensor and compare with what the
+    senders stated.  Returns the list of channels that differ (empty = every block arrived whole and in its place);
+    `skip`: channels not to hold against the gather (the root's own, which never travelled, are still checked by
+    default)."""
+    got = block_checksums(full).cpu()
+    bad = (got != stated.cpu()).any(dim=1).nonzero().flatten().tolist()
+    return [c for c in bad if c not in set(skip)]
+
+
 class GatherPipeline:
     """The exchange step in steady state ("chunk and overlap with the next tile's compute"):
     every step's decimated output is gathered to `dst` in `chunks` sub-collectives (groups of whole channels, so

@@ -10,7 +10,8 @@
 extern "C" {
 #include "sx_oracle.h"
 }
-extern int g_fake_launches;
+#include <atomic>
+extern std::atomic<int> g_fake_launches;
 
 static int bad = 0;
 static void check(const char *what, const float *got, const float *want, size_t n_floats)
@@ -46,7 +47,7 @@ static void rx_test()
         for (int c = 0; c < NCH; ++c) check("rx_read", buf[c].data(), ref[c].data() + 2 * pos, 2 * n);
         pos += (int64_t)n;
     }
-    const int launches_sequential = g_fake_launches;
+    const int launches_sequential = g_fake_launches.load();
     // a jump forward (overrun skip) and one backward (restart): the read-ahead is dropped, history re-primed
     for (int64_t jump : {(int64_t)150000, (int64_t)0, (int64_t)77}) {
         const size_t n = 3000;

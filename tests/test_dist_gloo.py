@@ -85,6 +85,75 @@ def test_gather_two_ranks_gloo(oracle, n_channels):
     assert np.array_equal(gathered.view(np.uint64), want.view(np.uint64))
 
 
+def _cert_worker(rank, world, port, n_channels, n, corrupt_rank, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        sxdist.init_process_group(backend="gloo")
+        lo, hi = sxdist.shard_channels(n_channels, world, rank)
+        g = torch.Generator().manual_seed(1000 + rank)
+        local = torch.complex(torch.randn(hi - lo, n, generator=g), torch.randn(hi - lo, n, generator=g))
+        sums = sxdist.block_checksums(local)                 # stated from what the sender holds ...
+        if rank == corrupt_rank:
+            local.view(torch.int64)[1, n // 2] ^= 1 << 33     # ... then one bit flips on the way
+        stated = sxdist.exchange_checksums(sums, n_channels)
+        full = sxdist.gather_channels(local, n_channels, dst=0)
+        bad = sxdist.check_gathered(full, stated) if rank == 0 else None
+        # a block that landed in another rank's place is caught too
+        swapped = None
+        if rank == 0 and corrupt_rank < 0:
+            per = n_channels // world
+            perm = full.clone()
+            perm[:per], perm[per:2 * per] = full[per:2 * per], full[:per]
+            swapped = sxdist.check_gathered(perm, stated)
+        q.put(("ok", bad, swapped, tuple(stated.shape)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc(), None, None))
+
+
+@pytest.mark.parametrize("corrupt_rank", [-1, 1, 0])
+def test_gather_is_certified_by_sender_checksums_gloo(corrupt_rank):
+    """What bench.py's N > 1 line relies on (GatherCertifier): every rank states two 64-bit checksums per channel of the
+    block it sends, the tables are all-gathered, the root recomputes them over the gathered tensor.  A clean gather passes;
+    one flipped bit in a peer's block (or the root's own) names exactly that channel; two blocks in each other's place
+    fail on every channel of both."""
+    world, n_channels, n = 2, 16, 4097
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cert_worker, args=(r, world, port, n_channels, n, corrupt_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] == "ok" for r in results), results
+    root = [r for r in results if r[1] is not None][0]
+    assert root[3] == (n_channels, 2)
+    if corrupt_rank < 0:
+        assert root[1] == [] and root[2] == list(range(16))
+    else:
+        assert root[1] == [8 * corrupt_rank + 1]
+
+
+def test_block_checksums_definition():
+    """sum(w) and sum((2 i + 1) w) over a row's 64-bit words mod 2^64, independent of dtype view and device."""
+    t = torch.complex(torch.randn(3, 1000), torch.randn(3, 1000))
+    s = sxdist.block_checksums(t).numpy().view(np.uint64)
+    w = t.numpy().view(np.uint64)
+    i = np.arange(1000, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        want = np.stack([w.sum(axis=1, dtype=np.uint64), (w * i).sum(axis=1, dtype=np.uint64)], axis=1)
+    assert np.array_equal(s, want)
+    assert torch.equal(sxdist.block_checksums(torch.view_as_real(t)), sxdist.block_checksums(t))
+    with pytest.raises(ValueError):
+        sxdist.block_checksums(torch.zeros(2, 3, dtype=torch.int32))
+
+
 def test_single_process_gather_is_identity():
     t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
     assert sxdist.gather_channels(t, 3) is t

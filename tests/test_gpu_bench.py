@@ -11,7 +11,38 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "3", "--warmup", "2", "--settle", "4", "--log2-samples", "22", "--no-cpu-baseline",
-         "--no-through-device"]
+         "--no-through-device", "--alone-seconds", "0.05"]
+
+
+def check_multi_rank_fields(line, world, backend):
+    """What makes an N > 1 line self-contained: the communicator's own rank count, the GPUs' PCI
+    addresses, every rank's kernel alone and together with the in-job efficiency, and a gather that rank 0 has checked
+    block by block (checksums of every channel + oracle windows on the first channel of every rank's block)."""
+    c = line["config"]
+    assert c["rccl_ranks"] == world and c["backend"] == backend
+    assert len(c["gpus"]) == world and all(isinstance(g, str) and g.count(":") == 2 for g in c["gpus"]), c["gpus"]
+    assert c["distinct_gpus"] == (world if backend == "nccl" else len(set(c["gpus"])))
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" in c["env"]
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(world))
+    for r in pr:
+        assert r["alone_ms"] > 0 and r["together_ms"] > 0 and r["gpu"] == c["gpus"][r["rank"]]
+        assert r["alone_launches"] >= 50 and r["together_launches"] >= 50
+        assert "power_w_alone" in r and "power_w_together" in r
+    mean = lambda k: sum(r[k] for r in pr) / world
+    assert abs(line["efficiency_kernel_only"] - mean("alone_ms") / mean("together_ms")) < 2e-3
+    e = line["efficiency_per_rank"]
+    assert 0 < e["min"] <= e["median"] <= e["max"]
+    g = line["gather"]
+    assert "error" not in g, g
+    assert g["rccl_ranks"] == world
+    assert line["gather_verified"] is True
+    checks = [g["check"]] + ([g["overlapped"]["check"]] if "overlapped" in g and "check" in g["overlapped"] else [])
+    for k in checks:
+        assert k["verified"] is True and k["bad_channels"] == [] and k["oracle_ok"] is True
+        assert k["peer_blocks_checked"] == world - 1 and k["channels_checksummed"] == 8 * world
+        assert k["oracle_outputs_on_first_channel_of_every_block"] >= 2048 * world and k["stream_block"] >= 1
+    return checks
 
 
 def run_bench(extra, env=None, timeout=600):
@@ -41,6 +72,12 @@ def test_bench_line_every_config(config):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 300.0 < r["shader_mhz"] < 2600.0
     assert line["value"] > 0 and r["kernel_ms"] > 0
+    # the regimes of the same kernel, as roofline fractions in the one record
+    bytes_ = r["algorithmic_bytes_per_launch"]
+    assert abs(r["frac_cold_first_20"] - bytes_ / (r["kernel_ms_first_20"] * 1e-3) / 8e12) < 2e-3
+    assert abs(r["frac_back_to_back_after_idle"] - bytes_ / (r["kernel_ms_back_to_back_loop"] * 1e-3) / 8e12) < 2e-3
+    assert r["frac_while_sampled"] is None or r["frac_while_sampled"] > 0
+    assert line["config"]["gpus"] and line["config"]["distinct_gpus"] == 1 and line["config"]["gpu_arch"].startswith("gfx950")
 
 
 def test_bench_config3_full_duplex_line():
@@ -93,6 +130,30 @@ def test_bench_starts_its_own_ranks_gloo_stand_in():
     g = line["gather"]
     assert "error" not in g, g
     assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
+    checks = check_multi_rank_fields(line, 2, "gloo")
+    assert len(checks) == 2                                   # the serial gather and the pipelined one
+    assert checks[0]["stream_block"] != checks[1]["stream_block"]      # each certified gather carries a block of its own
+
+
+@pytest.mark.parametrize("who", ["1", "0"])
+def test_bench_fails_on_a_corrupted_peer_block(who):
+    """Test hook SXFIR_BENCH_CORRUPT_RANK: that rank flips one bit of what it sends after stating its checksums.  The line
+    must come out with verified false, name the channel, and the job must exit non-zero (rank 1: a peer block that
+    travelled; rank 0: the root's own block)."""
+    e = dict(os.environ, SXFIR_DIST_BACKEND="gloo", SXFIR_BENCH_CORRUPT_RANK=who)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True,
+                         text=True, timeout=600, env=e)
+    assert run.returncode != 0, run.stdout[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:] + run.stderr[-2000:]
+    line = json.loads(lines[0])
+    assert line["verified"] is False and line["gather_verified"] is False
+    k = line["gather"]["check"]
+    assert k["verified"] is False and len(k["bad_channels"]) == 1
+    assert 8 * int(who) <= k["bad_channels"][0] < 8 * int(who) + 8
+    assert line["gather"]["overlapped"]["check"]["verified"] is False
 
 
 def test_bench_eight_ranks_gloo_stand_in():
@@ -108,6 +169,7 @@ def test_bench_eight_ranks_gloo_stand_in():
     o = g["overlapped"]
     assert o["gathered_shape"][0] == 64 and o["root_holds_own_channels"] is True and o["chunks_per_step"] == 4
     assert g["overlapped_value"] > 0 and 0 < g["link_bound_frac"]
+    assert len(check_multi_rank_fields(line, 8, "gloo")) == 2
 
 
 def test_bench_under_the_drivers_launcher_gloo_stand_in():
@@ -132,6 +194,7 @@ def test_bench_under_the_drivers_launcher_gloo_stand_in():
     assert line["n_gpus"] == 2 and line["verified"] is True and line["scaling"] == "weak"
     assert line["config"]["rccl_ranks"] == 2 and line["config"]["channels_per_gpu"] == 8
     assert line["gather"]["gathered_shape"][0] == 16
+    check_multi_rank_fields(line, 2, "gloo")
 
 
 def test_bench_two_ranks_over_rccl():
@@ -143,6 +206,7 @@ def test_bench_two_ranks_over_rccl():
     g = line["gather"]
     assert "error" not in g, g
     assert g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
+    assert len(check_multi_rank_fields(line, 2, "nccl")) == 2
 
 
 def test_bench_two_ranks_gather_through_the_c_abi():
@@ -156,6 +220,7 @@ def test_bench_two_ranks_gather_through_the_c_abi():
     assert "error" not in g, g
     assert g["via"].startswith("C ABI") and g["root_holds_own_channels"] is True and g["gathered_shape"][0] == 16
     assert g["overlapped"]["root_holds_own_channels"] is True and g["overlapped_value"] > 0
+    assert len(check_multi_rank_fields(line, 2, "nccl")) == 2
 
 
 def test_bench_refuses_the_c_abi_gather_over_the_gloo_stand_in():

@@ -53,6 +53,26 @@ if rank == 0:
         assert torch.equal(full[per * r:per * (r + 1)], want), r
     print("rccl ok world", world)
 
+# what bench.py's GatherCertifier does: senders state per-channel checksums computed on their GPU, the tables travel over
+# a host-side gloo group created BESIDE the nccl one, the root recomputes them over the gathered tensor
+ctl = dist.new_group(backend="gloo")
+sums = sxdist.block_checksums(y)
+assert sums.is_cuda and tuple(sums.shape) == (per, 2)
+stated = sxdist.exchange_checksums(sums, per * world, group=ctl)
+assert tuple(stated.shape) == (per * world, 2) and not stated.is_cuda
+full = sxdist.gather_channels(y, per * world, dst=0, always_collective=True)
+if rank == 0:
+    assert sxdist.check_gathered(full, stated) == []
+    assert torch.equal(sxdist.block_checksums(full.cpu()), sxdist.block_checksums(full).cpu())      # host and GPU evaluation agree
+    hit = per * (world - 1) + 3                                     # a channel of the last rank's block
+    full.view(torch.int64)[hit, 777] ^= 1
+    assert sxdist.check_gathered(full, stated) == [hit]
+    print("rccl checksums ok world", world)
+ids = [None] * world
+dist.all_gather_object(ids, torch.cuda.get_device_properties(local_rank).name, group=ctl)
+assert len(ids) == world and dist.get_world_size() == world
+dist.barrier(group=ctl)
+
 # the pipelined gather (GatherPipeline) over nccl: async collectives behind the kernels, two buffers in turn;
 # every step's gathered block must be that step's output (steps differ: the stream moves on)
 depth, steps = 2, 5
@@ -114,6 +134,7 @@ def test_gather_allreduce_barrier_through_rccl(tmp_path):
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "rccl ok world %d" % world in outs[0]
+    assert "rccl checksums ok world %d" % world in outs[0], outs[0][-1500:]
     assert "rccl pipeline ok world %d" % world in outs[0], outs[0][-1500:]
 
 
@@ -171,6 +192,15 @@ def test_comm_gather_from_python_world_of_one():
     rank, n, dev = C.c_int(-1), C.c_int(-1), C.c_int(-1)
     assert lib.sxfir_comm_rank(comm, C.byref(rank), C.byref(n), C.byref(dev)) == 0
     assert (rank.value, n.value) == (0, 1) and dev.value == torch.cuda.current_device()
+    # ... and as RCCL itself reports them (ncclCommUserRank / ncclCommCount / ncclCommCuDevice): what bench.py records
+    rank, n, dev = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    assert lib.sxfir_comm_query(comm, C.byref(rank), C.byref(n), C.byref(dev)) == 0, lib.sxfir_last_error()
+    assert (rank.value, n.value) == (0, 1) and dev.value == torch.cuda.current_device()
+    assert lib.sxfir_comm_query(None, None, None, None) == -1
+    bdf = C.create_string_buffer(32)
+    assert lib.sxfir_device_pci_bus_id(-1, bdf, 32) == 0, lib.sxfir_last_error()
+    assert bdf.value.count(b":") == 2 and b"." in bdf.value, bdf.value
+    assert lib.sxfir_device_pci_bus_id(0, bdf, 8) == -1                    # buffer too small: refused, not truncated
     src = torch.arange(1 << 16, dtype=torch.int32, device="cuda")
     dst = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
