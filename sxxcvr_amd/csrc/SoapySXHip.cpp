@@ -576,6 +576,7 @@ public:
         } else if (key == "TX_CAPTURE_CHANNEL") {
             const int c = std::stoi(value);
             if (c < 0 || c >= nchan) throw std::runtime_error("No such channel");
+            std::scoped_lock lock(pcm_tx.mutex);               // txCapture reads it under the TX mutex
             capture_channel = c;
         } else {
             throw std::runtime_error("Unknown setting");
@@ -584,10 +585,16 @@ public:
 
     std::string readSetting(const std::string &key) const override
     {
+        // Any thread may ask while RX and TX stream on theirs.  The positions are atomics (no queueing behind a blocking
+        // call); everything that looks into a chain takes that stream's mutex, as the stream calls do (:878, :979);
+        // the ratios change under all three mutexes (setSampleRate) and are read under the register one.
         if (key == "CLOCK_NOW") return std::to_string(clock.now());
-        if (key == "RX_POSITION") return std::to_string(pcm_rx.position);
-        if (key == "TX_POSITION") return std::to_string(pcm_tx.position);
-        if (key == "TX_WRITTEN") return std::to_string(tx_chain->written());
+        if (key == "RX_POSITION") return std::to_string(pcm_rx.position.load());
+        if (key == "TX_POSITION") return std::to_string(pcm_tx.position.load());
+        if (key == "TX_WRITTEN") {
+            std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
+            return std::to_string(tx_chain->written());
+        }
         if (key == "TX_PTT_SAMPLES") {
             std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
             return std::to_string(tx_chain->keyed_samples());
@@ -600,11 +607,15 @@ public:
             std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
             return std::to_string(tx_chain->direct_samples());
         }
-        if (key == "RX_DECIM") return std::to_string(decim);
-        if (key == "TX_INTERP") return std::to_string(interp);
-        if (key == "RX_NTAPS") return std::to_string(rx_chain->ntaps());
+        if (key == "RX_DECIM" || key == "TX_INTERP" || key == "RX_NTAPS") {
+            std::scoped_lock lock(reg_mutex);
+            return std::to_string(key == "RX_DECIM" ? decim : key == "TX_INTERP" ? interp : decim * taps_per_phase);
+        }
         if (key == "SEED") return std::to_string(seed);
-        if (key == "TX_CAPTURE_CHANNEL") return std::to_string(capture_channel);
+        if (key == "TX_CAPTURE_CHANNEL") {
+            std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
+            return std::to_string(capture_channel);
+        }
         throw std::runtime_error("Unknown setting");
     }
 

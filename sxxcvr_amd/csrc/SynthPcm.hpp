@@ -17,6 +17,7 @@
 // rate).  Sample data comes from / goes to the GPU chains (GpuChains.hpp).
 #pragma once
 
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
@@ -105,7 +106,10 @@ public:
     enum stream_mode stream_mode;
     bool setup_done;
     bool activated;
-    int64_t position;            // samples handed to / taken from the application, incl. skipped ones
+    // samples handed to / taken from the application, incl. skipped ones.  Written by the stream's own calls under the
+    // stream mutex (as in the reference, :373); atomic because the build's RX_POSITION / TX_POSITION settings read it from
+    // any thread without queueing behind a blocking read or write.
+    std::atomic<int64_t> position;
     uint64_t hwp_period_size;
     uint64_t hwp_buffer_size;
 
@@ -170,9 +174,14 @@ public:
         return state_ == RUNNING ? clock_->now() - start_clock_ : hw_frozen_;
     }
 
+    // Every operation below reads (and some change) state_ / start_clock_ / hw_frozen_, which a LINKED peer driven from
+    // another thread starts and stops too (SoapySX.cpp:36-43: snd_pcm_link): they hold the link mutex while they look,
+    // and never while they wait for the clock.
+
     // snd_pcm_avail_delay.  Returns 0 or -EPIPE (stopped by an xrun, LINK mode).
     int avail_delay(int64_t *avail, int64_t *delay)
     {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
         check_xrun();
         if (state_ == XRUN) return -EPIPE;
         const int64_t h = hw();
@@ -198,6 +207,7 @@ public:
 
     int64_t forward(int64_t frames)
     {
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
         const int64_t can = forwardable();
         if (can < 0) return can;
         if (frames > can) frames = can;
@@ -209,9 +219,13 @@ public:
     // snd_pcm_wait: block until at least one frame can be transferred.
     void wait_for_space_or_data()
     {
-        if (state_ != RUNNING) return;
-        if (dir == CAPTURE) clock_->wait_until(start_clock_ + appl_ + 1);
-        else clock_->wait_until(start_clock_ + appl_ - (int64_t)hwp_buffer_size + 1);
+        int64_t target;
+        {
+            std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+            if (state_ != RUNNING) return;
+            target = dir == CAPTURE ? start_clock_ + appl_ + 1 : start_clock_ + appl_ - (int64_t)hwp_buffer_size + 1;
+        }
+        clock_->wait_until(target);
     }
 
     // Blocking transfer bookkeeping of snd_pcm_readi: waits (lets the clock
@@ -220,10 +234,16 @@ public:
     // that was only prepared starts on its first read (start_threshold = 1).
     int64_t begin_read(int64_t frames, int64_t *first)
     {
-        if (state_ == PREPARED) start();
-        check_xrun();
-        if (state_ == XRUN) return -EPIPE;
-        clock_->wait_until(start_clock_ + appl_ + frames);
+        int64_t target;
+        {
+            std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+            if (state_ == PREPARED) start();
+            check_xrun();
+            if (state_ == XRUN) return -EPIPE;
+            target = start_clock_ + appl_ + frames;
+        }
+        clock_->wait_until(target);
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
         check_xrun();
         if (state_ == XRUN) return -EPIPE;
         *first = appl_;
@@ -236,11 +256,22 @@ public:
     // write starts the (linked) PCMs (start_threshold = 1).
     int64_t begin_write(int64_t frames, int64_t *first)
     {
-        check_xrun();
-        if (state_ == XRUN) return -EPIPE;
-        if (state_ == RUNNING) {
-            clock_->wait_until(start_clock_ + appl_ + frames - (int64_t)hwp_buffer_size);
-        } else {
+        int64_t target = 0;
+        bool running;
+        {
+            std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+            check_xrun();
+            if (state_ == XRUN) return -EPIPE;
+            running = state_ == RUNNING;
+            if (running) target = start_clock_ + appl_ + frames - (int64_t)hwp_buffer_size;
+        }
+        if (running) clock_->wait_until(target);
+        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+        if (running) {
+            // (no xrun evaluation of its own here: a call that waited for room has by construction not run dry; but a
+            // linked capture PCM that overflowed meanwhile has stopped this one too)
+            if (state_ == XRUN) return -EPIPE;
+        } else if (state_ != RUNNING) {
             const int64_t room = (int64_t)hwp_buffer_size - appl_;
             if (frames > room) frames = room > 0 ? room : 0;   // not running: cannot drain
         }

@@ -93,20 +93,91 @@ def test_tick_conversion_against_oracle(probe, oracle):
         assert int(back) == int(t)                                  # round trip is exact at every table rate
 
 
-def test_gpu_chains_over_fake_backend(oracle, tmp_path):
-    """GpuChains.hpp (RX batching + read-ahead + jump handling + channel layout, TX write-behind + silence +
-    sink-ring wrap) on the CPU: linked against tests/host/fake_sxfir.cpp, a TEST-ONLY implementation of the C ABI
-    in which the oracle does the arithmetic.  Every sample must equal one direct oracle pass over the stream."""
-    exe = str(tmp_path / "chains_probe")
+# ------------------------------------------------------------------------------------------------------------------
+# The host side under sanitizers.  The Device module is multi-threaded C++ (per-stream mutexes as SoapySX.cpp:373, :750,
+# :878, :979, :1110-1125; CopyPool workers; two HIP streams per chain; read-ahead slots).  Everything above the C ABI is
+# compiled here as it ships, over tests/host/fake_sxfir.cpp -- a TEST-ONLY backend in which every stream is a thread of
+# its own that runs its queue late (random delays), so that a wait the host code forgot shows as wrong samples AND as a
+# data race -- and run three ways: AddressSanitizer + UBSan, ThreadSanitizer, plain.  All builds and runs go side by side.
+# ------------------------------------------------------------------------------------------------------------------
+SAN = {
+    "asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+    "tsan": ["-fsanitize=thread"],
+    "plain": [],
+}
+
+
+def _oracle_link():
+    """The AVX2+FMA build of the oracle where the CPU has both (8 x faster; same bits): the fake backend's arithmetic."""
+    cpuinfo = open("/proc/cpuinfo").read()
+    return "-lsxoracle_fast" if (" avx2" in cpuinfo and " fma" in cpuinfo) else "-lsxoracle"
+
+
+@pytest.fixture(scope="module")
+def sanitized(oracle, tmp_path_factory):
+    """Builds {chains_probe, device_probe, host_logic_probe, stream_rules_probe} x {asan, tsan[, plain]} and runs them,
+    everything in parallel; returns {(probe, flavour): (returncode, stdout, stderr)}."""
+    out = tmp_path_factory.mktemp("san")
     csrc = os.path.join(ROOT, "sxxcvr_amd", "csrc")
     odir = os.path.join(ROOT, "oracle")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-I" + odir,
-           os.path.join(ROOT, "tests", "host", "chains_probe.cpp"), os.path.join(ROOT, "tests", "host", "fake_sxfir.cpp"),
-           "-o", exe, "-L" + odir, "-lsxoracle", "-Wl,-rpath," + odir, "-pthread"]
-    subprocess.run(cmd, check=True)
-    run = subprocess.run([exe], capture_output=True, text=True)
-    lines = run.stdout.splitlines()
-    assert run.returncode == 0 and lines[-1] == "bad 0", run.stdout[-2000:]
+    host = os.path.join(ROOT, "tests", "host")
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-I" + os.path.join(csrc, "compat"), "-I" + odir]
+    olink = ["-L" + odir, _oracle_link(), "-Wl,-rpath," + odir, "-pthread"]
+    fake = os.path.join(host, "fake_sxfir.cpp")
+    device_srcs = [os.path.join(host, "device_probe.cpp"), fake, os.path.join(csrc, "SoapySXHip.cpp"),
+                   os.path.join(csrc, "sx_device_capi.cpp"), os.path.join(csrc, "compat", "SoapySDRCompat.cpp")]
+    calls = os.environ.get("SX_HOST_PROBE_CALLS")          # 100000 = the full-size run recorded in profiles/round5_host_sanitizers.txt
+    jobs = {
+        ("chains", "asan"): ([os.path.join(host, "chains_probe.cpp"), fake], olink, []),
+        ("chains", "tsan"): ([os.path.join(host, "chains_probe.cpp"), fake], olink, []),
+        ("device", "plain"): (device_srcs, olink, [calls or "30000", "40", "lenient"]),
+        ("device", "asan"): (device_srcs, olink, [calls or "8000", "40", "lenient"]),
+        ("device", "tsan"): (device_srcs, olink, [calls or "4000", "40", "lenient"]),
+        ("host_logic", "asan"): ([os.path.join(host, "host_logic_probe.cpp"), os.path.join(csrc, "compat", "SoapySDRCompat.cpp")],
+                                 ["-pthread"], []),
+        ("host_logic", "tsan"): ([os.path.join(host, "host_logic_probe.cpp"), os.path.join(csrc, "compat", "SoapySDRCompat.cpp")],
+                                 ["-pthread"], []),
+        ("stream_rules", "asan"): ([os.path.join(host, "stream_rules_probe.cpp")], ["-L" + odir, "-lsxoracle", "-Wl,-rpath," + odir], []),
+    }
+    builds = {}
+    for (probe, flav), (srcs, link, _) in jobs.items():
+        exe = str(out / ("%s_%s" % (probe, flav)))
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-ffp-contract=off"] + SAN[flav] + inc + srcs + ["-o", exe] + link
+        builds[(probe, flav)] = (exe, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    runs = {}
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    for key, (exe, proc) in builds.items():
+        log, _ = proc.communicate(timeout=600)
+        assert proc.returncode == 0, "%s %s did not build:\n%s" % (key[0], key[1], log[-3000:])
+        runs[key] = subprocess.Popen([exe] + jobs[key][2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    results = {}
+    for key, proc in runs.items():
+        try:
+            so, se = proc.communicate(timeout=1500)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            so, se = proc.communicate()
+            se += "\nTIMEOUT"
+        results[key] = (proc.returncode, so, se)
+    return results
+
+
+def _clean(results, key):
+    rc, so, se = results[key]
+    assert "Sanitizer" not in se and "runtime error" not in se and "TIMEOUT" not in se, "%s %s:\n%s" % (key[0], key[1], se[-4000:])
+    assert rc == 0, "%s %s exited %d:\n%s\n%s" % (key[0], key[1], rc, so[-2000:], se[-2000:])
+    return so.splitlines()
+
+
+@pytest.mark.parametrize("flavour", ["asan", "tsan"])
+def test_gpu_chains_over_fake_backend(sanitized, flavour):
+    """GpuChains.hpp (RX batching + read-ahead + jump handling + channel layout, TX write-behind + silence +
+    sink-ring wrap) on the CPU: linked against tests/host/fake_sxfir.cpp, a TEST-ONLY asynchronous implementation of
+    the C ABI in which the oracle does the arithmetic.  Every sample must equal one direct oracle pass over the stream,
+    and neither AddressSanitizer + UBSan nor ThreadSanitizer may have anything to say."""
+    lines = _clean(sanitized, ("chains", flavour))
+    assert lines[-1] == "bad 0", "\n".join(lines[-30:])
     assert all(l.split()[1] == "0" for l in lines if " mismatches " in l)
     assert "tx_backwards refused" in lines
     # ten sequential reads (154k samples per channel) in a handful of batched passes, not one per read
@@ -127,6 +198,35 @@ def test_gpu_chains_over_fake_backend(oracle, tmp_path):
     assert big[1] == big[3] and int(big[1]) > 0
     keyed = [l for l in lines if l.startswith("tx_keyed ")][0].split()
     assert keyed[1] == keyed[3] and int(keyed[1]) > 0 and "tx_keyed_after_reset 0" in lines
+
+
+@pytest.mark.parametrize("flavour", ["plain", "asan", "tsan"])
+def test_device_threads_over_fake_backend(sanitized, flavour):
+    """tests/host/device_probe.cpp: SoapySXHip.cpp + sx_device_capi.cpp as they ship, driven through include/sx_device.h
+    the way applications do -- an RX thread, a TX thread and a third thread on getHardwareTime / settings / registers
+    (example/plot_rxtx_response.py:65-77; SoapySX.cpp:878, :979, :1110-1125) with 4096-sample and megabyte blocks, linked
+    streams started and stopped across threads, and thousands of mixed calls (timed writes, non-blocking reads, overrun
+    skips, resets) -- every RX block the oracle's at the position its timestamp names, every TX sample accounted for."""
+    lines = _clean(sanitized, ("device", flavour))
+    assert lines[-1] == "bad 0", "\n".join(lines[-30:])
+    assert not [l for l in lines if l.startswith("FAIL")]
+    t = [l for l in lines if l.startswith("threads blocks 40 bad 0")]
+    m = [l for l in lines if l.startswith("megabyte blocks 6 bad 0")]
+    k = [l for l in lines if l.startswith("linked rounds 3 xruns 3 bad 0")]
+    c = [l for l in lines if l.startswith("calls ")]
+    assert t and m and k and c, lines[-12:]
+    f = c[0].split()
+    assert int(f[3]) > 1000 and int(f[5]) > 1000 and int(f[7]) > 10 and f[f.index("bad") + 1] == "0"     # reads, writes, clock jumps
+
+
+@pytest.mark.parametrize("flavour", ["asan", "tsan"])
+def test_host_logic_probe_under_sanitizers(sanitized, flavour):
+    _clean(sanitized, ("host_logic", flavour))
+
+
+def test_stream_rules_probe_under_sanitizers(sanitized):
+    lines = _clean(sanitized, ("stream_rules", "asan"))
+    assert lines[-1].strip().endswith("cases 400000 mismatches 0")
 
 
 def test_stream_placement_rules_against_the_oracle(tmp_path):
