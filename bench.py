@@ -905,6 +905,11 @@ def main_duplex(args):
             "rx": direction(rx_ms, rxc["kernel"]), "tx": direction(tx_ms, txc["kernel"]),
             "alone_kernel_ms": {k: round(v, 4) for k, v in alone.items()},
             "sum_alone_ms": round(alone["rx"] + alone["tx"], 4),
+            # what running the two directions side by side buys over running them one after the other: the step's wall
+            # time over the sum of the two kernels alone.  ~1.0 (measured 1.016 in round 4): both kernels sit at the
+            # package power cap alone, so two streams share one power budget -- "full duplex" here is concurrency of the
+            # API (read and write in flight together, SoapySX.cpp:878 / :979), not extra throughput
+            "duplex_vs_serial": round(ms_per_step / (alone["rx"] + alone["tx"]), 4),
             "fp32_TFLOPs": round(128.0 * 2 * n / (ms_per_step * 1e-3) / 1e12, 2),
             "board": board,
         },
@@ -1037,7 +1042,7 @@ def main():
         plan.process(x, out=y)
 
     # Setup, untimed and independent of --warmup: let the chip's power management settle on this kernel (its
-    # time swings 0.49 -> 0.84 -> 0.60 ms over the first ~20 launches); same launches
+    # time swings 0.49 -> 0.84 -> 0.60 ms over the first ~20 launches, LABBOOK.md section 7); same launches
     # as a step, then the stream restarts at position 0.
     # The first 20 launches on a chip that has been idle (what a bursty readStream caller sees, the pattern of
     # example/linear_repeater.py:57-69): reported as roofline.kernel_ms_first_20, never part of `value`.
@@ -1252,7 +1257,7 @@ def main():
             mean_tog = sum(r["together_ms"] for r in per_rank) / world
             for r in per_rank:
                 for k in ("alone_ms", "together_ms"):
-                    r[k] = round(r[k], 4)
+                    r[k] = round(r[k], 6)
             line["per_rank"] = per_rank
             line["efficiency_kernel_only"] = round(mean_alone / mean_tog, 4)
             line["efficiency_per_rank"] = {"min": round(ratios[0], 4), "median": round(ratios[len(ratios) // 2], 4),

@@ -108,7 +108,7 @@ int sxfir_reset(sxfir_plan *plan, void *stream);
  * length: ntaps for a decimator, ntaps/ratio for an interpolator), as if that block had just been processed.
  * With it consecutive blocks of one stream can be handed to SEVERAL plans (on several HIP streams or GPUs): block
  * k+1 needs nothing from block k but the tail of its INPUT, which is in memory before either runs
- * (sxxcvr_amd.PipelinedResampler).  No speed-up on one GPU: DESIGN.md 7. */
+ * (sxxcvr_amd.PipelinedResampler).  No speed-up on one GPU: LABBOOK.md 7. */
 int sxfir_set_history(sxfir_plan *plan, const void *src_dev, size_t n, size_t stride, void *stream);
 /* Place the plan at sample `consumed` of its input stream (the count sxfir_position reports as consumed; the
  * outputs produced so far follow from it: ceil(consumed / D) for a decimator, consumed * L for an interpolator).

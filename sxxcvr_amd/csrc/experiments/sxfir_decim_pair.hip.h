@@ -1,6 +1,6 @@
 // Decimate-by-4, 128 taps: the two tap halves on two WAVES (gfx950).
 //
-// The /4 kernels are bound by the energy of their packed FMAs (the board sits at its power
+// The /4 kernels are bound by the energy of their packed FMAs (LABBOOK.md 5.1: the board sits at its power
 // cap), and the cheapest FMA has its tap in an SGPR pair.  A scalar operand is wave-uniform; instead of
 // giving every lane all taps (sxfir_decim_tile2.hip.h, T2_SCALAR: needs symmetric taps to fit the SGPR file and
 // 71 LDS reads per 512 FMAs) this kernel gives every WAVE one tap half:

@@ -57,7 +57,7 @@
 #include "sxfir_decim_tile2.hip.h"
 #include "sxfir_decim_wide.hip.h"               // /4, 128 symmetric taps: the shipped form since round 4
 #ifdef SXFIR_PROFILING
-#include "experiments/sxfir_decim_pair.hip.h"   // measured variant, not shipped
+#include "experiments/sxfir_decim_pair.hip.h"   // measured variant, not shipped (LABBOOK.md 5.1)
 #endif
 #ifdef SXFIR_PROFILING
 #include "experiments/sxfir_decim_sgpr.hip.h"

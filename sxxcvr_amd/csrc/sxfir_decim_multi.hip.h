@@ -18,7 +18,7 @@
 // Workgroup = W waves sharing one tile of W*OW outputs (+ 31 halo rows); every wave owns OW of them:
 // lanes = (p, c, g): tap-row range p (top lane bits), column group c (next lane bits), output group g
 // (8 outputs each).  PS = 2 (shipped): two row halves, 64 taps and 512 packed FMAs per lane and tile.
-// PS = 4 (SXFIR_MULTI_PS=4, measured slower: DESIGN.md): four row quarters, 32 taps and 256 packed FMAs, so
+// PS = 4 (SXFIR_MULTI_PS=4, measured slower: LABBOOK.md 5.2): four row quarters, 32 taps and 256 packed FMAs, so
 // that twice as many, lighter waves share a tile.
 // Reduction: v_permlane32_swap / v_permlane16_swap over p and c bit 0, lane xor 8 / 4 / 2 for the
 // remaining column bits: the adjacent-pair trees of the numeric contract, first over the

@@ -135,7 +135,7 @@ __device__ __forceinline__ void stage_edge_chunk(const DecimTileCtx<NT> &c, long
 // AUX: cache policy bits of every DMA (profiling modes), or -1 (the default, round 4): instructions 1..7 are
 // non-temporal loads; the last two -- the tile's last kilobyte, which the next tile reads again as its halo -- and
 // instruction 0 -- this tile's re-read of the previous one's -- stay plain loads: whichever of the two reaches the
-// XCD's L2 first allocates the line, the other hits (tools/membench5.hip).
+// XCD's L2 first allocates the line, the other hits (tools/membench5.hip, LABBOOK.md 5.1 round 4).
 template <int NT, int AUX = -1>
 __device__ __forceinline__ void stage_tile(const DecimTileCtx<NT> &c, int tile, f32x4 *buf)
 {

@@ -1,11 +1,11 @@
 // Decimate-by-4, 128 symmetric taps: 8 outputs per lane, one wave per tile of 512 outputs (gfx950).
 // The production kernel of BASELINE config 2 since round 4 (a measured variant in rounds 2-3).
 //
-// The /4 kernels are bound by the energy of their arithmetic at the board's power cap, and the
+// The /4 kernels are bound by the energy of their arithmetic at the board's power cap (LABBOOK.md 5.1), and the
 // arithmetic probe ranks the instruction mixes: taps as SGPR operands, and as few LDS reads per FMA as possible.
 // sxfir_decim_tile2.hip.h (T2_SCALAR) has the SGPR taps with 4 outputs per lane: 71 ds_read_b128 per 512 packed
 // FMAs.  This kernel doubles the outputs per lane.  In round 2 it tied with the 4-output form: two waves per SIMD left
-// its structure no faster than the power cap allowed the other.  Round 4's non-temporal staging loads (DESIGN.md 5.1
+// its structure no faster than the power cap allowed the other.  Round 4's non-temporal staging loads (LABBOOK.md 5.1
 // "Round 4") and a deeper LDS read-ahead (NB = 24 chunks; two waves per SIMD leave a wave 256 VGPRs) moved its
 // structure well below the cap (0.44 ms on an all-zero input), and at the cap its lower energy per sample -- 39.5 instead
 // of 71 LDS reads per 512 FMAs, a 6 % instead of a 12.5 % halo, sixteen consecutive FMAs sharing a sample pair -- now

@@ -266,7 +266,7 @@ class PipelinedResampler:
     before either pass runs: each plan's filter state is seeded from there (sxfir_set_history) and the passes are
     independent launches.  Each plan is also told where in the stream its block starts (sxfir_set_position), so
     blocks need not be multiples of the ratio: the outputs, their count and their positions are those of one plan
-    fed block by block.  (On one GPU this buys nothing once every block is new data -- DESIGN.md 7 -- it is the way
+    fed block by block.  (On one GPU this buys nothing once every block is new data -- LABBOOK.md 7 -- it is the way
     to split one stream over plans or GPUs.)
 
     Ordering: every pass waits (on the GPU) for the work the CALLER's current torch stream had queued when

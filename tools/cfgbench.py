@@ -1,4 +1,4 @@
-"""Throughput of the other BASELINE shapes (parity-test configs, not bench lines): for DESIGN.md."""
+"""Throughput of the other BASELINE shapes (parity-test configs, not bench lines): for LABBOOK.md section 7."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ def run(name, mode, ntaps, ratio, fmt, log2n, kernel=None, gain=1.0):
     x = torch.empty(n, dtype=dt_in, device="cuda"); sxxcvr_amd.synth_fill(x, 0x51255, 0, 0, fmt=fmt)
     n_out = n // ratio if mode == DECIMATE else n * ratio
     y = torch.empty(n_out, dtype=dt_in, device="cuda")
-    # warm up past the clock transient of the first launches ("measurement notes"); the slow
+    # warm up past the clock transient of the first launches (LABBOOK.md section 7); the slow
     # generic kernels get fewer repetitions
     fast = kernel is None
     for _ in range(100 if fast else 3): p.process(x, out=y)

@@ -1,4 +1,4 @@
-// Which of the clock figures is the shader clock?  ("clocks")
+// Which of the clock figures is the shader clock?  (LABBOOK.md section 5.1 "Round 3", section 7)
 //
 // One wave per SIMD issues N independent v_fma_f32, one every 4 cycles when alone on its SIMD
 // (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), so N * 4 / (wall time) is the shader clock by

@@ -1,5 +1,5 @@
 """Through-the-Device throughput (readStream / writeStream incl. PCIe and launch overheads); API-parity
-figure for DESIGN.md, never the bench value."""
+figure for LABBOOK.md, never the bench value."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 // When is what a kernel stored into HOST memory visible to the host?  (Round 3 saw, once, the last 16 bytes of a
-// tile of a zero-copy pass still holding the caller's zeros when readStream returned)
+// tile of a zero-copy pass still holding the caller's zeros when readStream returned; LABBOOK.md section 9.)
 //
 // A kernel writes a per-launch pattern into host memory in the decimator's store shape -- whole 1 KiB lines from
 // 64 lanes x 16 bytes, then a ragged last tile written element by element with 4-byte stores, ending in the middle

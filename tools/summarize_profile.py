@@ -137,19 +137,22 @@ for cfg in configs:
             out["trace_row"] = {"VGPR_Count_column": r.get("VGPR_Count"), "SGPR_Count_column": r.get("SGPR_Count"),
                                 "lds_bytes": r.get("LDS_Block_Size"), "grid": [r.get("Grid_Size_X"), r.get("Grid_Size_Y")],
                                 "workgroup": r.get("Workgroup_Size_X")}
-            # the profiled command is bench.py --steps 50 --warmup 50: its last launches are 50 warm-up steps, the 50
-            # timed steps (bracketed by the HIP events bench.py reports as roofline.kernel_ms), 50 launches from one
-            # back-to-back C loop and 50 more beside the clock probe; whatever comes before is the untimed settle
-            # phase, which contains the clock transient of the first ~20 launches
+            # the profiled command is bench.py --steps 50 --warmup 50 (default --settle 150).  Its launches of this kernel,
+            # in order: 20 after 0.5 s of idle (roofline.kernel_ms_first_20), 150 settle, 50 warm-up steps, the 50 TIMED
+            # steps (bracketed by the HIP events bench.py reports as roofline.kernel_ms), 50 from one back-to-back C loop
+            # right after the host-side oracle check, about a second of launches beside the telemetry sampler, and 50
+            # beside the clock probe.
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             n = len(d)
-            if n >= 200:
-                out["avg_ns_by_phase"] = {"warmup": sum(d[n - 200:n - 150]) / 50.0, "timed": sum(d[n - 150:n - 100]) / 50.0,
-                                          "back_to_back_loop": sum(d[n - 100:n - 50]) / 50.0,
-                                          "beside_clock_probe": sum(d[n - 50:]) / 50.0}
-                if n > 200:
-                    out["avg_ns_by_phase"]["settle"] = sum(d[:n - 200]) / float(n - 200)
-                    out["avg_ns_by_phase"]["settle_first_20"] = sum(d[:20]) / 20.0
+            if n >= 370:
+                mean = lambda a: sum(a) / float(len(a))
+                out["avg_ns_by_phase"] = {"first_20_after_idle": mean(d[0:20]), "settle": mean(d[20:170]), "warmup": mean(d[170:220]),
+                                          "timed": mean(d[220:270]), "back_to_back_loop": mean(d[270:320]),
+                                          "beside_clock_probe": mean(d[n - 50:])}
+                if n > 420:
+                    out["avg_ns_by_phase"]["while_sampled"] = mean(d[320:n - 50])
+                out["launches_by_phase"] = {"first_20_after_idle": 20, "settle": 150, "warmup": 50, "timed": 50, "back_to_back_loop": 50,
+                                            "while_sampled": max(0, n - 370), "beside_clock_probe": 50}
     for kname, regs in REGS.items():
         if "kernel" in out and kname.replace("sxfir::", "") in out["kernel"].replace("void ", "").replace("sxfir::", ""):
             out["code_object"] = dict(regs, name=kname)
@@ -188,6 +191,19 @@ for cfg in configs:
         lines = [l for l in open(b) if l.startswith("{")]
         if lines:
             out["bench"] = json.loads(lines[-1])
+    # The figures a reader needs to recompute the roofline fraction from this file alone: the rocprofv3 durations of this
+    # call (all launches / the timed phase) against the algorithmic bytes and the 8 TB/s peak, beside the UN-profiled
+    # bench line of the same call on the same box (bench.roofline.frac), and which box that was.
+    if "avg_ns" in out:
+        out["frac_rocprof_all_launches"] = algorithmic / (out["avg_ns"] * 1e-9) / 8e12
+    if out.get("avg_ns_by_phase"):
+        out["frac_rocprof_timed"] = algorithmic / (out["avg_ns_by_phase"]["timed"] * 1e-9) / 8e12
+    if "bench" in out:
+        out["frac_bench_line_same_call"] = out["bench"]["roofline"]["frac"]
+        out["box"] = {"gpus": out["bench"]["config"].get("gpus"), "power_cap_w": out["bench"]["roofline"].get("power_cap_w")}
+    boxf = os.path.join(src, "box.txt")
+    if os.path.exists(boxf):
+        out.setdefault("box", {})["rocm_smi"] = [l.strip() for l in open(boxf) if "GPU[" in l][:6]
     json.dump(out, open(os.path.join(dst, "%s_%s_summary.json" % (name, cfg)), "w"), indent=1)
     print(cfg, json.dumps({k: out[k] for k in out if k not in ("bench", "pmc_mean_per_launch")})[:1500])
 json.dump(traffic, open(traffic_path, "w"), indent=1)
