@@ -336,7 +336,7 @@ def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc, base=0
     on the host from the seed).  Returns (ok, outputs compared)."""
     import numpy as np
     ratio, ntaps, decim = cfg["ratio"], cfg["ntaps"], cfg["mode"] == "decim"
-    h = orc.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
+    h = cfg["taps"] if cfg.get("taps") is not None else orc.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
     js, cw = plan.contract
     n_out = n_in // ratio if decim else n_in * ratio
     win = min(2048, n_out)
@@ -948,6 +948,9 @@ def main():
                          "C ABI (sxfir_comm_gather over librccl directly)")
     ap.add_argument("--alone-seconds", type=float, default=0.6,
                     help="N > 1: seconds each rank times its kernel alone (and then all together) for the in-job efficiency figure")
+    ap.add_argument("--asymmetric-taps", action="store_true",
+                    help="--config 2 with a non-symmetric 128-tap filter: times decim4_tile_kernel<128>, the kernel any other "
+                         "128-tap /4 plan runs (a row of its own, not the headline)")
     ap.add_argument("--settle", type=int, default=150,
                     help="untimed launches before the warm-up steps (clock settling)")
     args = ap.parse_args()
@@ -1025,6 +1028,17 @@ def main():
     assert hi - lo == nchan_local
 
     taps = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
+    if args.asymmetric_taps:
+        # any 128-tap /4 filter that is not bit-symmetric (a non-linear-phase design, an equaliser folded in) cannot
+        # share taps between an output's two halves: such a plan runs decim4_tile_kernel<128> (taps in VGPRs) instead of
+        # the headline kernel.  Here: the same low-pass with a 0.1 % slope across the taps.  Timed, verified against the
+        # oracle with the same taps, reported as its own row -- never the headline.
+        if args.config != "2":
+            raise SystemExit("--asymmetric-taps is a variation of --config 2")
+        taps = (taps.astype(np.float64) * (1.0 + 1e-3 * np.arange(ntaps) / ntaps)).astype(np.float32)
+        cfg = dict(cfg, taps=taps, kernel="sxfir::decim4_tile_kernel<128> (taps in VGPRs: any 128-tap /4 filter)",
+                   name=cfg["name"] + ", NON-symmetric taps")
+        workload = workload.replace("(BASELINE config 2)", "(BASELINE config 2's shape, NON-symmetric taps: not the headline)")
     plan = sxxcvr_amd.Resampler(DECIMATE if decim else INTERPOLATE, taps, ratio, nchan=nchan_local, fmt=cfg["fmt"],
                                 device=gpu_index)
     dt = torch.complex64 if cfg["fmt"] == "CF32" else torch.int32
@@ -1165,7 +1179,7 @@ def main():
         value = world * wide_per_gpu * args.steps / elapsed / 1e6
         traffic, traffic_source = None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and args.log2_samples == 28:
+        if os.path.exists(tp) and world == 1 and args.log2_samples == 28 and not args.asymmetric_taps:
             try:
                 tj = json.load(open(tp))
                 ent = tj.get("configs", {}).get(args.config)
@@ -1193,7 +1207,7 @@ def main():
             "verified": verified,
             "config": {
                 "workload": workload,
-                "bench_config": args.config,
+                "bench_config": args.config + ("-asymmetric-taps" if args.asymmetric_taps else ""),
                 "ntaps": ntaps, ("decim" if decim else "interp"): ratio, "format": cfg["fmt"],
                 "channels_per_gpu": nchan_local, "wideband_samples_per_gpu": wide_per_gpu,
                 "untimed_settle_launches": args.settle,

@@ -3,6 +3,9 @@
 <name>_<config>_kernel_stats.csv, <name>_<config>_summary.json and the per-config entry of traffic.json.
 
     python3 tools/summarize_profile.py <tag> <name> [config ...]
+
+PROFILE_SUFFIX=_b appends to the file names (<name>_<config>_b_summary.json: a second box of the same round) and leaves
+traffic.json alone.
 """
 import csv
 import glob
@@ -15,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
 configs = sys.argv[3:] or ["2"]
+SUFFIX = os.environ.get("PROFILE_SUFFIX", "")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNELS = {"2": "decim4_", "3rx": "decim_dense_kernel<8", "3tx": "interp8_pass_kernel", "5": "decim_dense_kernel<32",
@@ -118,7 +122,7 @@ for cfg in configs:
     stats = one("trace/**/*kernel_stats.csv")
     if stats:
         rows = list(csv.DictReader(open(stats)))
-        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (name, cfg)), "w") as f:
+        with open(os.path.join(dst, "%s_%s%s_kernel_stats.csv" % (name, cfg, SUFFIX)), "w") as f:
             w = csv.DictWriter(f, fieldnames=rows[0].keys())
             w.writeheader()
             w.writerows(rows)
@@ -204,6 +208,7 @@ for cfg in configs:
     boxf = os.path.join(src, "box.txt")
     if os.path.exists(boxf):
         out.setdefault("box", {})["rocm_smi"] = [l.strip() for l in open(boxf) if "GPU[" in l][:6]
-    json.dump(out, open(os.path.join(dst, "%s_%s_summary.json" % (name, cfg)), "w"), indent=1)
+    json.dump(out, open(os.path.join(dst, "%s_%s%s_summary.json" % (name, cfg, SUFFIX)), "w"), indent=1)
     print(cfg, json.dumps({k: out[k] for k in out if k not in ("bench", "pmc_mean_per_launch")})[:1500])
-json.dump(traffic, open(traffic_path, "w"), indent=1)
+if not SUFFIX:
+    json.dump(traffic, open(traffic_path, "w"), indent=1)
