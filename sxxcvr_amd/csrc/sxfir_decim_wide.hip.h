@@ -228,6 +228,7 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
         tk = t_now; \
     }
 
+    const int swz_w = (lane & 1) ^ ((lane >> 1) & 3), swz_r = ((lane >> 2) & 1) ^ ((lane >> 3) & 3);   // the output transposition's swizzles
     int ntile = 0;
     for (; tile < a.n_tiles; tile += G) {
         stage(tile);
@@ -260,15 +261,19 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
         const long long m0 = (long long)tile * C::TILE_OUT;
         if (m0 + C::TILE_OUT <= a.n_out) {
             // transposed through the dead image so that each store instruction writes 1 KiB of consecutive
-            // addresses: 256 output chunks (+ a pad slot after every 16), lane l then stores chunks l + 64k
+            // addresses: output chunk c (256 per tile) sits at slot c ^ ((c >> 2) & 1) ^ ((c >> 3) & 3) -- no pad slots.
+            // Lane l writes its chunks 4l + k at 4l + (k ^ tw), tw = (l & 1) ^ ((l >> 1) & 3): the 8 lanes a
+            // ds_write_b128 is served with hit 8 different slots mod 8; lane l then reads chunks l + 64k' at
+            // 64k' + (l ^ tr), tr = ((l >> 2) & 1) ^ ((l >> 3) & 3): the 16 lanes of a ds_read_b128 service group hit
+            // 16 different slots mod 16 (searched with tools/lds_bank_model.py's groups: 0 conflicts either way; the
+            // padded layout of rounds 2-4, c + (c >> 4), had 2-way write conflicts and one pair per read group).
             // (written and read by this wave only: LDS operations of one wave complete in order)
-            const int oc = 4 * lane;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) img[oc + k + ((oc + k) >> 4)] = y[k];
+            for (int k = 0; k < 4; ++k) img[4 * lane + (k ^ swz_w)] = y[k];
             f32x4 *dst = reinterpret_cast<f32x4 *>(out + 2 * m0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const f32x4 v = img[68 * k + lane + (lane >> 4)];
+                const f32x4 v = img[64 * k + (lane ^ swz_r)];
                 store16_policy<(POL >> 8)>(v, dst + 64 * k + lane);
             }
         } else {

@@ -92,6 +92,8 @@ for S in "$@"; do
     kb4w)     # waves per CU capped through LDS padding (8 per CU, 32 generations) against 16 per CU, with and without nt loads; whole kernel and memory side; then the same on an all-zero input
               V="t2.1.1088:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.1088:32:0:0:0:10600 t2.1.66624:32:0:0:0:10600 t2.1.66624:64:0:0:0:10600 t2.1.1088:16:0:1:0:0 t2.1.66624:16:0:1:0:0 t2.1.1088:32:0:1:0:10600 t2.1.66624:32:0:1:0:10600 t2.1.66624:64:0:1:0:0"
               KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    valu5)    # round 5: the CF16 /32 mixes only (today's conversions in every reading lane against one conversion on the way into a CF32 image)
+              hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe from 22 >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe from 22 >> $LOG 2>&1; RC=$?; grep "ms per launch" $LOG ;;
     valu)     hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe >> $LOG 2>&1; RC=$?; tail -22 $LOG ;;
     kb4x)     # one tile per wave (64 generations) with nt loads, taps by value, deferred stores, 12 waves per CU, pinned FMA order: whole kernel, then memory sides, then all-zero input
               V="x:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.66624:32:0:0:0:0 t2.1.66624:64:0:0:0:0 t2.1.67136:64:0:0:0:0 t2.1.67136:16:0:0:0:0 t2.1.66625:16:0:0:0:0 t2.1.66624:21:0:0:0:3840 t2.1.132160:16:0:0:0:0 t2.1.197696:16:0:0:0:0"

@@ -30,7 +30,9 @@ __device__ __forceinline__ void pks_hi(f2& acc, const f2& h, const f2& x) {
 // values are only kept alive, no extra VALU work)
 // DPPS = v_mov_b32_dpp per 512 packed FMAs (DPPK 0: wave_shl:1, 1: row_shl:1): what moving window samples between
 // neighbouring lanes' registers would cost instead of re-reading them from LDS
-template <int MODE, int READS = 0, int DPPS = 0, int DPPK = 0>
+// WRITES = ds_write_b128 per 512 packed FMAs on top (a multiple of 8); DPPK 7 = v_cvt_f32_f16 (every other one the SDWA
+// form that takes the high half): the CF16 kernels' conversions
+template <int MODE, int READS = 0, int DPPS = 0, int DPPK = 0, int WRITES = 0>
 __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, float* __restrict__ out, int tiles,
                                              unsigned long long* stamps) {
   __shared__ f4 lds[640 * 4];
@@ -82,8 +84,16 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ taps, flo
           else if (DPPK == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
           else if (DPPK == 4) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[q & 7]) : "v"(x[q & 3]));
           else if (DPPK == 5) { if ((q & 7) == 0) img[640 - 64 + lane] = (f4){d[0], d[1], d[2], d[3]}; }
+          else if (DPPK == 7) {
+            if (q & 1) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+            else asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]));
+          }
           else asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d[q & 7]) : "v"(d[(q + 3) & 7]), "v"(d[(q + 5) & 7]) : );
         }
+      }
+      if (WRITES > 0) {
+#pragma unroll
+        for (int q = 0; q < WRITES / 8; ++q) img[640 - 64 + lane - 64 * (q & 1)] = (f4){d[q & 7], d[(q + 1) & 7], d[(q + 2) & 7], d[(q + 3) & 7]};
       }
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
@@ -131,7 +141,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(taps, h, 512, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int tiles = 256;                   // per wave and launch: one launch = the FIR work of one bench step
-  const char* names[22] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
+  const char* names[26] = {"v_pk_fma_f32, taps in VGPR pairs", "v_pk_fma_f32, taps in SGPR pairs", "v_fmac_f32, SGPR tap",
                           "VGPR taps + 47 ds_read_b128 per tile (first-generation kernel's mix)", "SGPR taps + 47 ds_read_b128 per tile",
                           "SGPR taps + 71 ds_read_b128 per tile (shipped scalar kernel's mix)", "SGPR taps + 39 ds_read_b128 per tile",
                           "VGPR taps + 71 ds_read_b128 per tile",
@@ -146,9 +156,16 @@ int main(int argc, char** argv) {
                           "SGPR taps + 24 ds_read_b128 per 512 FMAs (16 outputs per lane at /4)",
                           "SGPR taps + 128 v_cvt_f32_i32 per 512 FMAs", "SGPR taps + 128 v_mov_b32 per 512 FMAs",
                           "SGPR taps + 128 v_pk_add_f32 per 512 FMAs", "SGPR taps + 16 ds_write_b128 per 512 FMAs",
-                          "SGPR taps + 128 v_cndmask_b32 per 512 FMAs"};
-  for (int rep = 0; rep < (only >= 0 ? 1 : 2); ++rep)
-    for (int mode = (only >= 0 ? only : 0); mode < (only >= 0 ? only + 1 : 22); ++mode) {
+                          "SGPR taps + 128 v_cndmask_b32 per 512 FMAs",
+                          "VGPR taps + 23 ds_read_b128 + 184 v_cvt_f32_f16 per 512 FMAs (CF16 /32 today: every reading lane converts)",
+                          "VGPR taps + 46 ds_read_b128 + 40 v_cvt_f32_f16 + 8 ds_write_b128 per 512 FMAs (CF16 converted once on the way into a CF32 image)",
+                          "VGPR taps + 46 ds_read_b128 + 40 v_cvt_f32_f16 + 16 ds_write_b128 per 512 FMAs (the same, upper bound of the staging writes: 10 needed)",
+                          "VGPR taps + 23 ds_read_b128 per 512 FMAs, no conversions (what the conversions cost today)"};
+  // valu_power_probe from <first>     the mixes from <first> on only (e.g. "from 22": round 5's CF16 rows)
+  const int first = (argc > 2 && argv[1][0] == 'f') ? atoi(argv[2]) : 0;
+  const int only_ = first ? -1 : only;
+  for (int rep = 0; rep < (only_ >= 0 ? 1 : 2); ++rep)
+    for (int mode = (only_ >= 0 ? only_ : first); mode < (only_ >= 0 ? only_ + 1 : 26); ++mode) {
       auto launch = [&] {
         switch (mode) {
           case 0: hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
@@ -172,11 +189,15 @@ int main(int argc, char** argv) {
           case 18: hipLaunchKernelGGL((probe<1, 0, 128, 3>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 19: hipLaunchKernelGGL((probe<1, 0, 128, 4>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
           case 20: hipLaunchKernelGGL((probe<1, 0, 128, 5>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
-          default: hipLaunchKernelGGL((probe<1, 0, 128, 6>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 21: hipLaunchKernelGGL((probe<1, 0, 128, 6>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 22: hipLaunchKernelGGL((probe<0, 23, 184, 7>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 23: hipLaunchKernelGGL((probe<0, 46, 40, 7, 8>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          case 24: hipLaunchKernelGGL((probe<0, 46, 40, 7, 16>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
+          default: hipLaunchKernelGGL((probe<0, 23>), dim3(blocks), dim3(256), 0, 0, taps, out, tiles, stamps); break;
         }
       };
       for (int i = 0; i < 300; ++i) launch();          // ~100 ms: let the clocks settle on this load
-      if (only >= 0) {                                 // keep the load up while the board is sampled
+      if (only_ >= 0) {                                // keep the load up while the board is sampled
         const int n = (int)(run_s / 1.2e-3);
         for (int i = 0; i < n; ++i) { launch(); if (i % 64 == 63) CK(hipStreamSynchronize(0)); }
       }
