@@ -1001,7 +1001,16 @@ def main():
     ident["rank"] = rank
     ctl, identities = None, [ident]
     if world > 1:
-        ctl = dist.group.WORLD if host_collectives else dist.new_group(backend="gloo")
+        ctl, ctl_name = dist.group.WORLD, backend_name
+        if not host_collectives:
+            try:
+                ctl = dist.new_group(backend="gloo")
+                dist.barrier(group=ctl)
+                ctl_name = "gloo"
+            except Exception as e:
+                # no host-side group on this node (gloo could not connect the ranks): the control traffic rides the data
+                # communicator instead -- waiting ranks then park RCCL's barrier kernel on their GPUs, which the line says
+                ctl, ctl_name = dist.group.WORLD, "nccl (no gloo group: %s: %s)" % (type(e).__name__, str(e)[:120])
         identities = [None] * world
         dist.all_gather_object(identities, ident, group=ctl)
         comm_ranks = dist.get_world_size()
@@ -1216,6 +1225,7 @@ def main():
                 "verified_outputs": cmp1 + cmp2,
                 "rccl_ranks": dist.get_world_size() if world > 1 else None,     # the communicator's own count
                 "backend": backend_name,
+                "control_group": ctl_name if world > 1 else None,
                 "gpus": [i.get("pci_bus_id") for i in identities],
                 "distinct_gpus": len({i.get("pci_bus_id") for i in identities}),
                 "gpu_name": ident.get("name"), "gpu_arch": ident.get("arch"),

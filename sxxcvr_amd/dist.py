@@ -111,21 +111,24 @@ def block_checksums(block):
 
 def exchange_checksums(local_sums, n_channels, group=None):
     """All-gather the ranks' [local_channels, 2] checksum tables into the [n_channels, 2] table of the whole job, in
-    global channel order (equal shards).  Host tensors in, host tensor out: 16 bytes per channel, over `group`
-    (bench.py hands its control group: gloo, so that the data-path communicator carries nothing but the data)."""
+    global channel order (equal shards); returns a host tensor.  16 bytes per channel.  bench.py hands its host-side
+    control group (gloo), so that the data-path communicator carries nothing but the data; over an nccl group (the
+    fallback when no gloo group could be made) the tables travel as device tensors."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if n_channels % world:
         raise ValueError("equal shards only (%d channels over %d ranks)" % (n_channels, world))
-    local = local_sums.detach().to("cpu", torch.int64).contiguous()
+    local = local_sums.detach().to(torch.int64).contiguous()
     if tuple(local.shape) != (n_channels // world, 2):
         raise ValueError("a rank states %s checksums, expected %s" % (tuple(local.shape), (n_channels // world, 2)))
     if dist.get_backend(group) == "nccl":
-        raise ValueError("exchange_checksums wants a host-side group (gloo)")
+        local = local.to(torch.device("cuda", torch.cuda.current_device()))
+    else:
+        local = local.cpu()
     parts = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(parts, local, group=group)
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).cpu()
 
 
 def check_gathered(full, stated, skip=()):

@@ -22,7 +22,7 @@ def check_multi_rank_fields(line, world, backend):
     assert c["rccl_ranks"] == world and c["backend"] == backend
     assert len(c["gpus"]) == world and all(isinstance(g, str) and g.count(":") == 2 for g in c["gpus"]), c["gpus"]
     assert c["distinct_gpus"] == (world if backend == "nccl" else len(set(c["gpus"])))
-    assert "HSA_ENABLE_IPC_MODE_LEGACY" in c["env"]
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" in c["env"] and c["control_group"] == "gloo"
     pr = line["per_rank"]
     assert [r["rank"] for r in pr] == list(range(world))
     for r in pr:
