@@ -52,11 +52,18 @@ const char *SoapySXHip_commit = "round1";
 namespace {
 
 struct sampleRateDiv {
-    uint16_t div;   // ratio of master clock to sample rate
+    uint16_t div;    // ratio of master clock to sample rate
+    uint8_t clkout;  // iism_clk_div, register 0x12 bits 3-0
+    uint8_t mant;    // int_dec_mantisse, register 0x13 bit 7
+    uint8_t m;       // int_dec_m_parameter, register 0x13 bit 6
+    uint8_t n;       // int_dec_n_parameter, register 0x13 bits 5-3
 };
 
-// The six SX1255 I2S rates the reference supports (SoapySX.cpp:196-208).
-const sampleRateDiv sample_rates[] = {{1536}, {768}, {512}, {256}, {128}, {64}};
+// The six SX1255 I2S rates the reference supports and the register fields it programs for each (SoapySX.cpp:179-208;
+// div = 8 * 3^m * 2^n).  tests/golden/rate_table.json holds the reference's own table; tests/test_gpu_device.py and
+// tests/test_host_logic.py compare.
+const sampleRateDiv sample_rates[] = {{1536, 6, 0, 1, 6}, {768, 4, 0, 1, 5}, {512, 3, 0, 0, 6},
+                                      {256, 2, 0, 0, 5},  {128, 1, 0, 0, 4}, {64, 0, 0, 0, 3}};
 const size_t N_SAMPLE_RATES = sizeof(sample_rates) / sizeof(sample_rates[0]);
 
 int pcm_error_to_soapy_rx(int err) { return err == -EPIPE ? SOAPY_SDR_OVERFLOW : SOAPY_SDR_STREAM_ERROR; }
@@ -431,11 +438,18 @@ public:
         std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex, reg_mutex);
         if (rate != rate || rate <= 0) throw std::runtime_error("Sample rate must be positive");
         const double divider = round(masterClock / rate);
-        bool found = false;
+        const sampleRateDiv *row = nullptr;
         for (size_t i = 0; i < N_SAMPLE_RATES; i++) {
-            if ((double)sample_rates[i].div == divider) { found = true; break; }
+            if ((double)sample_rates[i].div == divider) { row = &sample_rates[i]; break; }
         }
-        if (!found) throw std::runtime_error("Unsupported sample rate");
+        if (!row) throw std::runtime_error("Unsupported sample rate");
+        // the register shadow reads back what the reference would have programmed (:1192-1208): the I2S clock divider and
+        // the decimator's mantissa / m / n fields, RX and TX enabled again afterwards
+        chip.put({0x12, 0, 4}, row->clkout);
+        chip.put({0x13, 7, 1}, row->mant);
+        chip.put({0x13, 6, 1}, row->m);
+        chip.put({0x13, 3, 3}, row->n);
+        chip.put({0x00, 1, 2}, 3);
         sampleRate = masterClock / divider;
         clock.set_rate(sampleRate);
         // decim=auto / interp=auto: the converters run at master clock / 16 and the ratio follows the rate,

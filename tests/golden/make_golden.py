@@ -125,11 +125,11 @@ def conv_tx_numpy(x, thr2):
     return v.astype(np.int64)
 
 
-REF_LIB = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libsxref_convert.so")
+REF_LIB = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libsxref.so")
 
 
 def load_reference_converters():
-    """oracle/_ref/libsxref_convert.so: the reference's own convert_rx_buffer / convert_tx_buffer
+    """oracle/_ref/libsxref.so: the reference's own convert_rx_buffer / convert_tx_buffer
     (SoapySX/SoapySX.cpp:103-137), compiled from /root/reference by `make -C oracle ref` (container only; those
     two functions need three standard headers and nothing else).  None when the reference is not here."""
     import ctypes as C
@@ -144,6 +144,8 @@ def load_reference_converters():
     lib.sxref_convert_rx_buffer.argtypes = [vp, sz, vp, sz, sz]
     lib.sxref_convert_tx_buffer.argtypes = [vp, sz, vp, sz, sz, C.c_float]
     lib.sxref_provenance.restype = C.c_char_p
+    lib.sxref_provenance_table.restype = C.c_char_p
+    lib.sxref_sample_rate_row.argtypes = [C.c_int, C.POINTER(C.c_uint)]
     return lib
 
 
@@ -236,6 +238,31 @@ def make_conv():
 
 
 # --------------------------------------------------------------------------
+# sample-rate register table: the reference's own static data
+# --------------------------------------------------------------------------
+def make_rate_table():
+    """rate_table.json = struct sampleRateRegs sample_rates[N_SAMPLE_RATES] (SoapySX.cpp:179-208) as the reference's
+    compiled translation-unit fragment holds it: per supported rate the divider master clock / rate and the SX1255
+    register fields setSampleRate programs (:1197-1203: 0x12 bits 3-0 = clkout, 0x13 bit 7 = mant, bit 6 = m, bits 5-3 = n).
+    Checked here against the chip's own relation div = 8 * 3^m * 2^n."""
+    import ctypes as C
+    ref = load_reference_converters()
+    if ref is None:
+        print("rate_table.json kept as committed: /root/reference is not here")
+        return
+    rows = []
+    for i in range(ref.sxref_n_sample_rates()):
+        o = (C.c_uint * 5)()
+        ref.sxref_sample_rate_row(i, o)
+        div, clkout, mant, m, n = [int(v) for v in o]
+        assert div == 8 * 3 ** m * 2 ** n and mant == 0, (div, m, n)
+        rows.append({"div": div, "clkout": clkout, "mant": mant, "m": m, "n": n})
+    with open(os.path.join(HERE, "rate_table.json"), "w") as f:
+        json.dump({"rows": rows, "provenance": ref.sxref_provenance_table().decode() + "; via oracle/Makefile target ref"}, f, indent=0)
+    print("rate_table.json: %d rows from the reference's sample_rates[] (%s)" % (len(rows), ref.sxref_provenance_table().decode()))
+
+
+# --------------------------------------------------------------------------
 # stream rules: hand-evaluated traces of SoapySX.cpp:897-966 / :989-1104
 # --------------------------------------------------------------------------
 def make_stream():
@@ -295,5 +322,6 @@ if __name__ == "__main__":
     make_fir(t)
     make_time()
     make_conv()
+    make_rate_table()
     make_stream()
     print("golden fixtures written to", HERE)

@@ -360,6 +360,27 @@ static void scenario_calls(long ncalls)
     sxfir_host_free(pin);
 }
 
+// What setSampleRate leaves in the register shadow for every supported rate (SoapySX.cpp:1192-1208: 0x12 bits 3-0 = clkout,
+// 0x13 bit 7 = mant, bit 6 = m, bits 5-3 = n, RX and TX enabled again in 0x00): printed for the caller, which compares with
+// tests/golden/rate_table.json = the reference's own sample_rates[] table.
+static void scenario_rate_registers()
+{
+    for (double clock : {38.4e6, 32.0e6}) {
+        sx_device *d = sx_device_make(clock == 38.4e6 ? "driver=sx,clock=virtual" : "driver=sx,clock=virtual,master_clock=32e6");
+        expect(d != nullptr, "make");
+        double rates[16];
+        const int n = sx_device_list_sample_rates(d, SX_SOAPY_SDR_RX, 0, rates, 16);
+        for (int i = 0; i < n; ++i) {
+            expect(sx_device_set_sample_rate(d, SX_SOAPY_SDR_TX, 0, rates[i]) == 0, "set_sample_rate");
+            unsigned r0 = 0, r12[2] = {0, 0};
+            sx_device_read_registers(d, "", 0x00, &r0, 1);
+            sx_device_read_registers(d, "", 0x12, r12, 2);
+            std::printf("rate_regs %.0f %.17g %u %u %u\n", clock, rates[i], r12[0], r12[1], r0);
+        }
+        sx_device_unmake(d);
+    }
+}
+
 // usage: device_probe [calls [blocks [strict|lenient]]]   lenient (the sanitizer builds, which run several times slower
 // than the wall clock allows for): the RX thread may be skipped ahead by the overrun rule; the data checks stay
 int main(int argc, char **argv)
@@ -374,6 +395,7 @@ int main(int argc, char **argv)
         std::printf("# %s: %.1f s\n", what, std::chrono::duration<double>(t1 - t0).count());
         t0 = t1;
     };
+    scenario_rate_registers();
     scenario_threads("threads", 4096, nblk, false, lenient);
     lap("threads");
     scenario_threads("megabyte", (size_t)1 << 18, 6, true, true);

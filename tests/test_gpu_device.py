@@ -59,9 +59,15 @@ def test_sample_rate_table():
     dev32 = SoapySDR.Device({"driver": "sx", "clock": "virtual", "master_clock": "32e6"})
     assert dev32.listSampleRates(SoapySDR.SOAPY_SDR_TX, 0) == [32e6 / d for d in (1536, 768, 512, 256, 128, 64)]
     assert dev32.getSampleRate(SoapySDR.SOAPY_SDR_RX, 0) == 125000.0          # masterClock / 256, :662
+    import json
+    table = {row["div"]: row for row in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rate_table.json")))["rows"]}
     for r in rates:
         dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, r)
         assert dev.getSampleRate(SoapySDR.SOAPY_SDR_RX, 0) == r
+        # the register shadow holds what the reference programs for this rate (:1197-1203), per its own table
+        row = table[int(round(38.4e6 / r))]
+        r12, r13 = dev.readRegisters("", 0x12, 2)
+        assert r12 & 0x0F == row["clkout"] and (r13 >> 7) & 1 == row["mant"] and (r13 >> 6) & 1 == row["m"] and (r13 >> 3) & 7 == row["n"]
     dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 75010.0)                      # rounds to the nearest divider, :1179
     assert dev.getSampleRate(SoapySDR.SOAPY_SDR_TX, 0) == 75000.0
     for bad in (100000.0, 38.4e6 / 384, 1.0):

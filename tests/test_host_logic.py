@@ -217,6 +217,17 @@ def test_device_threads_over_fake_backend(sanitized, flavour):
     assert t and m and k and c, lines[-12:]
     f = c[0].split()
     assert int(f[3]) > 1000 and int(f[5]) > 1000 and int(f[7]) > 10 and f[f.index("bad") + 1] == "0"     # reads, writes, clock jumps
+    # the register shadow after setSampleRate against the REFERENCE'S OWN table (tests/golden/rate_table.json: sample_rates[],
+    # SoapySX.cpp:179-208, compiled from /root/reference by `make -C oracle ref`): 0x12 bits 3-0 = clkout, 0x13 = mant / m / n
+    import json
+    table = {r["div"]: r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "rate_table.json")))["rows"]}
+    regs = [l.split() for l in lines if l.startswith("rate_regs ")]
+    assert len(regs) == 2 * len(table) == 12
+    for _, clock, rate, r12, r13, r0 in regs:
+        row = table[int(round(float(clock) / float(rate)))]
+        assert int(r12) & 0x0F == row["clkout"], (clock, rate, r12)
+        assert (int(r13) >> 7) & 1 == row["mant"] and (int(r13) >> 6) & 1 == row["m"] and (int(r13) >> 3) & 7 == row["n"], (rate, r13)
+        assert (int(r0) >> 1) & 3 == 3                         # RX and TX enabled again, :1207
 
 
 @pytest.mark.parametrize("flavour", ["asan", "tsan"])
