@@ -144,7 +144,7 @@ def load_reference_converters():
     lib.sxref_convert_rx_buffer.argtypes = [vp, sz, vp, sz, sz]
     lib.sxref_convert_tx_buffer.argtypes = [vp, sz, vp, sz, sz, C.c_float]
     lib.sxref_provenance.restype = C.c_char_p
-    lib.sxref_provenance_table.restype = C.c_char_p
+    lib.sxref_init_register.restype = C.c_uint
     lib.sxref_sample_rate_row.argtypes = [C.c_int, C.POINTER(C.c_uint)]
     return lib
 
@@ -257,9 +257,14 @@ def make_rate_table():
         div, clkout, mant, m, n = [int(v) for v in o]
         assert div == 8 * 3 ** m * 2 ** n and mant == 0, (div, m, n)
         rows.append({"div": div, "clkout": clkout, "mant": mant, "m": m, "n": n})
+    # ... and the power-up register image init_registers[] (:139-176) the Device's register shadow starts from
+    init = [int(ref.sxref_init_register(i)) for i in range(ref.sxref_n_init_registers())]
+    assert len(init) == 0x14 and init[0x12] & 0x0F == 2 and (init[0x13] >> 3) & 7 == 5      # boots at div 256: the table's own row
     with open(os.path.join(HERE, "rate_table.json"), "w") as f:
-        json.dump({"rows": rows, "provenance": ref.sxref_provenance_table().decode() + "; via oracle/Makefile target ref"}, f, indent=0)
-    print("rate_table.json: %d rows from the reference's sample_rates[] (%s)" % (len(rows), ref.sxref_provenance_table().decode()))
+        json.dump({"rows": rows, "init_registers": init,
+                   "provenance": ref.sxref_provenance().decode() + "; via oracle/Makefile target ref"}, f, indent=0)
+    print("rate_table.json: %d rows of sample_rates[] and %d init_registers[] from the reference (%s)"
+          % (len(rows), len(init), ref.sxref_provenance().decode()))
 
 
 # --------------------------------------------------------------------------

@@ -80,6 +80,13 @@ def test_register_shadow_against_oracle(probe, oracle):
     # register image after power-up: RX, TX and PA driver enabled in reg 0, default tuning word 433.92 MHz
     boot = [int(v) for v in one(probe, "boot")]
     assert boot[0] == 0x0F and boot[0x11] == 3                      # status: both PLLs locked (SX.cpp:635-636)
+    # every other register of the power-up image is the REFERENCE'S OWN init_registers[] (SoapySX.cpp:139-176, compiled from
+    # /root/reference into tests/golden/rate_table.json by `make -C oracle ref`): tuning words, gains, filters, I2S dividers
+    import json
+    init = json.load(open(os.path.join(ROOT, "tests", "golden", "rate_table.json")))["init_registers"]
+    assert len(boot) == len(init) == 0x14
+    assert [boot[i] for i in range(1, 0x14) if i != 0x11] == [init[i] for i in range(1, 0x14) if i != 0x11]
+    assert boot[0] == init[0] | (7 << 1)                            # + RX, TX and PA driver enabled (:625)
     f, w = oracle.quantize_frequency(38.4e6, 433.92e6)
     assert (boot[1] << 16) | (boot[2] << 8) | boot[3] == w and (boot[4] << 16) | (boot[5] << 8) | boot[6] == w
     ant = one(probe, "antenna")
