@@ -18,6 +18,7 @@
  *    THE REFERENCE: these two functions are the only part of the reference's
  *    translation unit that compiles in this image (three standard headers),
  *    and `make -C oracle ref` compiles them as they lie under /root/reference
+ *    (with the chip tables that follow them, :139-208: one contiguous span)
  *    into oracle/_ref/libsxref.so.  tests/golden/convert_kat.npz is
  *    that library's output (make_golden.py), and test_oracle_golden.py runs
  *    the restatement against it on 2^20 fresh samples in the container.  Rows
