@@ -85,6 +85,9 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SXFIR_BENCH_CHILD="1")
+        # this pool's host driver supports dmabuf IPC only: with the legacy IPC mode RCCL's (and torch's) cross-process buffer
+        # sharing fails with "hipIpcGetMemHandle: invalid argument".  The image exports the variable already; set here for a
+        # caller whose environment lacks it, and recorded in the line (config.env) with the value the ranks really ran with
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc, deadline = 0, None
