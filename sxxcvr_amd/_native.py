@@ -41,9 +41,14 @@ def load_sxfir(profiling=False):
         return _sxfir
     path = os.path.join(LIBDIR, "libsxfir_prof.so" if profiling else "libsxfir.so")
     if profiling and os.environ.get("SXFIR_PROF_LIB"):
-        # tools only (tools/prev_lib.sh): a profiling library built from another commit, for before / after timings
-        # on the same box; the product library's path is never taken from the environment
-        path = os.environ["SXFIR_PROF_LIB"]
+        # tools only (tools/prev_lib.sh): the PROFILING library of another commit, built into sxxcvr_amd/lib/prev/, for
+        # before / after timings on the same box.  Only a library in that directory is accepted, and only by the profiling
+        # loader: the product library's path is never taken from the environment.
+        cand = os.path.realpath(os.environ["SXFIR_PROF_LIB"])
+        prev = os.path.realpath(os.path.join(LIBDIR, "prev"))
+        if os.path.dirname(cand) != prev:
+            raise ImportError("SXFIR_PROF_LIB must name a library under %s (tools/prev_lib.sh builds it there), got %s" % (prev, cand))
+        path = cand
     if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build the HIP extension first (python -m sxxcvr_amd.build). "
