@@ -5,6 +5,8 @@ printing.  A virtual sample clock (device arg clock=virtual) makes every run
 deterministic; sample data is checked bit for bit against the oracle and
 position / timestamp arithmetic against the oracle's restatement of
 SoapySX.cpp:897-1104."""
+import os
+
 import numpy as np
 import pytest
 
@@ -343,11 +345,15 @@ def test_wall_clock_mode():
 def test_control_surface_register_shadow(oracle):
     """SoapySX/test/test.py and test_gains.py as assertions: tuning word, gain split, antennas,
     raw register access on the SX1255 register shadow (SoapySX.cpp:1225-1561)."""
-    dev = make()
+    dev = SoapySDR.Device({"driver": "sx", "clock": "virtual"})         # as constructed: no setSampleRate yet
     RX, TX = SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_TX
-    # start-up state: init_registers + RX/TX enabled, both synthesizers at 433.92 MHz
+    # start-up state: init_registers + RX/TX enabled, both synthesizers at 433.92 MHz, I2S dividers for master clock / 256
     regs = dev.readRegisters("", 0, 0x14)
     assert regs[0] == 0x0F and regs[7] == 0x11 and regs[0x11] == 3 and regs[0x12:0x14] == [0x22, 0x2C]
+    # ... which setSampleRate reprograms (:1197-1203; 600 kS/s = divider 64: clkout 0, n 3), leaving the rest alone
+    dev.setSampleRate(RX, 0, RATE)
+    after = dev.readRegisters("", 0, 0x14)
+    assert after[0x12:0x14] == [0x20, 0x1C] and after[:0x12] == regs[:0x12]
     f0, w0 = oracle.quantize_frequency(38.4e6, 433.92e6)
     assert dev.getFrequency(RX, 0) == f0 == dev.getFrequency(TX, 0)
     assert (regs[1] << 16 | regs[2] << 8 | regs[3]) == w0
