@@ -350,10 +350,10 @@ def test_control_surface_register_shadow(oracle):
     # start-up state: init_registers + RX/TX enabled, both synthesizers at 433.92 MHz, I2S dividers for master clock / 256
     regs = dev.readRegisters("", 0, 0x14)
     assert regs[0] == 0x0F and regs[7] == 0x11 and regs[0x11] == 3 and regs[0x12:0x14] == [0x22, 0x2C]
-    # ... which setSampleRate reprograms (:1197-1203; 600 kS/s = divider 64: clkout 0, n 3), leaving the rest alone
+    # ... which setSampleRate reprograms (:1197-1203; 75 kS/s = divider 512: clkout 3, m 0, n 6), leaving the rest alone
     dev.setSampleRate(RX, 0, RATE)
     after = dev.readRegisters("", 0, 0x14)
-    assert after[0x12:0x14] == [0x20, 0x1C] and after[:0x12] == regs[:0x12]
+    assert after[0x12:0x14] == [0x23, 0x34] and after[:0x12] == regs[:0x12]
     f0, w0 = oracle.quantize_frequency(38.4e6, 433.92e6)
     assert dev.getFrequency(RX, 0) == f0 == dev.getFrequency(TX, 0)
     assert (regs[1] << 16 | regs[2] << 8 | regs[3]) == w0
