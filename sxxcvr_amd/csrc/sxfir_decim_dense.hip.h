@@ -62,6 +62,30 @@ struct DecimDense {
     static constexpr int dma_slot(int i) { return 64 * i + (i * RPI) / PADROWS; }
 };
 
+typedef int v4i32 __attribute__((ext_vector_type(4)));      // a buffer resource descriptor in four SGPRs
+
+__device__ __forceinline__ float half_lo_to_float(unsigned w) { return half_bits_to_float(w & 0xffffu); }
+__device__ __forceinline__ float half_hi_to_float(unsigned w) { return half_bits_to_float(w >> 16); }
+
+// two outputs (four floats) leave as 16 bytes of CF32 or, CF16 storage, as two half pairs rounded once (8 bytes)
+template <bool HALFOUT>
+__device__ __forceinline__ void store_pair(char *dst, float i0, float q0, float i1, float q1)
+{
+    if constexpr (HALFOUT) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store((u32x2){pack_half2(i0, q0), pack_half2(i1, q1)}, reinterpret_cast<u32x2 *>(dst));
+    } else {
+        __builtin_nontemporal_store((f32x4){i0, q0, i1, q1}, reinterpret_cast<f32x4 *>(dst));
+    }
+}
+
+template <bool HALFOUT>
+__device__ __forceinline__ void store_one(char *dst, float i0, float q0)
+{
+    if constexpr (HALFOUT) reinterpret_cast<unsigned *>(dst)[0] = pack_half2(i0, q0);
+    else reinterpret_cast<float2 *>(dst)[0] = make_float2(i0, q0);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v)
 {
@@ -101,11 +125,20 @@ __device__ __forceinline__ float butterfly_add(float v)
 // the next tile's halo -- are copied inside LDS to its first 31 instead of being fetched again: at /32 the halo is 31 rows of a
 // 159-row image, a fifth of everything that moves from L2 into LDS.  Each wave copies exactly the chunks its own DMA instructions
 // (32 + ww + 4k) are about to overwrite -- read, then its DMAs, then the writes: program order inside the wave, no barrier added.
-template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0, bool SUBSET = false, bool HC = false>
+// HALFIN (round 5): CF16 storage (IQ as IEEE half pairs in HBM, fp32 arithmetic, outputs rounded to half once; BASELINE config 5's
+// fp16 leg).  The image in LDS is the SAME CF32 image: the texture path converts on the way in.  gfx950's LDS-DMA exists for
+// one typed load, buffer_load_format_x; with a buffer descriptor of format {16, FLOAT} it fetches one half per lane and writes
+// one float per lane, so one instruction turns 128 consecutive source bytes (32 samples) into 16 slots of the image -- no
+// v_cvt_f32_f16 (184 per 512 FMAs in decim_multi_kernel<.., CF16>, 13.6 % of its FIR phase), no ds_write, and the FIR below is the
+// CF32 kernel's, conversion-free.  Bit for bit the conversion v_cvt_f32_f16 makes for every finite half, zero, subnormal and
+// infinity (tools/typed_dma_probe.hip; a NaN stays a NaN with another payload).  Four typed instructions replace one 1-KiB DMA.
+template <int D, int ABL = 0, bool S32IN = false, int NTLD = 0, bool SUBSET = false, bool HC = false, bool HALFIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 decim_dense_kernel(const DecimMultiArgs a)
 {
     using C = DecimDense<D>;
+    constexpr int SB = HALFIN ? 4 : 8;                  // bytes per complex sample in HBM
+    static_assert(!HALFIN || (!S32IN && !SUBSET && !HC && ABL == 0), "CF16 storage: the plain VGPR-tap form");
     static_assert(!(HC && SUBSET), "halo carry: the VGPR-tap forms");
     static_assert(!SUBSET || (D == 8 && (ABL == 0 || (ABL == 1 && !S32IN))), "subset form: /8 (CF32 or S32 wire words: the table then holds the taps times 2^-31)");
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
@@ -121,8 +154,8 @@ decim_dense_kernel(const DecimMultiArgs a)
     if constexpr (SUBSET) G = (int)((rgrp_table((lane & 31) >> 3) >> (5 * (lane & 7))) & 31u) + (lane & 32);
     const int ch = blockIdx.y;
 
-    const char *in = reinterpret_cast<const char *>(a.in) + 8LL * a.in_stride * ch;
-    char *out = reinterpret_cast<char *>(a.out) + 8LL * a.out_stride * ch;
+    const char *in = reinterpret_cast<const char *>(a.in) + (long long)SB * a.in_stride * ch;
+    char *out = reinterpret_cast<char *>(a.out) + (long long)SB * a.out_stride * ch;
 
     // lane taps: h[kl], kl = 4*jj + rr  <->  tap D*(16*p + jj) + 4c + rr
     f32x2 hp[SUBSET ? 1 : 32];
@@ -173,11 +206,12 @@ decim_dense_kernel(const DecimMultiArgs a)
     const int tile_step = HC ? 1 : NG;
     // fused history carry-over (as decim_multi_kernel): the tail of (hist ++ in) becomes the next history
     if ((HC ? (first_tile <= a.n_tiles - 1 && a.n_tiles - 1 < end_tile) : first_tile == (a.n_tiles - 1) % NG) && ww == C::W - 1) {
-        char *ho = reinterpret_cast<char *>(a.hist_out) + 8LL * a.hist_stride * ch;
+        char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)SB * a.hist_stride * ch;
         for (int j = lane; j < C::NT; j += 64) {
             const long long s = a.n_in - C::NT + j;
-            const char *src = s >= 0 ? in + 8 * s : reinterpret_cast<const char *>(a.hist) + 8LL * a.hist_stride * ch + 8 * (s + C::NT);
-            reinterpret_cast<float2 *>(ho)[j] = *reinterpret_cast<const float2 *>(src);
+            const char *src = s >= 0 ? in + SB * s : reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch + SB * (s + C::NT);
+            if constexpr (HALFIN) reinterpret_cast<unsigned *>(ho)[j] = *reinterpret_cast<const unsigned *>(src);
+            else reinterpret_cast<float2 *>(ho)[j] = *reinterpret_cast<const float2 *>(src);
         }
     }
 
@@ -208,12 +242,47 @@ decim_dense_kernel(const DecimMultiArgs a)
     constexpr int HALO_INSTR = 31 / C::RPI;                              // DMA instructions that hold halo rows only
     constexpr int CARRY_SHIFT = 64 * 32 + C::TILE_OUT / C::PADROWS;      // slots between a halo row's two places
     static_assert(C::TILE_OUT % C::PADROWS == 0, "the pads before a row and before the row TILE_OUT above it differ by a constant");
+    // (HALFIN) LDS byte address of the wave's first staging slot, a scalar: M0 of the typed DMA = this + a constant
+    const unsigned lds_wave_base = HALFIN ? __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + (64 + PER_I) * ww)) : 0u;
     auto stage = [&](int tile, bool carry, bool last_of_run) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         const long long s_first = D * (M0 - 31) - (D - 1);               // first sample of the image
         const bool interior = tile >= 1 && tile <= tile_hi;
-        const char *base = in + 8 * s_first + 1024 * ww;
+        const char *base = in + SB * s_first + (128 * SB) * ww;
         if constexpr (ABL == 2) return;
+        if constexpr (HALFIN) {
+            if (interior) {
+                // Typed LDS-DMA: the wave's old instruction i = ww + 4 i0 (64 slots = 128 samples) becomes four
+                // buffer_load_format_x ... lds of 16 slots each: lane l fetches the half at byte 2 l of 128 consecutive source
+                // bytes and the texture path writes its float to LDS address M0 + 4 l.  The descriptor is based at the wave's
+                // first byte of THIS tile (64-bit base, rebuilt per tile from scalars), so every offset is a small constant
+                // and a call may be as long as it likes; {DATA_FORMAT 16, NUM_FORMAT FLOAT, X <- R}.
+                const unsigned long long wb = (unsigned long long)base;
+                v4i32 rs;
+                rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+                rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(wb >> 32)) & 0xffff;    // stride 0
+                rs.z = 1 << 20;                                                               // bytes addressable from the base: a tile's share and more
+                rs.w = 4 | (7 << 12) | (2 << 15);
+                unsigned voff = 2u * (unsigned)lane;
+                asm volatile("" : "+v"(voff));
+#pragma unroll
+                for (int i0 = 0; i0 < C::NIW; ++i0) {
+                    const int i = ww + 4 * i0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // slots of the image this instruction fills: 16, or fewer / none in the image's last instruction
+                        const int valid = i < C::NI - 1 ? 16 : (C::LAST_LANES - 16 * j < 0 ? 0 : (C::LAST_LANES - 16 * j > 16 ? 16 : C::LAST_LANES - 16 * j));
+                        if (i0 < C::NIW - 1 || i < C::NI - 1 || (i == C::NI - 1 && lane < 4 * valid)) {
+                            const unsigned soff = 2048u * i0 + 128u * j;                      // bytes from the wave's base
+                            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base + 16u * (unsigned)(C::dma_slot(4 * i0) + 16 * j));
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen lds"
+                                         :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                        }
+                    }
+                }
+                return;
+            }
+        }
         if (interior) {
             f32x4 hv[C::NIW - 8];
             if constexpr (HC) {
@@ -269,7 +338,7 @@ decim_dense_kernel(const DecimMultiArgs a)
             // from the kernel arguments here, not kept in registers across the tile loop.
             const auto *ap = rare_args();
             const long long last = ap->n_in - 1;
-            const char *hist = reinterpret_cast<const char *>(ap->hist) + 8LL * ap->hist_stride * ch;
+            const char *hist = reinterpret_cast<const char *>(ap->hist) + (long long)SB * ap->hist_stride * ch;
 #pragma nounroll
             for (int i0 = 0; i0 < C::NIW; ++i0) {
                 const int i = ww + 4 * i0;
@@ -278,10 +347,17 @@ decim_dense_kernel(const DecimMultiArgs a)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const long long s = s_first + 2 * (64 * i + lane) + e;
-                        const char *src = s >= 0 ? in + 8 * (s <= last ? s : last)
-                                                 : hist + 8 * (s + C::NT >= 0 ? s + C::NT : 0);
-                        wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
-                        wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
+                        const char *src = s >= 0 ? in + SB * (s <= last ? s : last)
+                                                 : hist + SB * (s + C::NT >= 0 ? s + C::NT : 0);
+                        if constexpr (HALFIN) {
+                            // (v_cvt_f32_f16: what the typed DMA of the interior tiles does, for every non-NaN half)
+                            const unsigned w = reinterpret_cast<const unsigned *>(src)[0];
+                            wds[2 * e] = __float_as_uint(half_lo_to_float(w));
+                            wds[2 * e + 1] = __float_as_uint(half_hi_to_float(w));
+                        } else {
+                            wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
+                            wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
+                        }
                     }
                     lds[64 * i + (i * C::RPI) / C::PADROWS + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]),
                                                                             __uint_as_float(wds[2]), __uint_as_float(wds[3])};
@@ -402,13 +478,13 @@ decim_dense_kernel(const DecimMultiArgs a)
             }
             const long long m = mg + 2 * b5;
             if (b3 == 0) {
-                char *dst = out + 8 * m;
+                char *dst = out + SB * m;
                 if (tile < n_full) {
-                    __builtin_nontemporal_store((f32x4){si[0], sq[0], si[1], sq[1]}, reinterpret_cast<f32x4 *>(dst));
+                    store_pair<HALFIN>(dst, si[0], sq[0], si[1], sq[1]);
                 } else {
                     const long long n_out = rare_args()->n_out;
-                    if (m + 2 <= n_out) __builtin_nontemporal_store((f32x4){si[0], sq[0], si[1], sq[1]}, reinterpret_cast<f32x4 *>(dst));
-                    else if (m < n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(si[0], sq[0]);
+                    if (m + 2 <= n_out) store_pair<HALFIN>(dst, si[0], sq[0], si[1], sq[1]);
+                    else if (m < n_out) store_one<HALFIN>(dst, si[0], sq[0]);
                 }
             }
         } else {
@@ -438,13 +514,13 @@ decim_dense_kernel(const DecimMultiArgs a)
             if (writer) {
                 const float s0 = sel ? ri[2] : ri[0], s1 = sel ? rq[2] : rq[0];
                 const float s2 = sel ? ri[3] : ri[1], s3 = sel ? rq[3] : rq[1];
-                char *dst = out + 8 * m;
+                char *dst = out + SB * m;
                 if (tile < n_full) {
-                    __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
+                    store_pair<HALFIN>(dst, s0, s1, s2, s3);
                 } else {
                     const long long n_out = rare_args()->n_out;
-                    if (m + 2 <= n_out) __builtin_nontemporal_store((f32x4){s0, s1, s2, s3}, reinterpret_cast<f32x4 *>(dst));
-                    else if (m < n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(s0, s1);
+                    if (m + 2 <= n_out) store_pair<HALFIN>(dst, s0, s1, s2, s3);
+                    else if (m < n_out) store_one<HALFIN>(dst, s0, s1);
                 }
             }
         }

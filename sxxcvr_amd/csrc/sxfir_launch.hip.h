@@ -83,7 +83,10 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 return SXFIR_OK;
             }
 #endif
-            if (p->dense_subset) {
+            if (p->fmt == SXFIR_CF16) {
+                // CF16 storage at /32: the typed LDS-DMA front end (round 5)
+                hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
+            } else if (p->dense_subset) {
                 if (int rc = need_tap_table(p, TAPS_SUBSET8, "decim_dense_kernel<8, SUBSET>")) return rc;
                 a.taps = p->taps_scaled_dev;                      // the subset-major tap table
                 if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, true, 2, true>), grid, dim3(256), 0, st, a);

@@ -92,6 +92,10 @@ for S in "$@"; do
     kb4w)     # waves per CU capped through LDS padding (8 per CU, 32 generations) against 16 per CU, with and without nt loads; whole kernel and memory side; then the same on an all-zero input
               V="t2.1.1088:16:0:0:0:0 t2.1.66624:16:0:0:0:0 t2.1.1088:32:0:0:0:10600 t2.1.66624:32:0:0:0:10600 t2.1.66624:64:0:0:0:10600 t2.1.1088:16:0:1:0:0 t2.1.66624:16:0:1:0:0 t2.1.1088:32:0:1:0:10600 t2.1.66624:32:0:1:0:10600 t2.1.66624:64:0:1:0:0"
               KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; RC=$?; KB_ZERO=1 KB_D=4 KB_ROUNDS=7 timeout 900 python3 tools/kbench.py $V >> $LOG 2>&1; grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped" ;;
+    kb32h5)   # round 5: CF16 /32, the dense kernel with the typed LDS-DMA front end (x) against the multi-column kernel (w4), long interleaved visits, random and zero input
+              KB_D=32 KB_FMT=CF16 KB_ROUNDS=5 KB_ITERS=200 KB_SETTLE=100 timeout 900 python3 tools/kbench.py x:8:0:0:0 w4:8:0:0:0 >> $LOG 2>&1; RC=$?
+              KB_ZERO=1 KB_D=32 KB_FMT=CF16 KB_ROUNDS=3 KB_ITERS=200 KB_SETTLE=100 timeout 600 python3 tools/kbench.py x:8:0:0:0 w4:8:0:0:0 >> $LOG 2>&1
+              grep -v "amdgpu.ids" $LOG | grep "ms med\|all-zero\|skipped\|DIFFERENT\|rror" ;;
     valu5)    # round 5: the CF16 /32 mixes only (today's conversions in every reading lane against one conversion on the way into a CF32 image)
               hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe from 22 >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe from 22 >> $LOG 2>&1; RC=$?; grep "ms per launch" $LOG ;;
     valu)     hipcc --offload-arch=gfx950 -O3 -w tools/valu_power_probe.hip -o /tmp/valu_power_probe >> $LOG 2>&1 && timeout 300 /tmp/valu_power_probe >> $LOG 2>&1; RC=$?; tail -22 $LOG ;;
