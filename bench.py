@@ -60,7 +60,7 @@ CONFIGS = {
               kernel="sxfir::decim_dense_kernel<32>",
               name="1024-tap decim-by-32, 1 ch CF32 streaming (BASELINE config 5, CF32 leg)"),
     "5h": dict(mode="decim", ntaps=1024, ratio=32, fmt="CF16", bytes=4 + 4 / 32, flop=128, gain=1.0,
-               kernel="sxfir::decim_multi_kernel<32, 4, CF16>",
+               kernel="sxfir::decim_dense_kernel<32, CF16 storage: typed LDS-DMA converts half -> float on the way into the image>",
                name="1024-tap decim-by-32, 1 ch CF16 storage, fp32 arithmetic (BASELINE config 5, fp16 IQ leg)"),
 }
 
@@ -1276,7 +1276,8 @@ def main():
         if args.config == "5h":
             line["roofline"]["note"] = ("CF16 storage halves the bytes but not the 128 flop per sample: this leg is "
                                         "bound by fp32 VALU throughput at the clock the power management allows; "
-                                        "see roofline.valu")
+                                        "see roofline.valu.  Since round 5 the half -> float conversion is made by the texture "
+                                        "path on the way into LDS (buffer_load_format_x ... lds), not by the VALU")
         if per_rank is not None:
             # in-job efficiency: every rank's kernel alone (the others idle) against all ranks at once
             ratios = sorted(r["alone_ms"] / r["together_ms"] for r in per_rank)

@@ -84,8 +84,10 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             }
 #endif
             if (p->fmt == SXFIR_CF16) {
-                // CF16 storage at /32: the typed LDS-DMA front end (round 5)
-                hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
+                // CF16 storage: the typed LDS-DMA front end (round 5)
+                if (p->ratio == 8) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
+                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
             } else if (p->dense_subset) {
                 if (int rc = need_tap_table(p, TAPS_SUBSET8, "decim_dense_kernel<8, SUBSET>")) return rc;
                 a.taps = p->taps_scaled_dev;                      // the subset-major tap table

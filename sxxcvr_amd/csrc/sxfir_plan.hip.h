@@ -208,7 +208,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the multi-column kernel
     // ... and, since round 5, CF16 storage at /32 (BASELINE config 5's fp16 leg): the dense kernel with the typed LDS-DMA front end
     // (HALFIN: the texture path converts half -> float on the way into the same CF32 image; no conversions in the FIR)
-    p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32) && (fmt != SXFIR_CF16 || ratio == 32);
+    p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32);
     // /8 CF32: the scalar-tap form of the dense kernel (tap subsets on the four waves, round 4: 4.4-5 % less time)
     p->dense_hc = false;
     p->dense_subset = p->dense32 && ratio == 8 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32);
@@ -283,7 +283,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         const void *k = nullptr;
         if (p->dense32 && fmt == SXFIR_CF16) {
-            k = (const void *)sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>;
+            k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 0, false, false, true>
+                : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 0, false, false, true>
+                              : (const void *)sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>;
         } else if (p->dense32) {
             const bool w = fmt == SXFIR_S32;
             k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, 2, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true>)

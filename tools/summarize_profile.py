@@ -22,7 +22,7 @@ SUFFIX = os.environ.get("PROFILE_SUFFIX", "")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERNELS = {"2": "decim4_", "3rx": "decim_dense_kernel<8", "3tx": "interp8_pass_kernel", "5": "decim_dense_kernel<32",
-           "5h": "decim_multi_kernel<32"}
+           "5h": "decim_dense_kernel<32, 0, false, 0, false, false, true"}
 BYTES = {"2": 10.0, "3rx": 9.0, "3tx": 9.0, "5": 8.25, "5h": 4.125}
 
 
