@@ -138,6 +138,16 @@ def test_shipped_code_object():
             # scalar registers spilled into VGPR lanes: a handful around the tile loop at most (the first scalar-tap /8
             # build had 202 of them inside it)
             assert r["sgpr_spill_lane_ops"] <= 40, r
+    # CF16 storage at /8, /16, /32 (round 5): the dense kernel's HALFIN instances stage through typed LDS-DMA -- four per 1-KiB instruction of the CF32 form, 36-40 per wave and
+    # staging call, two calls in the code (first tile, next tile) -- and convert nothing in the FIR: the only v_cvt_f32_f16 left are
+    # the eight of the edge tiles' register path; the multi-column CF16 kernels (184 conversions per 512 FMAs) ship for /4 only
+    half = [r for r in rows if r["name"].startswith("decim_dense_kernel<") and r["name"].rstrip(">").endswith("true")]
+    assert sorted(r["name"].split("<")[1].split(",")[0] for r in half) == ["16", "32", "8"], [r["name"] for r in half]
+    for r in half:
+        per_wave = 10 if r["name"].startswith("decim_dense_kernel<32") else 9          # 1-KiB instructions of the CF32 form per wave and tile
+        assert r["typed_lds_dma"] == 2 * 4 * per_wave and r["v_cvt_f32_f16"] <= 8 and r["global_load_lds_dwordx4"] == 0, r
+    mh = [r for r in rows if r["name"].startswith("decim_multi_kernel<")]
+    assert [r["name"] for r in mh] == ["decim_multi_kernel<4, 1, true, 0, 2, false>"], [r["name"] for r in mh]
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<2, ")]
     assert len(ip) == 4, ip                                 # with / without the keying count, CF32 / wire-word output
     for r in ip:

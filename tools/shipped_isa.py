@@ -63,7 +63,9 @@ def kernels(lib=None):
                   "global_load_lds_dwordx4_nt": len(re.findall(r"global_load_lds_dwordx4[^\n]*\bnt\b", body)),
                   "s_barrier": cnt(r"s_barrier$"), "v_mfma": cnt(r"v_mfma"), "dpp_or_permlane": len(re.findall(r"_dpp|v_permlane", body)),
                   "s_load_dwordx16": cnt(r"s_load_dwordx16$"), "instructions": len(ops),
-                  "valu": cnt(r"v_"), "sgpr_spill_lane_ops": cnt(r"v_(read|write)lane_b32$")})
+                  "valu": cnt(r"v_"), "sgpr_spill_lane_ops": cnt(r"v_(read|write)lane_b32$"),
+                  # CF16 storage: typed LDS-DMA (the texture path converts on the way in) against conversions by the VALU
+                  "typed_lds_dma": len(re.findall(r"buffer_load_format_x [^\n]*\blds\b", body)), "v_cvt_f32_f16": cnt(r"v_cvt_f32_f16")})
         fm = re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], (s\[\d+:\d+\]), (v\[\d+:\d+\])", body)
         if len(fm) > 1:
             r["scalar_tap_fmas"] = len(fm)

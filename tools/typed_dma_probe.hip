@@ -112,6 +112,23 @@ __global__ __launch_bounds__(256) void stage(const uint32_t *__restrict__ in, fl
     sums[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// Second question (the S32_LE wire words of row f-3): does a {32, SSCALED} descriptor turn an int32 into (float)int32 on the way in?
+// One wave, 64 words per instruction, formats tried: SSCALED (3), SINT (5: expected to pass the bits through), FLOAT (7).
+__global__ void stage_s32(const int *__restrict__ in, unsigned *__restrict__ out, int nfmt)
+{
+    __shared__ unsigned img[64];
+    const int lane = threadIdx.x;
+    v4i rs = make_rsrc(in, 256, 0);
+    rs.w = 4 | (nfmt << 12) | (4 << 15);                                      // DATA_FORMAT 32
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)img);
+    const unsigned voff = 4u * (unsigned)lane;
+    img[lane] = 0xdeadbeefu;
+    __syncthreads();
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, 0 offen lds\n\ts_waitcnt vmcnt(0)" :: "s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+    __syncthreads();
+    out[lane] = img[lane];
+}
+
 static float half_to_float(uint16_t h)
 {
     const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31, m = h & 1023;
@@ -194,6 +211,31 @@ int main()
         printf("%-90s %.4f ms per %.3f G samples = %.0f GB/s of CF16 source (%.2f x 2^28 samples per 0.5 ms)\n", names[mode], ms, samples / 1e9,
                samples * 4.0 / (ms * 1e-3) / 1e9, (samples / (double)(1 << 28)) * 0.5 / ms);
         fflush(stdout);
+    }
+    // ---- 32-bit integer formats
+    {
+        int hw[64];
+        for (int i = 0; i < 64; ++i) hw[i] = (int)(0x9e3779b9u * (unsigned)(i + 1));
+        hw[0] = 0; hw[1] = 1; hw[2] = -1; hw[3] = 0x7fffffff; hw[4] = (int)0x80000000; hw[5] = 0x7fffff80; hw[6] = 0x7fffffbf; hw[7] = 0x7fffffc0; hw[8] = 16777217; hw[9] = -16777217;
+        int *din; unsigned *dout;
+        CK(hipMalloc(&din, 256)); CK(hipMalloc(&dout, 256));
+        CK(hipMemcpy(din, hw, 256, hipMemcpyHostToDevice));
+        const int fmts[3] = {3, 5, 7};
+        const char *fn[3] = {"SSCALED", "SINT", "FLOAT"};
+        for (int f = 0; f < 3; ++f) {
+            hipLaunchKernelGGL(stage_s32, dim3(1), dim3(64), 0, 0, din, dout, fmts[f]);
+            unsigned got[64];
+            CK(hipMemcpy(got, dout, 256, hipMemcpyDeviceToHost));
+            int as_float = 0, raw = 0;
+            for (int i = 0; i < 64; ++i) {
+                const float want = (float)hw[i];
+                unsigned wb; memcpy(&wb, &want, 4);
+                as_float += got[i] == wb;
+                raw += got[i] == (unsigned)hw[i];
+            }
+            printf("buffer_load_format_x lds, {32, %s}: %d of 64 words equal (float)int32, %d of 64 equal the raw word; word[1]=0x%08x word[3]=0x%08x word[6]=0x%08x\n",
+                   fn[f], as_float, raw, got[1], got[3], got[6]);
+        }
     }
     return 0;
 }
