@@ -184,18 +184,23 @@ int main()
             std::vector<float> got((size_t)TILE_SAMPLES * 2);
             CK(hipMemcpy(got.data(), dump, got.size() * 4, hipMemcpyDeviceToHost));
             long bad = 0, nan_payload = 0, first = -1;
+            unsigned nan_half = 0, nan_got = 0, nan_want = 0;
             for (int i = 0; i < TILE_SAMPLES * 2; ++i) {
                 const uint16_t hv = (uint16_t)(h[i / 2] >> (16 * (i & 1)));
                 const float want = half_to_float(hv);
                 uint32_t gb, wb;
                 memcpy(&gb, &got[i], 4); memcpy(&wb, &want, 4);
                 if (gb != wb) {
-                    if (want != want && got[i] != got[i]) ++nan_payload;       // both NaN, payload or quiet bit differs
+                    if (want != want && got[i] != got[i]) {                    // both NaN, payload or quiet bit differs
+                        if (!nan_payload) { nan_half = hv; nan_got = gb; nan_want = wb; }
+                        ++nan_payload;
+                    }
                     else { ++bad; if (first < 0) first = i; }
                 }
             }
             printf("%-90s tile 0: %ld of %d floats differ from half->float (NaN payload differences: %ld)%s\n", names[mode], bad,
                    TILE_SAMPLES * 2, nan_payload, bad ? " <-- NOT the converted values" : "");
+            if (nan_payload) printf("   a NaN: half 0x%04x -> 0x%08x (v_cvt_f32_f16 / this host: 0x%08x)\n", nan_half, nan_got, nan_want);
             if (bad) {
                 const int i = (int)first;
                 uint32_t gb; memcpy(&gb, &got[i], 4);
