@@ -128,6 +128,69 @@ def test_cf16_storage_path(oracle, golden_dir):
     assert np.array_equal(to_cpu(s16).view(np.uint16), oracle.f32_to_f16(x[:4096].view(np.float32)))
 
 
+@pytest.mark.parametrize("D,nchan,skew", [(32, 1, 0), (32, 3, 1), (16, 1, 3), (16, 2, 0), (8, 1, 1), (8, 3, 2)])
+def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
+    """decim_dense_kernel<D, HALFIN> (round 5: CF16 storage at /8, /16, /32 through typed LDS-DMA -- the texture path converts
+    half -> float on the way into the CF32 image) at its seams, with asymmetric random taps: calls of two outputs, of one tile
+    minus / plus two, of many tiles plus a tail, several channels with a stride that is not the block length, an input view that
+    starts `skew` samples into its buffer (the typed loads want 2-byte alignment only, the descriptor base a sample's), history
+    carried from call to call in CF16.  Bit-exact against the oracle on the half-rounded input, output rounded to half once.
+    Infinities travel like v_cvt_f32_f16's; a NaN half arrives as a NaN (the interior tiles' texture path hands over the canonical
+    quiet NaN, the edge tiles' v_cvt_f32_f16 keeps the payload: outputs the NaN reaches are NaN either way, the others exact)."""
+    import torch
+    from sxxcvr_amd.resampler import KERNEL_TILED
+    h = (np.random.default_rng(100 + D).standard_normal(32 * D) / 64.0).astype(np.float32)
+    T = 4096 // D
+    outs = (2, T - 2, T, T + 2, 2, 40 * T + 78, T * 3, 30, 2 * T)
+    if nchan > 1:                                       # CF16: the tiled kernels take an output stride that is a multiple of 4 samples
+        outs = (4, T - 4, T, T + 4, 4, 40 * T + 76, T * 3, 28, 2 * T)
+    blocks = [D * m for m in outs]
+    total = sum(blocks)
+    xs = []
+    for c in range(nchan):
+        x = oracle.synth_iq(SEED, 90 + c, 0, total)
+        xs.append(oracle.f16_to_f32(oracle.f32_to_f16(x.view(np.float32))).view(np.complex64))
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D, nchan=nchan, fmt="CF16")
+    assert plan.contract == (2, 4)
+    plan.set_kernel(KERNEL_TILED)
+    got = [[] for _ in range(nchan)]
+    pos = 0
+    for n in blocks:
+        buf = np.zeros((nchan, n + skew + 5), dtype=np.uint32)
+        for c in range(nchan):
+            buf[c, skew:skew + n] = oracle.f32_to_f16(xs[c][pos:pos + n].view(np.float32)).view(np.uint32)
+        xg = to_gpu(buf.view(np.int32))
+        y = plan.process(xg[:, skew:skew + n] if nchan > 1 else xg[0, skew:skew + n])
+        torch.cuda.synchronize()
+        y = to_cpu(y).reshape(nchan, -1)
+        for c in range(nchan):
+            got[c].append(y[c])
+        pos += n
+    for c in range(nchan):
+        want = oracle.f32_to_f16(oracle.decim_f32(h, D, xs[c], 2, 4).view(np.float32))
+        assert np.array_equal(np.concatenate(got[c]).view(np.uint16), want), "CF16 dense /%d, channel %d of %d" % (D, c, nchan)
+    # infinities and NaNs, one channel, one call of many tiles: +inf, -inf and a NaN deep inside interior tiles and in the first
+    # (edge) tile
+    if nchan == 1:
+        n = D * (20 * T)
+        x = xs[0][:n].copy()
+        xb = oracle.f32_to_f16(x.view(np.float32)).copy()
+        marks = {D * (7 * T) + 11: 0x7C00, D * (9 * T) + 5: 0xFC00, D * (13 * T) + 2: 0x7E01, 3: 0xFFFF}      # I component of those samples
+        for smp, bits in marks.items():
+            xb[2 * smp] = bits
+        plan2 = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
+        plan2.set_kernel(KERNEL_TILED)
+        y = to_cpu(plan2.process(to_gpu(xb.view(np.uint32).view(np.int32)))).view(np.uint16)
+        xq = oracle.f16_to_f32(xb).view(np.complex64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, 2, 4).view(np.float32))
+        gf, wf = oracle.f16_to_f32(y), oracle.f16_to_f32(want)
+        assert np.array_equal(np.isnan(gf), np.isnan(wf))                      # the same outputs are NaN (NaN, and inf - inf) ...
+        ok = ~np.isnan(wf)
+        assert np.array_equal(y[ok], want[ok])                                  # ... and every other output has the oracle's bits
+        assert np.isnan(wf).any() and np.isinf(wf[ok]).any()
+
+
 @pytest.mark.parametrize("L,n_in", [(8, 1), (8, 64), (8, 64 * 50 + 7), (8, 1 << 16), (4, 1 << 15), (4, 129), (16, 5000),
                                     (32, 3333)])
 def test_tiled_interpolator_bit_exact(oracle, L, n_in):
