@@ -68,6 +68,9 @@ enum {
 enum { SXFIR_DECIMATE = 0, SXFIR_INTERPOLATE = 1 };
 
 /* IQ storage format in HBM.  Arithmetic is always fp32.
+ * SXFIR_CF16: IEEE half pairs (4 bytes per sample) in and out; every input half is widened to float exactly (a NaN half is a NaN
+ * float; which NaN is unspecified: the tiled decimators let the texture path widen on the way into LDS, which hands over the
+ * canonical quiet NaN), the outputs are rounded to half once, to nearest even.
  * SXFIR_S32 is the reference's on-wire format (S32_LE I2S words, I then Q, 8 bytes per sample) fused
  * into the resampling kernels: a DECIMATE plan reads S32 words (value = 2^-31 * word, convert_rx_buffer,
  * SX.cpp:103-112) and writes CF32; an INTERPOLATE plan reads CF32 and writes S32 words with the
