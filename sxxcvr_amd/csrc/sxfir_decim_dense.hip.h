@@ -138,7 +138,7 @@ decim_dense_kernel(const DecimMultiArgs a)
 {
     using C = DecimDense<D>;
     constexpr int SB = HALFIN ? 4 : 8;                  // bytes per complex sample in HBM
-    static_assert(!HALFIN || (!S32IN && !SUBSET && !HC && ABL == 0), "CF16 storage: the plain VGPR-tap form");
+    static_assert(!HALFIN || (!S32IN && !HC && ABL == 0), "CF16 storage: the shipped forms (VGPR taps; /8: scalar-tap subsets)");
     static_assert(!(HC && SUBSET), "halo carry: the VGPR-tap forms");
     static_assert(!SUBSET || (D == 8 && (ABL == 0 || (ABL == 1 && !S32IN))), "subset form: /8 (CF32 or S32 wire words: the table then holds the taps times 2^-31)");
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
@@ -442,13 +442,13 @@ decim_dense_kernel(const DecimMultiArgs a)
             // store still covers one kilobyte of consecutive bytes
             const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
             const long long m = M0 + 8 * Gq + 2 * kq;
-            char *dst = out + 8 * m;
+            char *dst = out + SB * m;
             if (tile < n_full) {
-                __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(dst));
+                store_pair<HALFIN>(dst, y.x, y.y, y.z, y.w);
             } else {
                 const long long n_out = rare_args()->n_out;     // the call's last tile
-                if (m + 2 <= n_out) __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(dst));
-                else if (m < n_out) reinterpret_cast<float2 *>(dst)[0] = make_float2(y.x, y.y);
+                if (m + 2 <= n_out) store_pair<HALFIN>(dst, y.x, y.y, y.z, y.w);
+                else if (m < n_out) store_one<HALFIN>(dst, y.x, y.y);
             }
             continue;
         }

@@ -211,7 +211,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32);
     // /8 CF32: the scalar-tap form of the dense kernel (tap subsets on the four waves, round 4: 4.4-5 % less time)
     p->dense_hc = false;
-    p->dense_subset = p->dense32 && ratio == 8 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32);
+    p->dense_subset = p->dense32 && ratio == 8;      // (CF16 storage too, round 5: the typed-DMA front end under the same scalar-tap FIR)
     p->t2_wpg = p->t2_opt = 0;
     p->dense_nt = 0;
     p->dense_nt_set = 0;
@@ -283,7 +283,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         const void *k = nullptr;
         if (p->dense32 && fmt == SXFIR_CF16) {
-            k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 0, false, false, true>
+            k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 0, true, false, true>
                 : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 0, false, false, true>
                               : (const void *)sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>;
         } else if (p->dense32) {
