@@ -275,8 +275,14 @@ decim_dense_kernel(const DecimMultiArgs a)
                         if (i0 < C::NIW - 1 || i < C::NI - 1 || (i == C::NI - 1 && lane < 4 * valid)) {
                             const unsigned soff = 2048u * i0 + 128u * j;                      // bytes from the wave's base
                             const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base + 16u * (unsigned)(C::dma_slot(4 * i0) + 16 * j));
-                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen lds"
-                                         :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                            // NTLD = 2 as in the CF32 form: rows no other tile reads stream through the L2 (nt), both halos stay plain
+                            constexpr int FIRST_NT_H = (31 / C::RPI + 4) / 4;
+                            if (NTLD == 2 && i0 >= FIRST_NT_H && i0 < 8)
+                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen nt lds"
+                                             :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                            else
+                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen lds"
+                                             :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
                         }
                     }
                 }

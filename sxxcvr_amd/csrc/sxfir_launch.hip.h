@@ -88,15 +88,15 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 if (p->ratio == 8 && p->dense_subset) {
                     if (int rc = need_tap_table(p, TAPS_SUBSET8, "decim_dense_kernel<8, SUBSET, HALFIN>")) return rc;
                     a.taps = p->taps_scaled_dev;                  // the subset-major tap table
-                    hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 0, true, false, true>), grid, dim3(256), 0, st, a);
+                    hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>), grid, dim3(256), 0, st, a);
                 }
 #ifdef SXFIR_PROFILING
                 else if (p->ratio == 8) hipLaunchKernelGGL((sxfir::decim_dense_kernel<8, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);   // VGPR taps: the A/B partner
 #else
                 else if (p->ratio == 8) return fail(SXFIR_EUNSUPPORTED, "internal: /8 CF16 without its subset table");
 #endif
-                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>), grid, dim3(256), 0, st, a);
+                else if (p->ratio == 16) hipLaunchKernelGGL((sxfir::decim_dense_kernel<16, 0, false, 2, false, false, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_dense_kernel<32, 0, false, 2, false, false, true>), grid, dim3(256), 0, st, a);
             } else if (p->dense_subset) {
                 if (int rc = need_tap_table(p, TAPS_SUBSET8, "decim_dense_kernel<8, SUBSET>")) return rc;
                 a.taps = p->taps_scaled_dev;                      // the subset-major tap table

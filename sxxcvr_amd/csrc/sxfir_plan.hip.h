@@ -283,9 +283,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         int nb = 0;
         const void *k = nullptr;
         if (p->dense32 && fmt == SXFIR_CF16) {
-            k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 0, true, false, true>
-                : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 0, false, false, true>
-                              : (const void *)sxfir::decim_dense_kernel<32, 0, false, 0, false, false, true>;
+            k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>
+                : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 2, false, false, true>
+                              : (const void *)sxfir::decim_dense_kernel<32, 0, false, 2, false, false, true>;
         } else if (p->dense32) {
             const bool w = fmt == SXFIR_S32;
             k = ratio == 8    ? (w ? (const void *)sxfir::decim_dense_kernel<8, 0, true, 2, true> : (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true>)
