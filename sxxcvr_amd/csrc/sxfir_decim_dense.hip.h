@@ -275,6 +275,8 @@ decim_dense_kernel(const DecimMultiArgs a)
                         if (i0 < C::NIW - 1 || i < C::NI - 1 || (i == C::NI - 1 && lane < 4 * valid)) {
                             const unsigned soff = 2048u * i0 + 128u * j;                      // bytes from the wave's base
                             const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base + 16u * (unsigned)(C::dma_slot(4 * i0) + 16 * j));
+                            // (M0 is a reserved register to the compiler -- it sets it right before each of its own uses and keeps nothing
+                            // in it across an asm statement -- so writing it here needs, and admits, no clobber entry)
                             // NTLD = 2 as in the CF32 form: rows no other tile reads stream through the L2 (nt), both halos stay plain
                             constexpr int FIRST_NT_H = (31 / C::RPI + 4) / 4;
                             if (NTLD == 2 && i0 >= FIRST_NT_H && i0 < 8)
