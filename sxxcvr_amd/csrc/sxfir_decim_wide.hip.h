@@ -31,6 +31,7 @@
 
 #include "sxfir_decim_tile.hip.h"
 #include "sxfir_decim_tile2.hip.h"
+#include "sxfir_decim_dense.hip.h"      // v4i32, half_lo_to_float / half_hi_to_float, pack_half2 (the CF16 front end)
 
 namespace sxfir {
 
@@ -127,10 +128,18 @@ __device__ __forceinline__ void store16_policy(f32x4 v, f32x4 *dst)
     else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
 }
 
-template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false, int POL = 0>
+// HALFIN (round 5): CF16 storage (IQ as IEEE half pairs in HBM; fp32 arithmetic; outputs rounded to half once).  The image in LDS
+// is the same CF32 image: typed LDS-DMA (buffer_load_format_x ... lds with a {16, FLOAT} descriptor, sxfir_decim_dense.hip.h) lets the
+// texture path convert on the way in -- instruction j turns source bytes [128 j, 128 j + 128) = chunks [16 j, 16 j + 16) into the
+// slots [17 j, 17 j + 16): the image's pad slot after every 16 chunks falls between instructions.  68 typed instructions per tile
+// instead of 19 one-kilobyte DMAs; the FIR below does not know the difference.
+template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false, int POL = 0, bool HALFIN = false>
 __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
 {
     using C = DecimWide;
+    static_assert(!HALFIN || (!S32IN && ABL == 0 && !PIN && POL == 0), "CF16 storage: the shipped form only");
+    static_assert(C::CHUNKS % 16 == 0, "whole 16-chunk rows");
+    constexpr int SB = HALFIN ? 4 : 8;                    // bytes per complex sample in HBM
     __shared__ __attribute__((aligned(16))) f32x4 img[C::SLOTS];
 
     unsigned long long wave_c0 = 0, wave_r0 = 0;
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
     }
     const int lane = threadIdx.x;
     const int ch = blockIdx.y;
-    const float *in = a.in + 2 * a.in_stride * ch;
-    const float *hist = a.hist + 2 * a.hist_stride * ch;
-    float *out = a.out + 2 * a.out_stride * ch;
+    const float *in = a.in + (SB / 4) * a.in_stride * ch;
+    const float *hist = a.hist + (SB / 4) * a.hist_stride * ch;
+    float *out = a.out + (SB / 4) * a.out_stride * ch;
     const long long last_chunk = (a.n_in - 1) >> 1;
     const int n_odd = (int)(a.n_in & 1);
 
@@ -163,13 +172,62 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
         for (int m = 0; m < 32; ++m) hs[m] = tq[m];
     }
 
-    unsigned boff[C::NI];
+    unsigned boff[HALFIN ? 1 : C::NI];
+    if constexpr (!HALFIN) {
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j) boff[j] = slot_source_offset(64u * j + lane, C::CHUNKS);
+        for (int j = 0; j < C::NI; ++j) boff[j] = slot_source_offset(64u * j + lane, C::CHUNKS);
+    }
+    const unsigned img_base = HALFIN ? __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)img) : 0u;   // M0 of the typed DMA = this + a constant
 
     auto stage = [&](int t) __attribute__((always_inline)) {
         const long long c0 = ((long long)t * C::TILE_IN - C::HALO) >> 1;
         const bool interior = (c0 >= 0) && (c0 + C::CHUNKS - 1 <= last_chunk - n_odd);
+        if constexpr (HALFIN) {
+            if (interior) {
+                // descriptor based at the tile's first byte (64-bit base from scalars, small constant offsets): {16, FLOAT, X <- R}
+                const unsigned long long tb = (unsigned long long)(reinterpret_cast<const char *>(in) + 8 * c0);
+                v4i32 rs;
+                rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)tb);
+                rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(tb >> 32)) & 0xffff;
+                rs.z = 1 << 20;
+                rs.w = 4 | (7 << 12) | (2 << 15);
+                unsigned voff = 2u * (unsigned)lane;
+                asm volatile("" : "+v"(voff));
+#pragma unroll
+                for (int j = 0; j < C::CHUNKS / 16; ++j) {
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane(img_base + 16u * 17u * (unsigned)j);
+                    const unsigned soff = 128u * (unsigned)j;
+                    // rows 8..59 of the 68 belong to this tile alone (nt); the first 8 re-read the previous tile's last kilobyte,
+                    // the last 8 are the next tile's halo: plain, as instructions 0, 17, 18 of the CF32 form
+                    if (NTL && j >= 8 && j < C::CHUNKS / 16 - 8)
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen nt lds"
+                                     :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                    else
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen lds"
+                                     :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                }
+            } else {
+                // edge tiles: chunk by chunk through registers (v_cvt_f32_f16: what the typed DMA does for every non-NaN half)
+#pragma nounroll
+                for (int j = 0; j < C::NI; ++j) {
+                    if (j < C::NI - 1 || lane < C::LASTL) {
+                        long long cc = c0 + (slot_source_offset(64u * j + lane, C::CHUNKS) >> 4);
+                        const unsigned *src;
+                        bool one = false;
+                        if (cc < 0) {
+                            src = reinterpret_cast<const unsigned *>(hist) + 2 * (cc + C::HIST / 2);
+                        } else {
+                            if (cc > last_chunk) cc = last_chunk;
+                            src = reinterpret_cast<const unsigned *>(in) + 2 * cc;
+                            one = n_odd && cc == last_chunk;          // the chunk's second sample lies beyond the caller's buffer
+                        }
+                        const unsigned w0 = src[0], w1 = one ? 0u : src[1];
+                        img[64 * j + lane] = (f32x4){half_lo_to_float(w0), half_hi_to_float(w0), half_lo_to_float(w1), half_hi_to_float(w1)};
+                    }
+                }
+            }
+            return;
+        }
         if (interior) {
             const char *src = reinterpret_cast<const char *>(reinterpret_cast<const f32x4 *>(in) + c0);
 #pragma unroll
@@ -208,11 +266,15 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
     };
 
     if (b == a.hist_wave) {
-        float *ho = a.hist_out + 2 * a.hist_stride * ch;
+        float *ho = a.hist_out + (SB / 4) * a.hist_stride * ch;
         for (int j = lane; j < C::HIST; j += 64) {
             const long long s = a.n_in - C::HIST + j;
-            const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
-            reinterpret_cast<float2 *>(ho)[j] = v;
+            if constexpr (HALFIN) {
+                reinterpret_cast<unsigned *>(ho)[j] = s >= 0 ? reinterpret_cast<const unsigned *>(in)[s] : reinterpret_cast<const unsigned *>(hist)[s + C::HIST];
+            } else {
+                const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
+                reinterpret_cast<float2 *>(ho)[j] = v;
+            }
         }
     }
 
@@ -270,20 +332,40 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
             // (written and read by this wave only: LDS operations of one wave complete in order)
 #pragma unroll
             for (int k = 0; k < 4; ++k) img[4 * lane + (k ^ swz_w)] = y[k];
-            f32x4 *dst = reinterpret_cast<f32x4 *>(out + 2 * m0);
+            if constexpr (HALFIN) {
+                // two outputs per lane and store: 8 bytes of half pairs, 512 consecutive bytes per instruction
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 *dst = reinterpret_cast<u32x2 *>(out + m0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 v = img[64 * k + (lane ^ swz_r)];
-                store16_policy<(POL >> 8)>(v, dst + 64 * k + lane);
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v = img[64 * k + (lane ^ swz_r)];
+                    __builtin_nontemporal_store((u32x2){pack_half2(v.x, v.y), pack_half2(v.z, v.w)}, dst + 64 * k + lane);
+                }
+            } else {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(out + 2 * m0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v = img[64 * k + (lane ^ swz_r)];
+                    store16_policy<(POL >> 8)>(v, dst + 64 * k + lane);
+                }
             }
         } else {
             // ragged last tile of the call: element by element, straight from the registers
             const long long m = m0 + 8 * lane;
-            float *dst = out + 2 * m;
+            if constexpr (HALFIN) {
+                unsigned *dst = reinterpret_cast<unsigned *>(out + m);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (m + 2 * k < a.n_out) { dst[4 * k] = y[k].x; dst[4 * k + 1] = y[k].y; }
-                if (m + 2 * k + 1 < a.n_out) { dst[4 * k + 2] = y[k].z; dst[4 * k + 3] = y[k].w; }
+                for (int k = 0; k < 4; ++k) {
+                    if (m + 2 * k < a.n_out) dst[2 * k] = pack_half2(y[k].x, y[k].y);
+                    if (m + 2 * k + 1 < a.n_out) dst[2 * k + 1] = pack_half2(y[k].z, y[k].w);
+                }
+            } else {
+                float *dst = out + 2 * m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (m + 2 * k < a.n_out) { dst[4 * k] = y[k].x; dst[4 * k + 1] = y[k].y; }
+                    if (m + 2 * k + 1 < a.n_out) { dst[4 * k + 2] = y[k].z; dst[4 * k + 3] = y[k].w; }
+                }
             }
         }
         // the next tile's DMA overwrites the image only after these LDS reads have returned

@@ -168,8 +168,11 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_tiles = (int)n_tiles;
         a.sched = p->sched;
         a.stamps = nullptr;
+        if (p->fmt == SXFIR_CF16 && !(p->wide8 && p->sched != 1))
+            return fail(SXFIR_EUNSUPPORTED, "CF16 storage at /4 runs the wide kernel only (a profiling knob asked for another /4 variant)");
 #ifdef SXFIR_PROFILING
-        if (const int pr = prof_launch_tile_variant(p, a, n_out, n_tiles, st)) return pr < 0 ? pr : SXFIR_OK;   // pair / wide / tile2 variants
+        if (p->fmt != SXFIR_CF16)
+            if (const int pr = prof_launch_tile_variant(p, a, n_out, n_tiles, st)) return pr < 0 ? pr : SXFIR_OK;   // pair / wide / tile2 variants
 #endif
         if (p->wide8 && p->sched != 1) {
             // 128 symmetric taps: decim4_wide_kernel, tiles of 512 outputs, one wave (= one workgroup) per tile and pass;
@@ -188,6 +191,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             }
             dim3 grid((unsigned)G, (unsigned)p->nchan);
             if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
+            else if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>), grid, dim3(64), 0, st, a);
             else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
             HIPCHECK(hipGetLastError());
             return SXFIR_OK;

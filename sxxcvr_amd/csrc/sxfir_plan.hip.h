@@ -157,10 +157,13 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
+        // CF16 storage at /4 with 128 symmetric taps: the wide kernel with the typed-DMA front end (round 5); any other CF16 /4
+        // filter of 128 taps keeps the multi-column kernel
+        const bool half4_wide = fmt == SXFIR_CF16 && ratio == 4 && ntaps == 128 && p->symmetric;
         p->tile_capable = ((fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64)) ||
-                           (fmt == SXFIR_S32 && ratio == 4 && ntaps == 128));
+                           (fmt == SXFIR_S32 && ratio == 4 && ntaps == 128) || half4_wide);
         // multi-column kernel: 32 taps per phase; CF32 at ratio 8/16/32, CF16 at ratio 4/8/16/32
-        p->multi_capable = (ntaps == 32 * ratio) &&
+        p->multi_capable = (ntaps == 32 * ratio) && !half4_wide &&
                            (((fmt == SXFIR_CF32 || fmt == SXFIR_S32) && (ratio == 8 || ratio == 16 || ratio == 32)) ||
                             (fmt == SXFIR_CF16 && (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32)));
         // Numeric contract: two row halves and column groups of 4 when the shape allows the
@@ -326,7 +329,9 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             // the shipped form for 128 symmetric taps: eight outputs per lane (sxfir_decim_wide.hip.h); 18.5 KB of LDS
             // per wave -> 8 waves per CU
             p->wide8 = true;
-            const void *kw = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_wide_kernel<0, true> : (const void *)sxfir::decim4_wide_kernel<0, false>;
+            const void *kw = fmt == SXFIR_S32    ? (const void *)sxfir::decim4_wide_kernel<0, true>
+                             : fmt == SXFIR_CF16 ? (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>
+                                                 : (const void *)sxfir::decim4_wide_kernel<0, false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
         }
 #ifdef SXFIR_PROFILING

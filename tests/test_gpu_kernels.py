@@ -128,7 +128,7 @@ def test_cf16_storage_path(oracle, golden_dir):
     assert np.array_equal(to_cpu(s16).view(np.uint16), oracle.f32_to_f16(x[:4096].view(np.float32)))
 
 
-@pytest.mark.parametrize("D,nchan,skew", [(32, 1, 0), (32, 3, 1), (16, 1, 3), (16, 2, 0), (8, 1, 1), (8, 3, 2)])
+@pytest.mark.parametrize("D,nchan,skew", [(32, 1, 0), (32, 3, 1), (16, 1, 3), (16, 2, 0), (8, 1, 1), (8, 3, 2), (4, 1, 1), (4, 3, 0)])
 def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
     """decim_dense_kernel<D, HALFIN> (round 5: CF16 storage at /8, /16, /32 through typed LDS-DMA -- the texture path converts
     half -> float on the way into the CF32 image) at its seams, with asymmetric random taps: calls of two outputs, of one tile
@@ -140,7 +140,10 @@ def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
     import torch
     from sxxcvr_amd.resampler import KERNEL_TILED
     h = (np.random.default_rng(100 + D).standard_normal(32 * D) / 64.0).astype(np.float32)
-    T = 4096 // D
+    if D == 4:
+        # /4: decim4_wide_kernel<..., HALFIN> (8 outputs per lane, scalar taps) takes bit-symmetric taps; 512-output tiles
+        h[64:] = h[:64][::-1]
+    T = 4096 // D if D != 4 else 512
     outs = (2, T - 2, T, T + 2, 2, 40 * T + 78, T * 3, 30, 2 * T)
     if nchan > 1:                                       # CF16: the tiled kernels take an output stride that is a multiple of 4 samples
         outs = (4, T - 4, T, T + 4, 4, 40 * T + 76, T * 3, 28, 2 * T)
