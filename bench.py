@@ -1142,6 +1142,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own kernel time over the same K timed steps (HIP events on its stream): the roofline fraction per GPU
+        timed = [None] * world
+        dist.all_gather_object(timed, float(kernel_ms), group=ctl)
+        for r, ms in zip(per_rank, timed):
+            r["timed_kernel_ms"] = round(ms, 6)
+            r["timed_frac"] = round(cfg["bytes"] * wide_per_gpu / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     # the last step's output against the oracle (steady-state streaming: the block entered with its own tail
     # as history, unless it was the very first block of the stream)
@@ -1287,6 +1293,10 @@ def main():
                 for k in ("alone_ms", "together_ms"):
                     r[k] = round(r[k], 6)
             line["per_rank"] = per_rank
+            fr = sorted(r["timed_frac"] for r in per_rank)
+            line["roofline"]["frac_per_gpu"] = {"min": fr[0], "median": fr[len(fr) // 2], "max": fr[-1],
+                                                "how": "every rank's own HIP-event time over the K timed steps (per_rank[].timed_kernel_ms); "
+                                                       "roofline.frac is rank 0's"}
             line["efficiency_kernel_only"] = round(mean_alone / mean_tog, 4)
             line["efficiency_per_rank"] = {"min": round(ratios[0], 4), "median": round(ratios[len(ratios) // 2], 4),
                                            "max": round(ratios[-1], 4),

@@ -29,10 +29,13 @@ def check_multi_rank_fields(line, world, backend):
         assert r["alone_ms"] > 0 and r["together_ms"] > 0 and r["gpu"] == c["gpus"][r["rank"]]
         assert r["alone_launches"] >= 50 and r["together_launches"] >= 50
         assert "power_w_alone" in r and "power_w_together" in r
+        assert r["timed_kernel_ms"] > 0 and 0 < r["timed_frac"] < 1
     mean = lambda k: sum(r[k] for r in pr) / world
     assert abs(line["efficiency_kernel_only"] - mean("alone_ms") / mean("together_ms")) < 5e-3 * line["efficiency_kernel_only"]
     e = line["efficiency_per_rank"]
     assert 0 < e["min"] <= e["median"] <= e["max"]
+    f = line["roofline"]["frac_per_gpu"]
+    assert 0 < f["min"] <= f["median"] <= f["max"] < 1 and f["min"] == min(r["timed_frac"] for r in pr)
     g = line["gather"]
     assert "error" not in g, g
     assert g["rccl_ranks"] == world
