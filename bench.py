@@ -1106,7 +1106,7 @@ def main():
         dist.barrier(group=ctl)
         mine["together_ms"], w_tog, mine["together_launches"] = timed_for(args.alone_seconds)
         dist.barrier(group=ctl)
-        sampler._stop.set()
+        sampler.stop()                                   # (the windows below read what it recorded)
         for key, win in (("alone", w_alone), ("together", w_tog)):
             st = sampler.window(*win)
             mine["power_w_" + key] = st["power_w"] if st else None
