@@ -56,9 +56,13 @@ struct DecimWide {
 // PIN: the packed FMAs as volatile asm, i.e. issued in source order -- all (up to sixteen) FMAs of a sample pair back to
 // back; left to the machine scheduler only 0.28 of adjacent FMAs share their sample pair in the CF32 build
 // FIRST0: a chain's first FMA takes +0 as an inline constant instead of a cleared accumulator register
-template <bool S32IN, int CIDX, int NB, bool PIN = false, bool FIRST0 = true>
+// ASYM (round 5): taps that are NOT bit-symmetric.  128 distinct taps do not fit the scalar registers (64 pairs = 128 SGPRs), so the
+// P1 chain's taps 127..64 take the 32 SGPR pairs (hs[m] = {h[64 + 2m], h[64 + 2m + 1]}) and the P0 chain's taps 63..0 sit in 32 VGPR
+// pairs (hv[m] = {h[2m], h[2m + 1]}): half the FMAs keep the cheaper scalar operand, the window is still read once (79 chunks) and the
+// tile, the staging and the stores are the symmetric form's.  Same chains, same order: the contract's bits.
+template <bool S32IN, int CIDX, int NB, bool PIN = false, bool FIRST0 = true, bool ASYM = false>
 __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB], const f32x2 (&hs)[32], f32x2 (&a1)[8],
-                                              f32x2 (&a0)[8])
+                                              f32x2 (&a0)[8], const f32x2 (&hv)[ASYM ? 32 : 1])
 {
     // the chunk was read NB steps ago (software pipeline: two waves per SIMD do not hide an LDS round trip by
     // themselves); its register is refilled with the chunk NB steps ahead as soon as it has been consumed
@@ -77,11 +81,18 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
             for (int i = 0; i < 8; ++i) {
                 const int kl = 4 * i + 64 - w1;
                 if (kl >= 0 && kl < 64) {
-                    const int j = 63 - kl;               // h[64 + kl] == h[63 - kl]
-                    if constexpr (PIN) { if (j & 1) pk_fma_sv_hi(a1[i], hs[j >> 1], x); else pk_fma_sv_lo(a1[i], hs[j >> 1], x); }
-                    else if (FIRST0 && kl == 63) pk_fma_s_lo_first(a1[i], hs[j >> 1], x);       // the chain's first tap (j = 0): from +0
-                    else if (j & 1) pk_fma_s_hi(a1[i], hs[j >> 1], x);
-                    else pk_fma_s_lo(a1[i], hs[j >> 1], x);
+                    if constexpr (ASYM) {
+                        // tap 64 + kl itself: hs holds h[64..127]
+                        if (FIRST0 && kl == 63) pk_fma_s_hi_first(a1[i], hs[kl >> 1], x);      // the chain's first tap (127): from +0
+                        else if (kl & 1) pk_fma_s_hi(a1[i], hs[kl >> 1], x);
+                        else pk_fma_s_lo(a1[i], hs[kl >> 1], x);
+                    } else {
+                        const int j = 63 - kl;               // h[64 + kl] == h[63 - kl]
+                        if constexpr (PIN) { if (j & 1) pk_fma_sv_hi(a1[i], hs[j >> 1], x); else pk_fma_sv_lo(a1[i], hs[j >> 1], x); }
+                        else if (FIRST0 && kl == 63) pk_fma_s_lo_first(a1[i], hs[j >> 1], x);       // the chain's first tap (j = 0): from +0
+                        else if (j & 1) pk_fma_s_hi(a1[i], hs[j >> 1], x);
+                        else pk_fma_s_lo(a1[i], hs[j >> 1], x);
+                    }
                 }
             }
         }
@@ -91,7 +102,12 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
             for (int i = 0; i < 8; ++i) {
                 const int kl = 4 * i + 64 - w0;
                 if (kl >= 0 && kl < 64) {
-                    if constexpr (PIN) { if (kl & 1) pk_fma_sv_hi(a0[i], hs[kl >> 1], x); else pk_fma_sv_lo(a0[i], hs[kl >> 1], x); }
+                    if constexpr (ASYM) {
+                        if (FIRST0 && kl == 63) pk_fma_hi_first(a0[i], hv[kl >> 1], x);        // taps 63..0 from VGPR pairs
+                        else if (kl & 1) pk_fma_hi(a0[i], hv[kl >> 1], x);
+                        else pk_fma_lo(a0[i], hv[kl >> 1], x);
+                    }
+                    else if constexpr (PIN) { if (kl & 1) pk_fma_sv_hi(a0[i], hs[kl >> 1], x); else pk_fma_sv_lo(a0[i], hs[kl >> 1], x); }
                     else if (FIRST0 && kl == 63) pk_fma_s_hi_first(a0[i], hs[kl >> 1], x);      // the chain's first tap: from +0
                     else if (kl & 1) pk_fma_s_hi(a0[i], hs[kl >> 1], x);
                     else pk_fma_s_lo(a0[i], hs[kl >> 1], x);
@@ -101,14 +117,14 @@ __device__ __forceinline__ void fir_wide_step(const f32x4 *win, f32x4 (&buf)[NB]
     }
 }
 
-template <bool S32IN, int NB, bool PIN, int... Cs>
+template <bool S32IN, int NB, bool PIN, bool ASYM, int... Cs>
 __device__ __forceinline__ void fir_wide_steps(std::integer_sequence<int, Cs...>, const f32x4 *win, const f32x2 (&hs)[32],
-                                               f32x2 (&a1)[8], f32x2 (&a0)[8])
+                                               f32x2 (&a1)[8], f32x2 (&a0)[8], const f32x2 (&hv)[ASYM ? 32 : 1])
 {
     f32x4 buf[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) buf[c] = win[c + (c >> 4)];
-    (fir_wide_step<S32IN, Cs, NB, PIN>(win, buf, hs, a1, a0), ...);
+    (fir_wide_step<S32IN, Cs, NB, PIN, true, ASYM>(win, buf, hs, a1, a0, hv), ...);
 }
 
 // ABL (profiling): 0 = the real kernel, 1 = staging + stores without the FIR, 5 = phase stamps (per wave 8 x uint64:
@@ -133,11 +149,12 @@ __device__ __forceinline__ void store16_policy(f32x4 v, f32x4 *dst)
 // texture path convert on the way in -- instruction j turns source bytes [128 j, 128 j + 128) = chunks [16 j, 16 j + 16) into the
 // slots [17 j, 17 j + 16): the image's pad slot after every 16 chunks falls between instructions.  68 typed instructions per tile
 // instead of 19 one-kilobyte DMAs; the FIR below does not know the difference.
-template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false, int POL = 0, bool HALFIN = false>
+template <int ABL = 0, bool S32IN = false, int NB = 24, bool NTL = true, bool PIN = false, int POL = 0, bool HALFIN = false, bool ASYM = false>
 __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
 {
     using C = DecimWide;
     static_assert(!HALFIN || (!S32IN && ABL == 0 && !PIN && POL == 0), "CF16 storage: the shipped form only");
+    static_assert(!ASYM || (ABL == 0 && !PIN && POL == 0), "non-symmetric taps: the shipped form only");
     static_assert(C::CHUNKS % 16 == 0, "whole 16-chunk rows");
     constexpr int SB = HALFIN ? 4 : 8;                    // bytes per complex sample in HBM
     __shared__ __attribute__((aligned(16))) f32x4 img[C::SLOTS];
@@ -165,11 +182,24 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
     // the 64 distinct taps as SGPR pairs (scalar loads from the constant address space; S32 wire-word plans pass
     // taps already scaled by 2^-31)
     f32x2 hs[32];
+    f32x2 hv[ASYM ? 32 : 1];
     {
         const __attribute__((address_space(4))) f32x2 *tq =
             (const __attribute__((address_space(4))) f32x2 *)(S32IN ? a.taps_scaled : a.taps);
 #pragma unroll
-        for (int m = 0; m < 32; ++m) hs[m] = tq[m];
+        for (int m = 0; m < 32; ++m) hs[m] = tq[(ASYM ? 32 : 0) + m];     // ASYM: taps 64..127 (the P1 chain's) in the scalar registers
+        if constexpr (ASYM) {
+            // ... and taps 0..63 (the P0 chain's) in 32 VGPR pairs, the same value in every lane
+            const f32x2 *tv = reinterpret_cast<const f32x2 *>(S32IN ? a.taps_scaled : a.taps);
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                f32x2 t = tv[m];
+                asm volatile("" : "+v"(t));              // keep it a vector register pair (a uniform load would land in SGPRs)
+                hv[m] = t;
+            }
+        } else {
+            hv[0] = (f32x2){0.0f, 0.0f};
+        }
     }
 
     unsigned boff[HALFIN ? 1 : C::NI];
@@ -310,7 +340,7 @@ __global__ __launch_bounds__(64) void decim4_wide_kernel(const DecimTileArgs a)
             a0[4] = (f32x2){v1.x, v1.y};
             a0[7] = (f32x2){v1.z, v1.w};
         } else {
-            fir_wide_steps<S32IN, NB, PIN>(std::make_integer_sequence<int, C::WCH>{}, win, hs, a1, a0);
+            fir_wide_steps<S32IN, NB, PIN, ASYM>(std::make_integer_sequence<int, C::WCH>{}, win, hs, a1, a0, hv);
         }
         f32x4 y[4];
 #pragma unroll

@@ -190,9 +190,16 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 a.hist_wave = (p->sched == 0 && a.w8) ? (t % a.w8) * 8 + t / a.w8 : t;
             }
             dim3 grid((unsigned)G, (unsigned)p->nchan);
-            if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
-            else if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>), grid, dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
+            if (p->symmetric) {
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true>), grid, dim3(64), 0, st, a);
+                else if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>), grid, dim3(64), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
+            } else {
+                // taps that are not bit-symmetric: the same kernel with the P0 chain's taps in VGPR pairs (ASYM)
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true, 24, true, false, 0, false, true>), grid, dim3(64), 0, st, a);
+                else if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true, true>), grid, dim3(64), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, false, true>), grid, dim3(64), 0, st, a);
+            }
             HIPCHECK(hipGetLastError());
             return SXFIR_OK;
         }

@@ -157,9 +157,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
-        // CF16 storage at /4 with 128 symmetric taps: the wide kernel with the typed-DMA front end (round 5); any other CF16 /4
-        // filter of 128 taps keeps the multi-column kernel
-        const bool half4_wide = fmt == SXFIR_CF16 && ratio == 4 && ntaps == 128 && p->symmetric;
+        // CF16 storage at /4 with 128 taps: the wide kernel with the typed-DMA front end (round 5)
+        const bool half4_wide = fmt == SXFIR_CF16 && ratio == 4 && ntaps == 128;
         p->tile_capable = ((fmt == SXFIR_CF32 && ratio == 4 && (ntaps == 128 || ntaps == 64)) ||
                            (fmt == SXFIR_S32 && ratio == 4 && ntaps == 128) || half4_wide);
         // multi-column kernel: 32 taps per phase; CF32 at ratio 8/16/32, CF16 at ratio 4/8/16/32
@@ -325,13 +324,20 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                    : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>;
 #endif
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
-        if (ntaps == 128 && p->symmetric) {
-            // the shipped form for 128 symmetric taps: eight outputs per lane (sxfir_decim_wide.hip.h); 18.5 KB of LDS
-            // per wave -> 8 waves per CU
+        if (ntaps == 128) {
+            // the shipped form for 128 taps: eight outputs per lane (sxfir_decim_wide.hip.h); 18.5 KB of LDS per wave -> 8 waves
+            // per CU.  Bit-symmetric taps (every linear-phase design): all 64 distinct taps in SGPR pairs; any other taps (ASYM,
+            // round 5): taps 127..64 in SGPR pairs, taps 63..0 in VGPR pairs
             p->wide8 = true;
-            const void *kw = fmt == SXFIR_S32    ? (const void *)sxfir::decim4_wide_kernel<0, true>
-                             : fmt == SXFIR_CF16 ? (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>
-                                                 : (const void *)sxfir::decim4_wide_kernel<0, false>;
+            const void *kw;
+            if (p->symmetric)
+                kw = fmt == SXFIR_S32    ? (const void *)sxfir::decim4_wide_kernel<0, true>
+                     : fmt == SXFIR_CF16 ? (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>
+                                         : (const void *)sxfir::decim4_wide_kernel<0, false>;
+            else
+                kw = fmt == SXFIR_S32    ? (const void *)sxfir::decim4_wide_kernel<0, true, 24, true, false, 0, false, true>
+                     : fmt == SXFIR_CF16 ? (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true, true>
+                                         : (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, false, true>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
         }
 #ifdef SXFIR_PROFILING

@@ -238,8 +238,9 @@ def test_unaligned_and_odd_stride_inputs(oracle, taps):
 
 @pytest.mark.parametrize("fmt", ["CF32", "S32"])
 def test_asymmetric_taps_take_the_vgpr_tile_kernel(oracle, fmt):
-    """128 symmetric taps run the scalar-tap form of the /4 tile kernel (taps in SGPRs); any other 128-tap
-    filter runs the form with per-lane tap registers.  Same contract, same bits, across calls."""
+    """128 bit-symmetric taps run the /4 wide kernel with all 64 distinct taps in SGPRs; any other 128-tap filter runs its ASYM
+    form (round 5: taps 127..64 in SGPR pairs, taps 63..0 in VGPR pairs; rounds 1-4: the tile kernel with per-lane tap
+    registers).  Same contract, same bits, across calls."""
     rng = np.random.default_rng(77)
     h = (rng.standard_normal(128) / 128).astype(np.float32)
     assert not np.array_equal(h, h[::-1])

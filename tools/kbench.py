@@ -38,6 +38,9 @@ yoff = int(os.environ.get("KB_YOFF", "0"))          # output buffer displaced by
 ybase = torch.empty(nchan * (n // D) * (4 if FMT == "CF16" else 8) + yoff + 64, dtype=torch.uint8, device="cuda")
 y = ybase[yoff:yoff + nchan * (n // D) * (4 if FMT == "CF16" else 8)].view(dt).view(nchan, n // D)
 taps = sxxcvr_amd.design_lowpass(32 * D, D)
+if os.environ.get("KB_ASYM") == "1":
+    # taps that are not bit-symmetric (bench.py --asymmetric-taps): "x" then runs the wide kernel's ASYM form, "sb" the tile kernel
+    taps = (taps.astype(np.float64) * (1.0 + 1e-3 * np.arange(taps.size) / taps.size)).astype(np.float32)
 plans = []
 for v, ov, occ, abl, sched, pad in configs:
     os.environ["SXFIR_LDS_PAD"] = str(pad)
