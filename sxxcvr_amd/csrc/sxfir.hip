@@ -23,13 +23,13 @@
 // tests/test_gpu_variants.py) adds the A/B variants, the ablation modes and the environment knobs.
 // (shipped: CF16 storage only -- since round 3 every CF32 / S32-word plan at ratio 8, 16, 32 runs decim_dense_kernel,
 // so the multi-column kernel's CF32 and S32 instances exist in the profiling build alone, as the A/B partner)
-// (CF16 at /8, /16, /32 left the shipped list in round 5: decim_dense_kernel<D, ..., HALFIN> runs them, 8-12 % faster; the multi-column
-// CF16 instances of those ratios stay in the profiling build as the A/B partners, SXFIR_DENSE=0.  Shipped: CF16 at /4.)
-#define SXFIR_MULTI_SHIPPED(X) \
-    X(4, 1, true, 2)
+// (Round 5: CF16 storage left the multi-column kernel altogether -- decim_dense_kernel<D, ..., HALFIN> runs /8, /16, /32 and
+// decim4_wide_kernel<..., HALFIN> runs /4, 8-15 % faster through typed LDS-DMA -- so the production library carries no instance of it;
+// the profiling build keeps them as A/B partners: SXFIR_DENSE=0.)
+#define SXFIR_MULTI_SHIPPED(X)
 #ifdef SXFIR_PROFILING
 #define SXFIR_MULTI_VARIANTS(X) \
-    SXFIR_MULTI_SHIPPED(X) X(8, 4, true, 2) X(16, 4, true, 2) X(32, 4, true, 2) \
+    SXFIR_MULTI_SHIPPED(X) X(4, 1, true, 2) X(8, 4, true, 2) X(16, 4, true, 2) X(32, 4, true, 2) \
     X(8, 4, false, 2) X(16, 4, false, 2) X(32, 4, false, 2) \
     X(4, 1, false, 2) X(4, 4, false, 2) X(8, 1, false, 2) X(8, 2, false, 2) X(16, 2, false, 2) X(32, 8, false, 2) \
     X(8, 1, true, 2) X(8, 2, true, 2) X(16, 2, true, 2) X(32, 8, true, 2) \

@@ -195,10 +195,14 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 else if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>), grid, dim3(64), 0, st, a);
                 else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false>), grid, dim3(64), 0, st, a);
             } else {
-                // taps that are not bit-symmetric: the same kernel with the P0 chain's taps in VGPR pairs (ASYM)
-                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true, 24, true, false, 0, false, true>), grid, dim3(64), 0, st, a);
-                else if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true, true>), grid, dim3(64), 0, st, a);
+                // taps that are not bit-symmetric: the same kernel with the P0 chain's taps in VGPR pairs (ASYM); shipped for CF16 storage
+                if (p->fmt == SXFIR_CF16) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true, true>), grid, dim3(64), 0, st, a);
+#ifdef SXFIR_PROFILING
+                else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, true, 24, true, false, 0, false, true>), grid, dim3(64), 0, st, a);
                 else hipLaunchKernelGGL((sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, false, true>), grid, dim3(64), 0, st, a);
+#else
+                else return fail(SXFIR_EUNSUPPORTED, "internal: non-symmetric taps on the wide kernel outside CF16 storage");
+#endif
             }
             HIPCHECK(hipGetLastError());
             return SXFIR_OK;

@@ -324,10 +324,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                    : (const void *)sxfir::decim4_tile2_kernel<128, 1, sxfir::T2_SHIPPED>;
 #endif
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ksb, 64, 0) == hipSuccess && nb > 0) p->occ_sb = nb;
-        if (ntaps == 128) {
-            // the shipped form for 128 taps: eight outputs per lane (sxfir_decim_wide.hip.h); 18.5 KB of LDS per wave -> 8 waves
-            // per CU.  Bit-symmetric taps (every linear-phase design): all 64 distinct taps in SGPR pairs; any other taps (ASYM,
-            // round 5): taps 127..64 in SGPR pairs, taps 63..0 in VGPR pairs
+        if (ntaps == 128 && (p->symmetric || fmt == SXFIR_CF16)) {
+            // the shipped form for 128 bit-symmetric taps (every linear-phase design): eight outputs per lane, all 64 distinct taps in
+            // SGPR pairs (sxfir_decim_wide.hip.h); 18.5 KB of LDS per wave -> 8 waves per CU.  Its ASYM form (round 5: taps 127..64 in
+            // SGPR pairs, taps 63..0 in VGPR pairs) ships for CF16 storage only, where it beats the multi-column kernel by 3 %; on CF32
+            // and S32 words it measured 1.4 % slower / 0.7 % faster than decim4_tile_kernel<128> (profiles/round5_kbench_asym.txt),
+            // which therefore keeps the non-symmetric 128-tap plans (the instances exist in the profiling build: SXFIR_WIDE_ASYM=1)
             p->wide8 = true;
             const void *kw;
             if (p->symmetric)
@@ -335,12 +337,17 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                      : fmt == SXFIR_CF16 ? (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true>
                                          : (const void *)sxfir::decim4_wide_kernel<0, false>;
             else
-                kw = fmt == SXFIR_S32    ? (const void *)sxfir::decim4_wide_kernel<0, true, 24, true, false, 0, false, true>
-                     : fmt == SXFIR_CF16 ? (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true, true>
-                                         : (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, false, true>;
+                kw = (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, true, true>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kw, 64, 0) == hipSuccess && nb > 0) p->occ_wide = nb;
         }
 #ifdef SXFIR_PROFILING
+        if (ntaps == 128 && !p->symmetric && fmt != SXFIR_CF16 && getenv("SXFIR_WIDE_ASYM") && atoi(getenv("SXFIR_WIDE_ASYM"))) {
+            p->wide8 = true;                                   // A/B: the wide kernel's ASYM form on CF32 / S32 words
+            int nbw = 0;
+            const void *kw = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_wide_kernel<0, true, 24, true, false, 0, false, true>
+                                              : (const void *)sxfir::decim4_wide_kernel<0, false, 24, true, false, 0, false, true>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbw, kw, 64, 0) == hipSuccess && nbw > 0) p->occ_wide = nbw;
+        }
         if (ntaps == 128) {
             const void *kp = fmt == SXFIR_S32 ? (const void *)sxfir::decim4_pair_kernel<0, true> : (const void *)sxfir::decim4_pair_kernel<0, false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kp, 128, 0) == hipSuccess && nb > 0) p->occ_pair = nb;

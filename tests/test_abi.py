@@ -118,11 +118,11 @@ def test_shipped_code_object():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import shipped_isa
     rows = shipped_isa.kernels()
-    assert len(rows) >= 30
+    assert len(rows) >= 28
     for r in rows:
         assert r["scratch_bytes"] == 0, r["name"]
         assert r["v_mfma"] == 0, r["name"]
-    w8 = [r for r in rows if r["name"] == "decim4_wide_kernel<0, false, 24, true, false, 0, false>"]
+    w8 = [r for r in rows if r["name"] == "decim4_wide_kernel<0, false, 24, true, false, 0, false, false>"]
     assert len(w8) == 1, [r["name"] for r in rows]
     w8 = w8[0]
     # the shipped /4 kernel for 128 symmetric taps: 8 outputs per lane x 128 taps = 1024 packed FMAs with scalar taps,
@@ -147,11 +147,15 @@ def test_shipped_code_object():
         per_wave = 10 if r["name"].startswith("decim_dense_kernel<32") else 9          # 1-KiB instructions of the CF32 form per wave and tile
         assert r["typed_lds_dma"] == 2 * 4 * per_wave and r["v_cvt_f32_f16"] <= 8 and r["global_load_lds_dwordx4"] == 0, r
     # ... and CF16 at /4 with symmetric taps: the wide kernel with the same front end, 68 typed instructions per tile (one staging site in the tile loop)
-    wh = [r for r in rows if r["name"] == "decim4_wide_kernel<0, false, 24, true, false, 0, true>"]
+    wh = [r for r in rows if r["name"] == "decim4_wide_kernel<0, false, 24, true, false, 0, true, false>"]
     assert len(wh) == 1 and wh[0]["typed_lds_dma"] == 68 and wh[0]["v_cvt_f32_f16"] <= 8 and wh[0]["v_pk_fma_f32"] == 1024, wh
     assert wh[0]["lds_bytes"] == 18496 and wh[0]["scalar_tap_fmas"] == 1024 and wh[0]["global_load_lds_dwordx4"] == 0
-    mh = [r for r in rows if r["name"].startswith("decim_multi_kernel<")]
-    assert [r["name"] for r in mh] == ["decim_multi_kernel<4, 1, true, 0, 2, false>"], [r["name"] for r in mh]
+    # ... its ASYM form (taps that are not bit-symmetric: P0 taps in VGPR pairs) ships for CF16 storage only, and with it the
+    # multi-column kernel has left the production library
+    wa = [r for r in rows if r["name"].startswith("decim4_wide_kernel<") and r["name"].rstrip(">").endswith(", true")]
+    assert [r["name"] for r in wa] == ["decim4_wide_kernel<0, false, 24, true, false, 0, true, true>"], [r["name"] for r in wa]
+    assert wa[0]["vgpr"] <= 256 and wa[0]["typed_lds_dma"] == 68 and wa[0]["v_pk_fma_f32"] == 1024
+    assert not [r for r in rows if r["name"].startswith("decim_multi_kernel<")]
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<2, ")]
     assert len(ip) == 4, ip                                 # with / without the keying count, CF32 / wire-word output
     for r in ip:
