@@ -194,6 +194,32 @@ def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
         assert np.isnan(wf).any() and np.isinf(wf[ok]).any()
 
 
+def test_cf16_div4_with_taps_that_are_not_symmetric(oracle):
+    """CF16 storage at /4 with 128 taps that are not bit-symmetric: decim4_wide_kernel<..., HALFIN, ASYM> (typed LDS-DMA front end; the
+    P1 chain's taps in SGPR pairs, the P0 chain's in VGPR pairs).  Streaming over ragged calls, two channels, bit-exact against the
+    oracle on the half-rounded input."""
+    import torch
+    from sxxcvr_amd.resampler import KERNEL_TILED
+    h = (np.random.default_rng(404).standard_normal(128) / 64.0).astype(np.float32)
+    assert not np.array_equal(h, h[::-1])
+    lens = [4 * 512 * 9 + 4 * 36, 4 * 8, 4 * 512 * 3, 4 * 1000]
+    total, nchan = sum(lens), 2
+    xs = [oracle.f16_to_f32(oracle.f32_to_f16(oracle.synth_iq(SEED, 120 + c, 0, total).view(np.float32))).view(np.complex64) for c in range(nchan)]
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, 4, nchan=nchan, fmt="CF16")
+    plan.set_kernel(KERNEL_TILED)
+    assert plan.contract == (2, 4)
+    got, pos = [[] for _ in range(nchan)], 0
+    for n in lens:
+        buf = np.stack([oracle.f32_to_f16(xs[c][pos:pos + n].view(np.float32)).view(np.uint32) for c in range(nchan)])
+        y = to_cpu(plan.process(to_gpu(buf.view(np.int32)))).reshape(nchan, -1)
+        for c in range(nchan):
+            got[c].append(y[c])
+        pos += n
+    for c in range(nchan):
+        want = oracle.f32_to_f16(oracle.decim_f32(h, 4, xs[c], 2, 4).view(np.float32))
+        assert np.array_equal(np.concatenate(got[c]).view(np.uint16), want), "CF16 /4, asymmetric taps, channel %d" % c
+
+
 @pytest.mark.parametrize("L,n_in", [(8, 1), (8, 64), (8, 64 * 50 + 7), (8, 1 << 16), (4, 1 << 15), (4, 129), (16, 5000),
                                     (32, 3333)])
 def test_tiled_interpolator_bit_exact(oracle, L, n_in):
