@@ -52,7 +52,7 @@ extern "C" {
  *    them no longer links against the production library; every other version-1 entry point is unchanged.
  * 3: sxfir_set_position added (round 3); nothing removed or changed.
  * 4: sxfir_interpolate_keyed and the sxfir_comm_* gather over RCCL added (round 4); nothing removed or changed.
- * 5: sxfir_device_pci_bus_id and sxfir_comm_query added (round 5); the sxfir_comm_* calls now leave the calling thread's
+ * 5: sxfir_device_pci_bus_id, sxfir_comm_query and sxfir_contract_rotation added (round 5); the sxfir_comm_* calls now leave the calling thread's
  *    current GPU as they found it; nothing removed. */
 #define SXFIR_ABI_VERSION 5
 
@@ -129,6 +129,12 @@ int sxfir_set_tx_threshold(sxfir_plan *plan, float tx_threshold2);
  * (k = j*ratio + r) and column groups of `cw` phases r; interpolator: `jsplit`
  * contiguous ranges of j, cw = 1.  See DESIGN.md "Numeric contract". */
 int sxfir_contract(const sxfir_plan *plan, int *jsplit, int *cw);
+/* ... and its rotation: 0 for every shape but the decimators by 48 and 96 with 32 taps per phase (the reference's rates
+ * master clock / 768 and / 1536, SoapySX.cpp:180-208), where it is 1: the rows and columns of the contract are then
+ * those of the slot index k' = j*ratio + r, and slot k' holds tap k = (k' + 1) mod ntaps with its sample x[m*ratio - k].
+ * The filter is the same sum; a row of the picture is then the `ratio` samples that end BEFORE sample (m - j)*ratio --
+ * whole 128-byte lines of the input -- and tap 0 opens the last subset's chain. */
+int sxfir_contract_rotation(const sxfir_plan *plan, int *rot);
 
 /* Absolute count of input samples consumed / output samples produced since
  * the last reset (per channel; all channels advance together). */

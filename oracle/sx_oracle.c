@@ -256,11 +256,15 @@ int sxo_interp_f64(const float *h, int ntaps, int L, const float *x, size_t n_x,
 /* ------------------------------------------------------------------------- */
 #define SXO_MAX_GROUPS 32
 
+/* Adjacent-pair tree: every level adds neighbours (0,1), (2,3), ...; an odd element at the end of a level moves up
+ * unchanged (12 groups: 6, 3, then (a + b) and c, then their sum).  For a power of two this is the balanced tree. */
 static inline float tree_sum(float *p, int g)
 {
     while (g > 1) {
-        for (int i = 0; i < g / 2; i++) p[i] = p[2 * i] + p[2 * i + 1];
-        g /= 2;
+        const int h = g / 2;
+        for (int i = 0; i < h; i++) p[i] = p[2 * i] + p[2 * i + 1];
+        if (g & 1) p[h] = p[g - 1];
+        g = h + (g & 1);
     }
     return p[0];
 }
@@ -272,8 +276,13 @@ static inline float tree_sum(float *p, int g)
  *                   i.e. ascending sample time inside the (c, p) subset
  *   col[c]        = adjacent-pair tree over p of partial[c][p]
  *   y             = adjacent-pair tree over c of col[c]
- * (jsplit = 1, cw = D) is the plain descending-k chain. */
-static void decim_f32_range(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
+ * (jsplit = 1, cw = D) is the plain descending-k chain.
+ * rot (0 or 1; ratios 48 and 96): the rows and columns above are those of the ROTATED tap index k' = (k - rot) mod ntaps,
+ *   i.e. slot k' = j*D + r stands for tap k = (k' + rot) mod ntaps and its sample x[m*D - k].  The filter is the same
+ *   sum; what changes is which taps share a chain: with rot = 1 a row of the picture is the D samples that END BEFORE
+ *   sample (m - j)*D -- whole 128-byte lines of the input for D = 48, 96 -- and tap 0 (the newest sample, alone in the
+ *   next line) opens the chain of the last subset instead of closing the chain of the first. */
+static void decim_f32_range(const float *h, int ntaps, int D, int jsplit, int cw, int rot, const float *x,
                             int64_t m_begin, int64_t m_end, int64_t m0, float *y)
 {
     const int jt = (ntaps + D - 1) / D;
@@ -294,8 +303,10 @@ static void decim_f32_range(const float *h, int ntaps, int D, int jsplit, int cw
                 for (int b = 0; b < BLK; b++) { ai[b] = 0.0f; aq[b] = 0.0f; }
                 for (int j = (p + 1) * jl - 1; j >= p * jl; j--) {
                     for (int r = (c + 1) * cw - 1; r >= c * cw; r--) {
-                        const int k = j * D + r;
+                        int k = j * D + r;
                         if (k >= ntaps) continue;
+                        k += rot;
+                        if (k >= ntaps) k -= ntaps;
                         const float t = h[k];
                         if (safe) {
                             const float *xs = x + 2 * (m * (int64_t)D - k);
@@ -335,23 +346,30 @@ static void decim_f32_range(const float *h, int ntaps, int D, int jsplit, int cw
 
 static int pow2(int v) { return v >= 1 && !(v & (v - 1)); }
 
-static int decim_check(int ntaps, int D, int jsplit, int cw, size_t n_x, int64_t m0, size_t n_out)
+static int decim_check(int ntaps, int D, int jsplit, int cw, int rot, size_t n_x, int64_t m0, size_t n_out)
 {
     if (ntaps < 1 || D < 1 || m0 < 0) return -2;
+    if (rot < 0 || rot >= D || (rot && ntaps % D)) return -2;
     const int jt = (ntaps + D - 1) / D;
     if (!pow2(jsplit) || jsplit > SXO_MAX_GROUPS || jt % jsplit) return -2;
-    if (cw < 1 || D % cw || !pow2(D / cw) || D / cw > SXO_MAX_GROUPS) return -2;
+    if (cw < 1 || D % cw || D / cw > SXO_MAX_GROUPS) return -2;
     if (n_out && (m0 + (int64_t)n_out - 1) * D >= (int64_t)n_x) return -1;
+    return 0;
+}
+
+int sxo_decim_f32_rot(const float *h, int ntaps, int D, int jsplit, int cw, int rot, const float *x,
+                      size_t n_x, int64_t m0, size_t n_out, float *y)
+{
+    const int rc = decim_check(ntaps, D, jsplit, cw, rot, n_x, m0, n_out);
+    if (rc) return rc;
+    decim_f32_range(h, ntaps, D, jsplit, cw, rot, x, m0, m0 + (int64_t)n_out, m0, y);
     return 0;
 }
 
 int sxo_decim_f32(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                   size_t n_x, int64_t m0, size_t n_out, float *y)
 {
-    const int rc = decim_check(ntaps, D, jsplit, cw, n_x, m0, n_out);
-    if (rc) return rc;
-    decim_f32_range(h, ntaps, D, jsplit, cw, x, m0, m0 + (int64_t)n_out, m0, y);
-    return 0;
+    return sxo_decim_f32_rot(h, ntaps, D, jsplit, cw, 0, x, n_x, m0, n_out, y);
 }
 
 int sxo_max_threads(void)
@@ -366,7 +384,13 @@ int sxo_max_threads(void)
 int sxo_decim_f32_mt(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                      size_t n_x, int64_t m0, size_t n_out, float *y, int threads)
 {
-    const int rc = decim_check(ntaps, D, jsplit, cw, n_x, m0, n_out);
+    return sxo_decim_f32_rot_mt(h, ntaps, D, jsplit, cw, 0, x, n_x, m0, n_out, y, threads);
+}
+
+int sxo_decim_f32_rot_mt(const float *h, int ntaps, int D, int jsplit, int cw, int rot, const float *x,
+                         size_t n_x, int64_t m0, size_t n_out, float *y, int threads)
+{
+    const int rc = decim_check(ntaps, D, jsplit, cw, rot, n_x, m0, n_out);
     if (rc) return rc;
     const int64_t chunk = 4096;
     const int64_t nchunks = ((int64_t)n_out + chunk - 1) / chunk;
@@ -378,7 +402,7 @@ int sxo_decim_f32_mt(const float *h, int ntaps, int D, int jsplit, int cw, const
         const int64_t b = m0 + c * chunk;
         int64_t e = b + chunk;
         if (e > m0 + (int64_t)n_out) e = m0 + (int64_t)n_out;
-        decim_f32_range(h, ntaps, D, jsplit, cw, x, b, e, m0, y);
+        decim_f32_range(h, ntaps, D, jsplit, cw, rot, x, b, e, m0, y);
     }
     return 0;
 }

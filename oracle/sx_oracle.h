@@ -76,11 +76,21 @@ int sxo_decim_f64(const float *h, int ntaps, int D, const float *x, size_t n_x,
  * contiguous ranges, phases into column groups of `cw`; inside a (range,
  * column) subset a fmaf chain from +0.0f runs over j DESCENDING, r DESCENDING
  * (ascending sample time); partials are combined by an adjacent-pair tree
- * over the row ranges, then an adjacent-pair tree over the columns.
+ * over the row ranges, then an adjacent-pair tree over the columns (an odd
+ * element at the end of a level moves up unchanged: 12 columns -> 6 -> 3 ->
+ * (a + b), c -> their sum; the ratios 48 and 96 of the reference's rate table).
  * (jsplit=1, cw=D) is the plain descending-k chain; (2, 4) at D=4 splits the
  * taps into two contiguous halves. */
 int sxo_decim_f32(const float *h, int ntaps, int D, int jsplit, int cw, const float *x,
                   size_t n_x, int64_t m0, size_t n_out, float *y);
+/* The same with the contract's rotation (0 or 1; 1 for the ratios 48 and 96): rows and columns are those of the slot
+ * index k' = j*D + r, which stands for tap k = (k' + rot) mod ntaps and its sample x[m*D - k] -- the same filter, other
+ * chains: a row is then the D samples that end BEFORE sample (m - j)*D (whole cache lines of the input), and tap 0
+ * opens the last subset's chain.  Needs ntaps % D == 0. */
+int sxo_decim_f32_rot(const float *h, int ntaps, int D, int jsplit, int cw, int rot, const float *x,
+                      size_t n_x, int64_t m0, size_t n_out, float *y);
+int sxo_decim_f32_rot_mt(const float *h, int ntaps, int D, int jsplit, int cw, int rot, const float *x,
+                         size_t n_x, int64_t m0, size_t n_out, float *y, int threads);
 
 /* ---- a-0: FIR interpolator, y[n] = sum_j h[j*L + n%L] x[n/L - j], x[<0]=0 ---- */
 int sxo_interp_f64(const float *h, int ntaps, int L, const float *x, size_t n_x,

@@ -71,6 +71,7 @@ def load_sxfir(profiling=False):
         "sxfir_set_kernel": (ci, [vp, ci]),
         "sxfir_set_tx_threshold": (ci, [vp, C.c_float]),
         "sxfir_contract": (ci, [vp, P(ci), P(ci)]),
+        "sxfir_contract_rotation": (ci, [vp, P(ci)]),
         "sxfir_position": (ci, [vp, P(i64), P(i64)]),
         "sxfir_outputs_for": (ci, [vp, sz, P(sz)]),
         "sxfir_decimate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),

@@ -54,6 +54,7 @@
 #endif
 #define SXFIR_MULTI_KEY(DD, WW, HH, PP) (((PP) == 4 ? 1000000 : 0) + ((HH) ? 10000 : 0) + (DD) * 100 + (WW))
 #include "sxfir_decim_dense.hip.h"
+#include "sxfir_decim_blocks.hip.h"             // /48, /96: sixteen-column blocks (whole input lines), scalar taps (round 5)
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_interp_pass.hip.h"
 #include "sxfir_decim_tile2.hip.h"

@@ -1,0 +1,266 @@
+// Decimate-by-48 and -by-96, 32 taps per phase (1536 / 3072 taps), CF32 or S32 wire words: the two slowest rates of the
+// reference's table (SoapySX.cpp:180-208: master clock / 768 and / 1536; the device's converters run at master clock / 16,
+// so the ratio is divider / 16).  New code: the reference programs the SX1255's own decimator for these rates (:1192-1208).
+//
+// A row of the polyphase picture is D = 48 or 96 samples: a tile of outputs with its 31 halo rows no longer fits LDS the way
+// decim_dense_kernel<32> holds it (543 rows x 96 samples = 417 KB), and 1536 taps fit no register file.  But the numeric
+// contract (2, 4) never mixes columns before its tree: a (row half p, column group c) subset is a 64-tap fmaf chain over FOUR
+// columns of the picture, and what meets in the tree are finished partial sums.  So the picture is cut into BLOCKS of sixteen
+// columns -- four column groups, eight subsets -- and a (tile, block) step is the scalar-tap problem of
+// decim_dense_kernel<8, SUBSET> with rows that lie D samples apart in HBM:
+//
+//   * The contract's ROTATION (sxfir_contract_rotation = 1 for these two shapes):
+//     slot k' = j D + r of the picture holds tap (k' + 1) mod NT, so row j of output m is the D samples that end BEFORE
+//     sample (m - j) D and a block's piece of a row is one whole, aligned 128-byte line of the input.  Unrotated, a row ends AT
+//     sample (m - j) D, every piece straddles two lines, and each line is fetched by two steps: the first build of this
+//     kernel (eight-column blocks, unrotated) moved 3 x the algorithmic bytes through the L2's memory side and took 1.19 ms
+//     per 2^28 samples; the same with aligned 64-byte pieces 2 x and 0.77 ms (a line's two halves in two steps).  The
+//     filter is the same sum; tap 0 -- the newest sample, alone at the start of the NEXT line -- opens the chain of the last
+//     subset (slot NT - 1) instead of closing the chain of the first: one FMA per output with an operand from 32 rows on.
+//   * The image of a step: 544 rows (31 halo rows, 512 outputs' rows, one more for tap 0) x 16 samples, linear, one pad slot
+//     per 8 rows: 70 704 bytes, two workgroups per CU.  A DMA instruction moves eight whole lines (lane l: row l / 8,
+//     chunk l % 8); 17 per wave and step.  Lane g owns outputs 8 g .. 8 g + 7 of the tile: its window starts 65 slots after
+//     its neighbour's, so the sixteen lanes a ds_read_b128 is served with hit sixteen different slots mod 16.
+//   * The eight subsets of a block go to the four waves in two passes (wave ww: row half p = ww & 1, column groups ww / 2
+//     and ww / 2 + 2); a pass's 64 taps are 32 SGPR pairs loaded with four s_load_dwordx16 from a block-major table of the
+//     rotated taps (block b at 512 b, subset 2 c + p at 64 (2 c + p), (jj, rr) at 4 jj + rr): every FMA has its tap as the
+//     scalar operand, 46 window reads per 512 packed FMAs.
+//   * The subsets' partials meet through the dead image in the contract's order ((p0 + p1) per column group, adjacent
+//     groups, then the two pairs): the block's value, level 2 of the tree over the D / 4 column groups.  The block values of a
+//     tile meet in registers the way a binary counter adds: (B0 + B1) + B2 for three blocks, ((B0 + B1) + (B2 + B3)) +
+//     (B4 + B5) for six -- the adjacent-pair tree in which an odd element at the end of a level moves up unchanged, as
+//     the generic kernel states it.
+//   * Steps run (tile, block 0), (tile, block 1), ...; the next step's DMAs are issued when the partials have been
+//     exchanged, behind the arithmetic of the CU's other workgroup.
+//
+// Edge tiles (first / last of a call), the fused history carry-over and the ragged last stores follow the dense kernel.
+#pragma once
+
+#include "sxfir_decim_dense.hip.h"
+
+namespace sxfir {
+
+struct DecimBlocks16 {
+    static constexpr int W = 4;                       // waves per workgroup
+    static constexpr int TILE_OUT = 512;
+    static constexpr int NROWS = TILE_OUT + 31 + 1;   // aligned rows q in [M0 - 31, M0 + TILE_OUT]; the last for tap 0 alone
+    static constexpr int CPR = 8;                     // 16-byte chunks per row of a block
+    static constexpr int CH = NROWS * CPR;
+    static constexpr int RPI = 64 / CPR;              // rows per DMA instruction
+    static constexpr int PADROWS = 8;
+    static constexpr int NI = CH / 64;                // 68 DMA instructions per step
+    static constexpr int NIW = NI / W;                // 17 per wave
+    static constexpr int LDS_SLOTS = CH + (NROWS - 1) / PADROWS;
+    static constexpr int WCH = 46;                    // window chunks per lane and pass: 23 rows x 2
+    static constexpr int TAP0_SLOTS = 32 * CPR + 32 / PADROWS;   // tap 0's sample: the same chunk 32 rows on
+    static_assert(CH % 64 == 0 && NI % W == 0 && PADROWS == RPI, "whole instructions, a pad after each");
+    static_assert(LDS_SLOTS * 16 <= 160 * 1024 / 2, "two workgroups per CU");
+    static constexpr int dma_slot(int i) { return 65 * i; }
+};
+
+// NB = blocks per row (3: /48, 6: /96).  NTLD: the lines no other tile reads (image rows 32 .. 511) as non-temporal loads.
+template <int NB, bool S32IN = false, bool NTLD = false>
+__global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs a)
+{
+    static_assert(NB == 3 || NB == 6, "ratios 48 and 96");
+    using C = DecimBlocks16;
+    constexpr int D = 16 * NB;
+    constexpr int NT = 32 * D;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ww = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = ww & 1, c0 = ww >> 1;                 // the wave's subsets: (p, c0) and (p, c0 + 2)
+    const int G = lane;                                 // output group of the lane
+    const int ch = blockIdx.y;
+
+    const char *in = reinterpret_cast<const char *>(a.in) + 8ll * a.in_stride * ch;
+    char *out = reinterpret_cast<char *>(a.out) + 8ll * a.out_stride * ch;
+    const __attribute__((address_space(4))) f32x2 *tq = (const __attribute__((address_space(4))) f32x2 *)a.taps;
+
+    // Window of pass A: rows 8u .. 8u + 22 of the image (u = G + 2 - 2p), chunks CPR - 2 - 2 c0 + {0, 1} of each; slot = chunk
+    // + (pads before its row); the window's 8-row segments each lie between two pads.  Pass B: four chunks lower.
+    const int u = G - 2 * p + 2;
+    const f32x4 *win0 = lds + (C::CPR * 8 * u + C::CPR - 2 - 2 * c0 + u);
+    const f32x4 *win1 = win0 + 1;
+    const f32x4 *win2 = win0 + 2;
+
+    const int NG = a.n_groups;
+    // tiles [1, tile_hi] lie wholly inside this call's input (tile 0 reaches into the history), tiles below n_full store
+    // all 512 outputs
+    const long long q_hi = a.n_in / D - C::TILE_OUT;
+    const int tile_hi = q_hi < 0 ? -1 : (int)(q_hi >> 9);
+    const int n_full = (int)(a.n_out >> 9);
+    const int first_tile = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    // fused history carry-over: the tail of (hist ++ in) becomes the next history
+    if (first_tile == (a.n_tiles - 1) % NG && ww == C::W - 1) {
+        float2 *ho = reinterpret_cast<float2 *>(a.hist_out) + a.hist_stride * ch;
+        const float2 *hi = reinterpret_cast<const float2 *>(a.hist) + a.hist_stride * ch;
+        for (int j = lane; j < NT; j += 64) {
+            const long long s = a.n_in - NT + j;
+            ho[j] = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : hi[s + NT];
+        }
+    }
+
+    auto rare_args = [&]() __attribute__((always_inline)) {
+        const __attribute__((address_space(4))) DecimMultiArgs *ap =
+            (const __attribute__((address_space(4))) DecimMultiArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        return ap;
+    };
+
+    // HBM -> LDS for one (tile, block) step: instruction i = ww + 4 i0 moves image rows [8 i, 8 i + 8) -- eight lines, D
+    // samples apart -- to the slots from 65 i on.  Block b's line of aligned row q is samples D q - 16 (b + 1) .. D q - 16 b - 1.
+    const unsigned lane_off = (unsigned)(8 * D) * (unsigned)(lane >> 3) + 16u * (unsigned)(lane & 7);
+    auto stage = [&](int tile, int blk) __attribute__((always_inline)) {
+        const long long M0 = (long long)tile * C::TILE_OUT;
+        const long long s_first = D * (M0 - 31) - 16 * (blk + 1);         // first sample of the block image
+        const bool interior = tile >= 1 && tile <= tile_hi;
+        if (interior) {
+            const char *base = in + 8 * s_first + (8 * D * C::RPI) * ww;
+#pragma unroll
+            for (int i0 = 0; i0 < C::NIW; ++i0) {
+                unsigned lo = lane_off;
+                asm volatile("" : "+v"(lo));          // a 32-bit offset next to its use: SGPR base + VGPR offset form
+                const char *bi = base + (8 * D * C::RPI * 4) * i0;
+                asm volatile("" : "+s"(bi));
+                // image rows 32 .. 511 (instructions 4 .. 63) are this tile's alone; the others are a neighbour's halo too
+                if (NTLD && i0 >= 1 && i0 < 16) glds16<2>(bi + lo, lds + (65 * ww + C::dma_slot(4 * i0)));
+                else glds16(bi + lo, lds + (65 * ww + C::dma_slot(4 * i0)));
+            }
+        } else {
+            // edge tiles (first / last of a call): through registers, sample by sample
+            const auto *ap = rare_args();
+            const long long last = ap->n_in - 1;
+            const char *hist = reinterpret_cast<const char *>(ap->hist) + 8ll * ap->hist_stride * ch;
+#pragma nounroll
+            for (int i0 = 0; i0 < C::NIW; ++i0) {
+                const int i = ww + 4 * i0;
+                const int cidx = 64 * i + lane;                          // chunk of the image: row cidx / 8, chunk cidx % 8
+                unsigned wds[4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const long long s = s_first + (long long)D * (cidx >> 3) + 2 * (cidx & 7) + e;
+                    const char *src = s >= 0 ? in + 8 * (s <= last ? s : last) : hist + 8 * (s + NT >= 0 ? s + NT : 0);
+                    wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
+                    wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
+                }
+                lds[C::dma_slot(i) + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]), __uint_as_float(wds[2]),
+                                                     __uint_as_float(wds[3])};
+            }
+        }
+    };
+
+    auto add4 = [](const f32x4 &l, const f32x4 &r) __attribute__((always_inline)) {
+        return (f32x4){__fadd_rn(l.x, r.x), __fadd_rn(l.y, r.y), __fadd_rn(l.z, r.z), __fadd_rn(l.w, r.w)};
+    };
+
+    int tile = first_tile, blk = 0;
+    if (tile >= a.n_tiles) return;
+    stage(tile, 0);
+    f32x4 lv0, lv1, lv2;                                // waiting block sums of 1, 2, 4 blocks
+    lv0 = lv1 = lv2 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    while (true) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMAs landed ...
+        __syncthreads();                                    // ... and everybody else's
+
+        // ---- two passes: window sample w meets output i at local tap kl = 4*i + 63 - w
+        f32x2 acc[2][8];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            f32x2 hs[32];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) hs[m] = tq[256 * blk + 32 * (2 * (c0 + 2 * ps) + p) + m];
+            // slot NT - 1 = (last block, p = 1, c = 3, jj = 15, rr = 3) holds tap 0, whose sample is x[m D]: the same chunk of
+            // the image 32 rows further on (the first FMA of the chain; wave-uniform)
+            const bool tap0 = ps == 1 && blk == NB - 1 && ww == 3;
+            f32x2 xs[8];
+            if (tap0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 v = (win0 - 4)[C::CPR * i + C::TAP0_SLOTS];
+                    xs[i] = __builtin_shufflevector(v, v, 0, 1);
+                    if constexpr (S32IN) xs[i] = (f32x2){(float)__float_as_int(xs[i].x), (float)__float_as_int(xs[i].y)};
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < C::WCH; ++t) {
+                const f32x4 *wp = (t < 16 ? win0 : (t < 32 ? win1 : win2)) - 4 * ps;
+                const f32x4 v = wp[C::CPR * (t >> 1) + (t & 1)];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int w = 2 * t + s;
+                    f32x2 x = s ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1);
+                    if constexpr (S32IN) x = (f32x2){(float)__float_as_int(x.x), (float)__float_as_int(x.y)};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int kl = 4 * i + 63 - w;
+                        if (kl >= 0 && kl < 64) {
+                            if (kl == 63) {
+                                if (ps == 1) {
+                                    const f32x2 xf = tap0 ? xs[i] : x;
+                                    pk_fma_s_hi_first(acc[ps][i], hs[31], xf);
+                                } else {
+                                    pk_fma_s_hi_first(acc[ps][i], hs[31], x);
+                                }
+                            } else if (kl & 1) pk_fma_s_hi(acc[ps][i], hs[kl >> 1], x);
+                            else pk_fma_s_lo(acc[ps][i], hs[kl >> 1], x);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                    // everyone is done reading this step's image
+        // the eight subsets' partials meet in the dead image: subset s = 2c + p at 256 s; chunk k (two outputs) of group G at slot
+        // 4G + (k ^ ((G >> 1) & 3)): the eight lanes a ds_write_b128 is served with hit eight different slots mod 16
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                lds[256 * (2 * (c0 + 2 * ps) + p) + 4 * G + (k ^ ((G >> 1) & 3))] =
+                    (f32x4){acc[ps][2 * k].x, acc[ps][2 * k].y, acc[ps][2 * k + 1].x, acc[ps][2 * k + 1].y};
+        __syncthreads();
+        f32x4 y;
+        {
+            f32x4 col[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) col[cc] = add4(lds[256 * (2 * cc) + 64 * ww + lane], lds[256 * (2 * cc + 1) + 64 * ww + lane]);
+            y = add4(add4(col[0], col[1]), add4(col[2], col[3]));
+        }
+        __syncthreads();                                    // the exchange area may be overwritten by the next DMA
+        int nblk = blk + 1, ntile = tile;
+        if (nblk == NB) { nblk = 0; ntile = tile + NG; }
+        if (ntile < a.n_tiles) stage(ntile, nblk);
+
+        // ---- the tree over the blocks (wave-uniform branches)
+        if (blk & 1) {
+            y = add4(lv0, y);
+            if (blk & 2) { y = add4(lv1, y); lv2 = y; }
+            else lv1 = y;
+        } else lv0 = y;
+
+        if (blk == NB - 1) {
+            // 3 = 11b: levels 0 and 1 wait; 6 = 110b: levels 1 and 2
+            const f32x4 r = NB == 3 ? add4(lv1, lv0) : add4(lv2, lv1);
+            const long long M0 = (long long)tile * C::TILE_OUT;
+            // the slot this lane read holds chunk kq of group Gq: a permutation inside each 64-byte group, so the wave's
+            // store still covers one kilobyte of consecutive bytes
+            const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
+            const long long m = M0 + 8 * Gq + 2 * kq;
+            char *dst = out + 8 * m;
+            if (tile < n_full) {
+                store_pair<false>(dst, r.x, r.y, r.z, r.w);
+            } else {
+                const long long n_out = rare_args()->n_out;     // the call's last tile
+                if (m + 2 <= n_out) store_pair<false>(dst, r.x, r.y, r.z, r.w);
+                else if (m < n_out) store_one<false>(dst, r.x, r.y);
+            }
+        }
+        if (ntile >= a.n_tiles) break;
+        tile = ntile;
+        blk = nblk;
+    }
+}
+
+}  // namespace sxfir

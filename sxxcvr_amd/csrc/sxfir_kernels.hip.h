@@ -92,6 +92,7 @@ struct GenericArgs {
                             // interp: phase offset (always 0 here)
     int ntaps, ratio, hist_len;
     int jsplit, cw;         // numeric contract
+    int rot;                // decimator: slot k' = j*D + r holds tap (k' + rot) mod ntaps (sxfir_contract_rotation)
     float thr2;             // S32 output only: transmitter-keying threshold (squared magnitude)
 };
 
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(256) void decim_generic_kernel(const GenericArgs a)
             float si = 0.0f, sq = 0.0f;
             for (int j = (p + 1) * jl - 1; j >= p * jl; --j) {
                 for (int r = (c + 1) * a.cw - 1; r >= c * a.cw; --r) {
-                    const int k = j * D + r;
+                    int k = j * D + r;
                     if (k >= a.ntaps) continue;
+                    k += a.rot;
+                    if (k >= a.ntaps) k -= a.ntaps;
                     const float2 x = sample_at<F>(a, in, hist, newest - k);
                     const float t = a.taps[k];
                     si = __builtin_fmaf(t, x.x, si);
@@ -148,11 +151,17 @@ __global__ __launch_bounds__(256) void decim_generic_kernel(const GenericArgs a)
         ci[c] = pi[0];
         cq[c] = pq[0];
     }
-    for (int n = ncol; n > 1; n >>= 1)
+    // adjacent pairs, level by level; an odd element at the end of a level moves up unchanged (12 columns: 6, 3, 2, 1)
+    for (int n = ncol; n > 1; n = n / 2 + (n & 1)) {
         for (int i = 0; i < n / 2; ++i) {
             ci[i] = __fadd_rn(ci[2 * i], ci[2 * i + 1]);
             cq[i] = __fadd_rn(cq[2 * i], cq[2 * i + 1]);
         }
+        if (n & 1) {
+            ci[n / 2] = ci[n - 1];
+            cq[n / 2] = cq[n - 1];
+        }
+    }
     FO::store(out, m, make_float2(ci[0], cq[0]), a.thr2);
 }
 

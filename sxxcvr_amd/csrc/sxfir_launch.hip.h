@@ -61,7 +61,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.out_stride = (long long)out_stride;
         a.hist_stride = p->hist_len;
         const int W = p->multi_waves;
-        const int tile_out = W * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
+        const int tile_out = p->blocks ? 512 : W * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
         const long long n_tiles = (n_out + tile_out - 1) / tile_out;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
         long long groups = ((long long)p->compute_units * p->occ_multi * p->oversub) / p->nchan;
@@ -71,6 +71,21 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
         a.stamps = nullptr;
+        if (p->blocks) {
+            // /48, /96: sixteen-column blocks, scalar taps from the block-major table of the rotated taps
+            if (int rc = need_tap_table(p, TAPS_BLOCKS16, "decim_blocks_kernel")) return rc;
+            a.taps = p->taps_scaled_dev;
+            if (p->blocks == 3) {
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false>), grid, dim3(256), 0, st, a);
+            } else {
+                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false>), grid, dim3(256), 0, st, a);
+            }
+            HIPCHECK(hipGetLastError());
+            *history_done = true;
+            return SXFIR_OK;
+        }
         if (p->dense32) {
             // non-temporal staging loads for the image rows no other tile reads (NTLD = 2: both halos stay plain loads),
             // measured in round 4 (profiles/round4h_kbench_both_halos_plain.txt: whole kernel -0.9 % at /32, -2.8 % at /8
@@ -265,6 +280,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.hist_len = p->hist_len;
         a.jsplit = p->jsplit;
         a.cw = p->cw;
+        a.rot = p->rot;
         dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
         a.thr2 = p->thr2;
         if (p->fmt == SXFIR_CF32)
@@ -463,6 +479,7 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
     a.hist_len = p->hist_len;
     a.jsplit = p->jsplit;
     a.cw = p->cw;
+    a.rot = 0;
     dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)p->nchan);
     a.thr2 = p->thr2;
     if (p->fmt == SXFIR_CF32)

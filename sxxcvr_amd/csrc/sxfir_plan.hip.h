@@ -3,13 +3,15 @@
 // Included by sxfir.hip after the kernel headers; not a stand-alone translation unit.
 #pragma once
 
-enum TapTable { TAPS_SCALED = 0, TAPS_SUBSET8 = 1, TAPS_PASS8 = 2 };
+enum TapTable { TAPS_SCALED = 0, TAPS_SUBSET8 = 1, TAPS_PASS8 = 2, TAPS_BLOCKS16 = 3 };
 
 struct sxfir_plan {
     int mode, ntaps, ratio, nchan, fmt, device;
     int kernel;            // SXFIR_KERNEL_*
     int hist_len;          // samples of history kept per channel
+    int blocks;            // /48, /96: sixteen-column blocks of decim_blocks_kernel (3, 6), else 0
     int jsplit, cw;        // numeric contract
+    int rot;               // ... and its rotation (0; 1 for /48, /96: sxfir_contract_rotation)
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
@@ -154,6 +156,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->hist_dev = nullptr;
     p->hist_alt = nullptr;
     p->itile_capable = false;
+    p->blocks = 0;
+    p->rot = 0;
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
@@ -171,7 +175,16 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const int jt = (ntaps + ratio - 1) / ratio;
         const int ncol4 = ratio / 4;
         const bool pow2_cols = ratio % 4 == 0 && (ncol4 & (ncol4 - 1)) == 0 && ncol4 <= 32;
-        if (ntaps % ratio == 0 && pow2_cols && jt % 2 == 0) {
+        // /48 and /96 with 32 taps per phase (the reference's rates master clock / 768 and / 1536, SoapySX.cpp:180-208):
+        // decim_blocks_kernel, sixteen-column blocks of whole input lines under the ROTATED contract (slot k' holds tap
+        // (k' + 1) mod ntaps: sxfir_contract_rotation); 12 / 24 column groups meet in the adjacent-pair tree whose odd element
+        // at the end of a level moves up unchanged (oracle B and the generic kernel state the same tree and rotation)
+        p->blocks = (ntaps == 32 * ratio && (ratio == 48 || ratio == 96) && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) ? ratio / 16 : 0;
+        if (p->blocks) {
+            p->multi_capable = true;
+            p->rot = 1;
+        }
+        if (ntaps % ratio == 0 && (pow2_cols || p->blocks) && jt % 2 == 0) {
             p->jsplit = 2;
             p->cw = 4;
         } else {
@@ -284,7 +297,11 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const int W = p->multi_waves;
         int nb = 0;
         const void *k = nullptr;
-        if (p->dense32 && fmt == SXFIR_CF16) {
+        if (p->blocks) {
+            const bool w = fmt == SXFIR_S32;
+            k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true> : (const void *)sxfir::decim_blocks_kernel<3, false>)
+                               : (w ? (const void *)sxfir::decim_blocks_kernel<6, true> : (const void *)sxfir::decim_blocks_kernel<6, false>);
+        } else if (p->dense32 && fmt == SXFIR_CF16) {
             k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>
                 : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 2, false, false, true>
                               : (const void *)sxfir::decim_dense_kernel<32, 0, false, 2, false, false, true>;
@@ -426,7 +443,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         std::vector<float> scaled(taps, taps + ntaps);
         // the layout follows the kernel the plan will launch (the same flags launch_decim / launch_interp branch on),
         // not the shape: a plan whose /8 scalar-tap form was switched off (profiling knobs) keeps the plain table
-        p->tap_table = p->dense_subset ? TAPS_SUBSET8 : (mode == SXFIR_INTERPOLATE && p->ipass) ? TAPS_PASS8 : TAPS_SCALED;
+        p->tap_table = p->blocks ? TAPS_BLOCKS16 : p->dense_subset ? TAPS_SUBSET8 : (mode == SXFIR_INTERPOLATE && p->ipass) ? TAPS_PASS8 : TAPS_SCALED;
         if (p->tap_table == TAPS_SUBSET8) {
             // /8 scalar-tap form (decim_dense_kernel<8, ..., SUBSET>): subset s = 2c + p at 64 s, (jj, rr) at 4 jj + rr
             for (int c = 0; c < 2; ++c)
@@ -435,6 +452,18 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                         for (int rr = 0; rr < 4; ++rr)
                             scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] =
                                 taps[8 * (16 * ph + jj) + 4 * c + rr] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);   // 2^-31: exact
+        } else if (p->tap_table == TAPS_BLOCKS16) {
+            // decim_blocks_kernel: the ROTATED taps (slot k' holds tap (k' + 1) mod ntaps); block b (columns 16 b .. 16 b + 15)
+            // at 512 b, subset s = 2c + p at 64 s inside it, (jj, rr) at 4 jj + rr
+            for (int b = 0; b < p->blocks; ++b)
+                for (int c = 0; c < 4; ++c)
+                    for (int ph = 0; ph < 2; ++ph)
+                        for (int jj = 0; jj < 16; ++jj)
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int slot = ratio * (16 * ph + jj) + 16 * b + 4 * c + rr;
+                                scaled[(size_t)(512 * b + 64 * (2 * c + ph) + 4 * jj + rr)] =
+                                    taps[(slot + 1) % ntaps] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);
+                            }
         } else if (p->tap_table == TAPS_PASS8) {
             for (int c = 0; c < 2; ++c)
                 for (int ph = 0; ph < 2; ++ph)
@@ -556,6 +585,13 @@ int sxfir_contract(const sxfir_plan *p, int *jsplit, int *cw)
     if (!p) return fail(SXFIR_EINVAL, "plan is NULL");
     if (jsplit) *jsplit = p->jsplit;
     if (cw) *cw = p->cw;
+    return SXFIR_OK;
+}
+
+int sxfir_contract_rotation(const sxfir_plan *p, int *rot)
+{
+    if (!p || !rot) return fail(SXFIR_EINVAL, "NULL argument");
+    *rot = p->rot;
     return SXFIR_OK;
 }
 

@@ -16,6 +16,14 @@ KERNEL_AUTO, KERNEL_TILED, KERNEL_GENERIC = 0, 1, 2
 _FMT = {"CF32": CF32, "CF16": CF16, "S32": S32, CF32: CF32, CF16: CF16, S32: S32}
 
 
+class Contract(tuple):
+    """(jsplit, cw) with the rotation beside it: unpacks and compares as the pair it always was."""
+    def __new__(cls, pair, rot=0):
+        self = super().__new__(cls, pair)
+        self.rot = rot
+        return self
+
+
 def check(rc, lib=None):
     _check(rc, lib)
 
@@ -128,9 +136,12 @@ class Resampler:
     # -- introspection --------------------------------------------------------
     @property
     def contract(self):
-        a, b = C.c_int(), C.c_int()
+        """(jsplit, cw) of the plan's numeric contract; the tuple's attribute `rot` is the contract's rotation
+        (sxfir_contract_rotation: 1 for the decimators by 48 and 96, else 0)."""
+        a, b, r = C.c_int(), C.c_int(), C.c_int()
         self._ck(self._lib.sxfir_contract(self._plan, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        self._ck(self._lib.sxfir_contract_rotation(self._plan, C.byref(r)))
+        return Contract((a.value, b.value), r.value)
 
     @property
     def position(self):

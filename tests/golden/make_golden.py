@@ -43,6 +43,11 @@ def make_taps():
         "n256_d8": (256, 8, 1.0),
         "n256_l8": (256, 8, 8.0),
         "n1024_d32": (1024, 32, 1.0),
+        # the reference's two slowest rates (SoapySX.cpp:180-208: dividers 768 and 1536 -> ratios 48 and 96), both directions
+        "n1536_d48": (1536, 48, 1.0),
+        "n3072_d96": (3072, 96, 1.0),
+        "n1536_l48": (1536, 48, 48.0),
+        "n3072_l96": (3072, 96, 96.0),
     }.items():
         out[name] = design(n, r, gain=g)
     np.savez(os.path.join(HERE, "taps.npz"), **out)
@@ -65,6 +70,19 @@ def make_fir(taps):
     h = taps["n256_l8"].astype(np.float64)
     xs = x[:256]
     out["interp_n256_l8"] = signal.upfirdn(h, xs.astype(np.complex128), up=8, down=1)[: 256 * 8]
+    # ratios 48 and 96 on a longer block (their filters are 1536 and 3072 taps long); a generator of its own, so that
+    # the arrays above stay what they were
+    rng2 = np.random.default_rng(0x51255 + 48)
+    n2 = 12288
+    x2 = (rng2.integers(-(2 ** 23), 2 ** 23, size=n2) / 2.0 ** 23
+          + 1j * rng2.integers(-(2 ** 23), 2 ** 23, size=n2) / 2.0 ** 23).astype(np.complex64)
+    out["x_long"] = x2
+    for name, d in (("n1536_d48", 48), ("n3072_d96", 96)):
+        h = taps[name].astype(np.float64)
+        out["decim_" + name] = signal.upfirdn(h, x2.astype(np.complex128), up=1, down=d)[: (n2 + d - 1) // d]
+    for name, l in (("n1536_l48", 48), ("n3072_l96", 96)):
+        h = taps[name].astype(np.float64)
+        out["interp_" + name] = signal.upfirdn(h, x2[:128].astype(np.complex128), up=l, down=1)[: 128 * l]
     # impulse + step edge cases (exact answers: the taps themselves / their prefix sums)
     np.savez(os.path.join(HERE, "fir_kat.npz"), **out)
 

@@ -77,6 +77,10 @@ def _load(name):
     lib.sxo_decim_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp]
     lib.sxo_decim_f32_mt.restype = C.c_int
     lib.sxo_decim_f32_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp, C.c_int]
+    lib.sxo_decim_f32_rot.restype = C.c_int
+    lib.sxo_decim_f32_rot.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp]
+    lib.sxo_decim_f32_rot_mt.restype = C.c_int
+    lib.sxo_decim_f32_rot_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, i64, sz, vp, C.c_int]
     lib.sxo_max_threads.restype = C.c_int
     lib.sxo_f32_to_f16.argtypes = [vp, vp, sz]
     lib.sxo_f16_to_f32.argtypes = [vp, vp, sz]
@@ -156,13 +160,13 @@ class Oracle:
         n_out = (len(x) + D - 1) // D - m0 if n_out is None else n_out
         return self._run(self.lib.sxo_decim_f64, h, D, x, m0, n_out)
 
-    def decim_f32(self, h, D, x, jsplit=1, cw=None, m0=0, n_out=None, threads=None):
-        """Order-matched fp32 decimator; (jsplit, cw) is the kernel's contract."""
+    def decim_f32(self, h, D, x, jsplit=1, cw=None, m0=0, n_out=None, threads=None, rot=0):
+        """Order-matched fp32 decimator; (jsplit, cw) and the rotation (Resampler.contract.rot) are the kernel's contract."""
         n_out = (len(x) + D - 1) // D - m0 if n_out is None else n_out
-        g = (jsplit, D if cw is None else cw)
+        g = (jsplit, D if cw is None else cw, rot)
         if threads is None:
-            return self._run(self.lib.sxo_decim_f32, h, D, x, m0, n_out, groups=g)
-        return self._run(self.lib.sxo_decim_f32_mt, h, D, x, m0, n_out, groups=g, threads=threads)
+            return self._run(self.lib.sxo_decim_f32_rot, h, D, x, m0, n_out, groups=g)
+        return self._run(self.lib.sxo_decim_f32_rot_mt, h, D, x, m0, n_out, groups=g, threads=threads)
 
     def interp_f64(self, h, L, x, n0=0, n_out=None):
         n_out = len(x) * L - n0 if n_out is None else n_out

@@ -41,7 +41,7 @@ def test_tiled_n128_d4_bit_exact(oracle, taps, n_in):
     assert plan.position == (n_in, (n_in + 3) // 4)
 
 
-@pytest.mark.parametrize("ntaps,D", [(128, 4), (64, 4), (256, 8), (1024, 32), (96, 8), (33, 5), (7, 3), (1, 1)])
+@pytest.mark.parametrize("ntaps,D", [(128, 4), (64, 4), (256, 8), (1024, 32), (96, 8), (33, 5), (7, 3), (1, 1), (1536, 48), (3072, 96), (96, 48)])
 def test_generic_bit_exact(oracle, ntaps, D):
     h = sxxcvr_amd.design_lowpass(ntaps, D)
     x = oracle.synth_iq(SEED, 1, 0, 6000)
@@ -49,7 +49,7 @@ def test_generic_bit_exact(oracle, ntaps, D):
     plan.set_kernel(KERNEL_GENERIC)
     js, cw = plan.contract
     y = _run(plan, x)
-    assert_bit_exact(y, oracle.decim_f32(h, D, x, js, cw), "generic %d/%d" % (ntaps, D))
+    assert_bit_exact(y, oracle.decim_f32(h, D, x, js, cw, rot=plan.contract.rot), "generic %d/%d" % (ntaps, D))
 
 
 def test_tiled_and_generic_agree(oracle, taps):
@@ -175,7 +175,7 @@ def test_full_size_properties(oracle, taps):
 
 
 @pytest.mark.parametrize("D,n_in", [(8, 8), (8, 4096), (8, 4096 + 8 * 37), (8, 1 << 19), (16, 1 << 18), (32, 32),
-                                    (32, 4096 * 3 + 32 * 5), (32, 1 << 20)])
+                                    (32, 4096 * 3 + 32 * 5), (32, 1 << 20), (48, 48), (48, 48 * 5461), (96, 96 * 3), (96, 96 * 5461)])
 def test_multi_column_tiled_bit_exact(oracle, D, n_in):
     """decim_multi_kernel: decimate-by-8/16/32 with 32 taps per phase (configs 3 and 5 shapes)."""
     h = sxxcvr_amd.design_lowpass(32 * D, D)
@@ -184,11 +184,13 @@ def test_multi_column_tiled_bit_exact(oracle, D, n_in):
     assert plan.contract == (2, 4)
     plan.set_kernel(KERNEL_TILED)
     y = _run(plan, x)
-    assert_bit_exact(y, oracle.decim_f32(h, D, x, 2, 4), "multi D=%d n_in=%d" % (D, n_in))
+    rot = plan.contract.rot
+    assert rot == (1 if D in (48, 96) else 0)
+    assert_bit_exact(y, oracle.decim_f32(h, D, x, 2, 4, rot=rot), "multi D=%d n_in=%d" % (D, n_in))
     # streaming continuation through the fused history carry-over
     x2 = oracle.synth_iq(SEED, 11, n_in, 4096 * D // 8)
     y2 = _run(plan, x2)
-    both = oracle.decim_f32(h, D, np.concatenate([x, x2]), 2, 4)
+    both = oracle.decim_f32(h, D, np.concatenate([x, x2]), 2, 4, rot=rot)
     assert_bit_exact(y2, both[len(y):], "multi D=%d continuation" % D)
 
 
@@ -294,7 +296,7 @@ def test_history_longer_than_2048_samples(oracle, mode):
         xs = [oracle.synth_iq(SEED, 40 + c, 0, sum(lens)) for c in range(2)]
         plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio, nchan=2)
         js, cw = plan.contract
-        refs = [oracle.decim_f32(h, ratio, x, js, cw) for x in xs]
+        refs = [oracle.decim_f32(h, ratio, x, js, cw, rot=plan.contract.rot) for x in xs]
     else:
         ratio, ntaps = 2, 2 * 2500                      # 2500 rows of history
         h = (np.random.default_rng(9).standard_normal(ntaps) / ntaps).astype(np.float32)

@@ -620,8 +620,8 @@ def test_ratio_follows_sample_rate(oracle):
         dev.deactivateStream(tx)
         dev.closeStream(rx)
         dev.closeStream(tx)
-    # 50 kS/s = master clock / 768 -> ratio 48: twelve column groups, not a power of two, so the plan's
-    # contract is one chain over all taps, (1, 48), and the generic kernel runs it
+    # 50 kS/s = master clock / 768 -> ratio 48: twelve column groups meet in the adjacent-pair tree with an odd level, under
+    # the rotated contract (sxfir_contract_rotation = 1): decim_blocks_kernel, or the generic kernel for ragged calls
     dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 50000.0)
     assert dev.readSetting("RX_DECIM") == "48" and dev.readSetting("RX_NTAPS") == str(32 * 48)
     rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
@@ -629,7 +629,7 @@ def test_ratio_follows_sample_rate(oracle):
     buf = np.zeros(700, dtype=np.complex64)
     assert dev.readStream(rx, [buf], 700).ret == 700
     h = sxxcvr_amd.design_lowpass(32 * 48, 48)
-    assert_bit_exact(buf, oracle.decim_f32(h, 48, oracle.synth_iq(SEED, 0, 0, 700 * 48), 1, 48), "rx at 50 kS/s")
+    assert_bit_exact(buf, oracle.decim_f32(h, 48, oracle.synth_iq(SEED, 0, 0, 700 * 48), 2, 4, rot=1), "rx at 50 kS/s")
     dev.deactivateStream(rx)
     dev.closeStream(rx)
     # 25 kS/s = master clock / 1536 -> ratio 96, 3072 taps: the carried-over history (3072 samples) is longer
@@ -648,7 +648,7 @@ def test_ratio_follows_sample_rate(oracle):
         got[pos:pos + m] = buf
         pos += m
     h = sxxcvr_amd.design_lowpass(32 * 96, 96)
-    assert_bit_exact(got, oracle.decim_f32(h, 96, oracle.synth_iq(SEED, 0, 0, n_out * 96), 1, 96), "rx at 25 kS/s")
+    assert_bit_exact(got, oracle.decim_f32(h, 96, oracle.synth_iq(SEED, 0, 0, n_out * 96), 2, 4, rot=1), "rx at 25 kS/s")
     dev.deactivateStream(rx)
     dev.closeStream(rx)
     with pytest.raises(RuntimeError, match="Unsupported sample rate"):

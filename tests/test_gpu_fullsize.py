@@ -40,10 +40,10 @@ def test_full_size_decimators(oracle, D):
         cnt = min(200, total - m0)
         got = to_cpu(y[m0:m0 + cnt])
         if m0 < 32:
-            ref = oracle.decim_f32(h, D, oracle.synth_iq(SEED, 0, 0, D * (m0 + cnt)), js, cw)[m0:m0 + cnt]
+            ref = oracle.decim_f32(h, D, oracle.synth_iq(SEED, 0, 0, D * (m0 + cnt)), js, cw, rot=plan.contract.rot)[m0:m0 + cnt]
         else:
             w = oracle.synth_iq(SEED, 0, D * m0 - nt, nt + D * cnt)
-            ref = oracle.decim_f32(h, D, w, js, cw)[32:32 + cnt]
+            ref = oracle.decim_f32(h, D, w, js, cw, rot=plan.contract.rot)[32:32 + cnt]
         assert_bit_exact(got, ref, "/%d window at %d" % (D, m0))
     # (2) chunking invariance across an uneven split on an output boundary
     cut = D * (total // 3)
@@ -172,7 +172,7 @@ def test_offsets_beyond_4_gib(oracle, mode, ratio):
         total = n_in // ratio
         for m0 in (total // 2 + 5, total - 150):                      # input byte offsets around 4 GiB and 8 GiB
             w = oracle.synth_iq(SEED, 0, ratio * m0 - nt, nt + ratio * 150)
-            ref = oracle.decim_f32(h, ratio, w, *plan.contract)[32:32 + 150]
+            ref = oracle.decim_f32(h, ratio, w, *plan.contract, rot=plan.contract.rot)[32:32 + 150]
             assert_bit_exact(to_cpu(y[m0:m0 + 150]), ref, "/%d at output %d" % (ratio, m0))
     else:
         for q0 in (n_in // 2 + 3, n_in - 60):                         # output byte offsets around 4 GiB and 8 GiB

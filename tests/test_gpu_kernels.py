@@ -355,7 +355,7 @@ def test_s32_wire_front_and_back_end(oracle):
     assert keyed.any() and (~keyed).any()
 
 
-@pytest.mark.parametrize("D,n_in", [(8, (1 << 16) + 8 * 5), (16, 50000), (32, 4096 * 5 + 32 * 3)])
+@pytest.mark.parametrize("D,n_in", [(8, (1 << 16) + 8 * 5), (16, 50000), (32, 4096 * 5 + 32 * 3), (48, 48 * 512 * 5 + 48 * 3), (96, 96 * 1500)])
 def test_s32_wire_words_through_the_multi_column_kernel(oracle, D, n_in):
     """f-3 at the config 3 / config 5 shapes: the /8, /16, /32 LDS-tiled decimator reads S32_LE I2S wire words
     (convert_rx_buffer, SX.cpp:103-112, inside the kernel).  Bit-exact against oracle conversion + oracle FIR,
@@ -371,7 +371,7 @@ def test_s32_wire_words_through_the_multi_column_kernel(oracle, D, n_in):
         plan = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="S32")
         plan.set_kernel(kern)
         if ref is None:
-            ref = oracle.decim_f32(h, D, oracle.convert_rx(words), *plan.contract)
+            ref = oracle.decim_f32(h, D, oracle.convert_rx(words), *plan.contract, rot=plan.contract.rot)
         wg = to_gpu(words.reshape(-1, 2))
         y1 = to_cpu(plan.process(wg[:n_in].clone()))
         y2 = to_cpu(plan.process(wg[n_in:].clone()))
@@ -423,10 +423,11 @@ def test_every_configuration_against_scipy_fp64(name, mode, ntaps, ratio, fmt):
     assert err <= tol, "%s: max |GPU - scipy fp64| = %.3g > %.3g" % (name, err, tol)
 
 
-@pytest.mark.parametrize("D", [8, 16, 32])
+@pytest.mark.parametrize("D", [8, 16, 32, 48, 96])
 @pytest.mark.parametrize("nchan,pad", [(1, 0), (3, 6)])
 def test_dense_kernel_edges(oracle, D, nchan, pad):
-    """decim_dense_kernel<D> (/8, /16, /32 with 32 taps per phase, linear LDS image) at its seams, with ASYMMETRIC
+    """decim_dense_kernel<D> (/8, /16, /32 with 32 taps per phase, linear LDS image) and decim_blocks_kernel (/48, /96: the
+    reference's two slowest rates, eight-column blocks, tiles of 512 outputs) at their seams, with ASYMMETRIC
     random taps so that a lane that picked the wrong tap, row or column group cannot hide: calls of one output, of one
     tile (512 / 256 / 128 outputs) minus / plus one, of many tiles plus a ragged tail, several channels with a stride
     that is not the block length; history carried from call to call (the first tile of every call reads the previous
@@ -436,7 +437,7 @@ def test_dense_kernel_edges(oracle, D, nchan, pad):
     import torch
     from sxxcvr_amd.resampler import KERNEL_TILED
     h = (np.random.default_rng(D).standard_normal(32 * D) / 64.0).astype(np.float32)
-    T = 4096 // D                                       # outputs per workgroup tile
+    T = 4096 // D if D <= 32 else 512                   # outputs per workgroup tile
     outs = (1, T - 1, T, T + 1, 2, 40 * T + 77, T * 3, 31)
     if nchan > 1:                                       # the tiled kernels take an even output stride between channels
         outs = (2, T - 2, T, T + 2, 2, 40 * T + 78, T * 3, 30)
@@ -463,5 +464,5 @@ def test_dense_kernel_edges(oracle, D, nchan, pad):
             got[c].append(y[c])
         pos += n
     for c in range(nchan):
-        ref = oracle.decim_f32(h, D, xs[c], 2, 4)
+        ref = oracle.decim_f32(h, D, xs[c], 2, 4, rot=plan.contract.rot)
         assert_bit_exact(np.concatenate(got[c]), ref, "dense /%d, channel %d of %d" % (D, c, nchan))

@@ -48,7 +48,7 @@ def test_random_decimator_shapes(oracle, ratio, ntaps, nchan, blocks, pad):
             got[c].append(y[c])
         pos += n
     for c in range(nchan):
-        ref = oracle.decim_f32(h, ratio, xs[c], js, cw)
+        ref = oracle.decim_f32(h, ratio, xs[c], js, cw, rot=plan.contract.rot)
         assert_bit_exact(np.concatenate(got[c]), ref, "decim ratio=%d ntaps=%d chan=%d" % (ratio, ntaps, c))
 
 
@@ -117,7 +117,7 @@ def test_random_decimator_shapes_other_formats(oracle, fmt, ratio, ntaps, nchan,
             got[c].append(y[c])
         pos += n
     for c in range(nchan):
-        ref = oracle.decim_f32(h, ratio, xs[c], js, cw)
+        ref = oracle.decim_f32(h, ratio, xs[c], js, cw, rot=plan.contract.rot)
         if fmt == "CF16":
             want = oracle.f32_to_f16(ref.view(np.float32))
             assert np.array_equal(np.concatenate(got[c]).view(np.uint16), want), "CF16 ratio=%d ntaps=%d" % (ratio, ntaps)

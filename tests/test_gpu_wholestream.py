@@ -64,7 +64,8 @@ def _compare_blocks(got, ref, what):
 
 
 @pytest.mark.parametrize("name,ntaps,ratio", [("config 2", 128, 4), ("config 3 RX", 256, 8), ("decimate by 16", 512, 16),
-                                               ("config 5 CF32", 1024, 32)])
+                                               ("config 5 CF32", 1024, 32), ("master clock / 768: decimate by 48", 1536, 48),
+                                               ("master clock / 1536: decimate by 96", 3072, 96)])
 def test_whole_stream_decimators_cf32(fast_oracle, name, ntaps, ratio):
     import torch
     _enough_memory(8)
@@ -84,9 +85,9 @@ def test_whole_stream_decimators_cf32(fast_oracle, name, ntaps, ratio):
     for s0 in (0, (n // 3) & ~(BLOCK - 1), n - BLOCK):
         assert np.array_equal(x[s0:s0 + BLOCK].cpu().numpy().view(np.uint64), xs[s0:s0 + BLOCK].view(np.uint64)), "source"
     del x
-    ref = orc.decim_f32(h, ratio, xs, *plan.contract, threads=threads).view(np.uint64)
+    ref = orc.decim_f32(h, ratio, xs, *plan.contract, threads=threads, rot=plan.contract.rot).view(np.uint64)
     compared = _compare_blocks(got, ref, name)
-    assert compared == n // ratio
+    assert compared == -(-n // ratio)
     print("%s: %d outputs compared bit for bit" % (name, compared))
 
 
