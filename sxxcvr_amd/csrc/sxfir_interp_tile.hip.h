@@ -74,10 +74,20 @@ struct InterpTile {
 // S32OUT: outputs leave as S32_LE I2S wire words with the keying bits (convert_tx_buffer, SoapySX.cpp:116-137)
 // KEYED: the transmitter-keying count of the call's input is taken from the staged tile (every input sample is in
 // LDS exactly once as a tile's own sample), so a pass that reads its input over PCIe reads it once, not twice
-template <int L, bool S32OUT = false, bool KEYED = false>
+// LT (round 5): the plan's ratio when it is a multiple of L -- x48 and x96 (the reference's rates master clock / 768 and / 1536,
+// SoapySX.cpp:180-208) as LT / 16 PHASE BLOCKS of the x16 kernel.  An interpolator's phases never meet, so block pb -- phases
+// [16 pb, 16 pb + 16) -- is the x16 problem with the taps h[j LT + 16 pb + r] and outputs that lie LT apart per input: every
+// eight lanes of a store instruction then write one whole 128-byte line (an input's sixteen outputs of the block) instead
+// of 64 lanes one kilobyte.  The phase block is the fastest-varying part of the workgroup index (blocks of one tile are
+// dispatched together and complete each other's DRAM pages); the tiny input tile is staged by each of them.
+template <int L, bool S32OUT = false, bool KEYED = false, int LT = L>
 __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 {
     using C = InterpTile<L>;
+    static_assert(LT % L == 0 && (LT == L || L == 16), "phase blocks of the x16 kernel");
+    constexpr int NPB = LT / L;
+    const int pb = NPB == 1 ? 0 : (int)(blockIdx.x % NPB);
+    const int vb = NPB == 1 ? (int)blockIdx.x : (int)(blockIdx.x / NPB);          // workgroup index among a block's
     // input image, then the 512-output (4 KiB) transposition buffer
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::NLOAD * 64 + 256];
     f32x4 *obuf = lds + C::NLOAD * 64;
@@ -96,8 +106,8 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
     f32x2 hp[32];          // 64-bit register pairs for the packed FMAs
 #pragma unroll
     for (int k = 0; k < 32; ++k)
-        hp[k] = (f32x2){a.taps[(16 * p + (k >> 1)) * L + 4 * c + 2 * (k & 1)],
-                        a.taps[(16 * p + (k >> 1)) * L + 4 * c + 2 * (k & 1) + 1]};
+        hp[k] = (f32x2){a.taps[(16 * p + (k >> 1)) * LT + L * pb + 4 * c + 2 * (k & 1)],
+                        a.taps[(16 * p + (k >> 1)) * LT + L * pb + 4 * c + 2 * (k & 1) + 1]};
 
     // window: samples q0 + 4g - 16p - 16 + w, w = 0..19  ->  LDS sample index (+32) 4g - 16p + 16 + w
     const f32x4 *win = lds + (2 * g - 8 * p + 8);
@@ -106,8 +116,8 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
     // workgroups of one XCD (blockIdx % 8; speed only) a contiguous block of them, so that a tile's 32-sample history --
     // its neighbour's tail -- is found in that XCD's L2 (dealt round robin the re-reads went to HBM: 1.014 x the bytes)
     const int NGR = a.n_groups;
-    const int first_tile = (NGR % 8 == 0) ? (int)(blockIdx.x % 8) * (NGR / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    if (first_tile == (a.n_tiles - 1) % NGR && lane < C::HIST) {
+    const int first_tile = (NGR % 8 == 0) ? (vb % 8) * (NGR / 8) + vb / 8 : vb;
+    if (first_tile == (a.n_tiles - 1) % NGR && lane < C::HIST && pb == 0) {
         const long long s = a.n_in - C::HIST + lane;
         const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
                                 : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 
         if constexpr (KEYED) {
             // the tile's own samples are chunks 16 .. 16 + TILE_IN/2 of the image (the 32 before them are history)
-            if (ch == 0 && q0 < a.key_hi && q0 + C::TILE_IN > a.key_lo) {
+            if (ch == 0 && pb == 0 && q0 < a.key_hi && q0 + C::TILE_IN > a.key_lo) {
                 unsigned total = 0;
 #pragma unroll
                 for (int k = 0; k < (C::TILE_IN / 2 + 63) / 64; ++k) {
@@ -216,8 +226,8 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
             obuf[C::swz(oc)] = (f32x4){oi[qi][0], oq[qi][0], oi[qi][1], oq[qi][1]};
             obuf[C::swz(oc) ^ 1] = (f32x4){oi[qi][2], oq[qi][2], oi[qi][3], oq[qi][3]};
         }
-        const long long o0 = (q0 + kt * C::QT) * L;                          // first output of the sub-tile
-        const long long o_end = a.n_in * L;
+        const long long o0 = (q0 + kt * C::QT) * LT + L * pb;               // first output of the sub-tile (of this phase block)
+        const long long o_end = a.n_in * LT;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int oc = 64 * k + lane;
@@ -226,7 +236,8 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
                 const int2 w0 = tx_words(v.x, v.y, a.thr2), w1 = tx_words(v.z, v.w, a.thr2);
                 v = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
             }
-            const long long o = o0 + 2 * oc;
+            // chunk oc of the sub-tile: input oc / (L / 2), chunk oc % (L / 2) of its L outputs
+            const long long o = NPB == 1 ? o0 + 2 * oc : o0 + (long long)(oc / (L / 2)) * LT + 2 * (oc % (L / 2));
             if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
         }
         }   // kt

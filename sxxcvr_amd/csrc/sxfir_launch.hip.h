@@ -401,7 +401,8 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.in_stride = (long long)in_stride;
         t.out_stride = (long long)out_stride;
         t.hist_stride = p->hist_len;
-        const int qt = 4 * 4 * (32 / (p->ratio / 4));          // InterpTile<L>::TILE_IN
+        const int npb = p->ratio > 32 ? p->ratio / 16 : 1;     // x48, x96: phase blocks of the x16 kernel
+        const int qt = 4 * 4 * (32 / ((npb > 1 ? 16 : p->ratio) / 4));          // InterpTile<L>::TILE_IN
         const long long n_tiles = ((long long)n_in + qt - 1) / qt;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
         long long groups = ((long long)p->compute_units * 16 * p->oversub) / p->nchan;
@@ -413,8 +414,19 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.key_counter = key ? key->counter : nullptr;
         t.key_lo = key ? key->lo : 0;
         t.key_hi = key ? key->hi : 0;
-        dim3 grid((unsigned)groups, (unsigned)p->nchan);
-        if (key && p->fmt == SXFIR_S32) {
+        dim3 grid((unsigned)(groups * npb), (unsigned)p->nchan);
+        if (npb > 1) {
+#define SXFIR_IBLOCKS(SS, KK) \
+            do { \
+                if (p->ratio == 48) hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, SS, KK, 48>), grid, dim3(64), 0, st, t); \
+                else hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, SS, KK, 96>), grid, dim3(64), 0, st, t); \
+            } while (0)
+            if (key && p->fmt == SXFIR_S32) SXFIR_IBLOCKS(true, true);
+            else if (key) SXFIR_IBLOCKS(false, true);
+            else if (p->fmt == SXFIR_S32) SXFIR_IBLOCKS(true, false);
+            else SXFIR_IBLOCKS(false, false);
+#undef SXFIR_IBLOCKS
+        } else if (key && p->fmt == SXFIR_S32) {
             switch (p->ratio) {
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true, true>), grid, dim3(64), 0, st, t); break;
 #ifdef SXFIR_PROFILING

@@ -221,9 +221,10 @@ def test_cf16_div4_with_taps_that_are_not_symmetric(oracle):
 
 
 @pytest.mark.parametrize("L,n_in", [(8, 1), (8, 64), (8, 64 * 50 + 7), (8, 1 << 16), (4, 1 << 15), (4, 129), (16, 5000),
-                                    (32, 3333)])
+                                    (32, 3333), (48, 1), (48, 127), (48, 128 * 40 + 5), (96, 128), (96, 3001)])
 def test_tiled_interpolator_bit_exact(oracle, L, n_in):
-    """interp_tile_kernel (interpolate-by-4/8/16/32, 32 taps per phase) vs the oracle, incl. streaming."""
+    """interp_tile_kernel (interpolate-by-4/8/16/32, 32 taps per phase; by 48 and 96 -- the reference's two slowest rates --
+    as phase blocks of the x16 kernel) vs the oracle, incl. streaming."""
     from sxxcvr_amd.resampler import KERNEL_GENERIC, KERNEL_TILED
     h = sxxcvr_amd.design_lowpass(32 * L, L, 8.0, float(L))
     x = oracle.synth_iq(SEED, 13, 0, n_in + 777)
@@ -242,7 +243,8 @@ def test_tiled_interpolator_bit_exact(oracle, L, n_in):
                                                       (4, "CF32", 2, 1 << 15, False), (16, "CF32", 1, 4099, False),
                                                       (32, "S32", 3, 3333, False), (8, "CF32", 1, 3001, True),
                                                       (4, "CF32", 1, 1, False), (8, "CF32", 1, 1 << 18, False),
-                                                      (8, "CF32", 2, 4097, False), (8, "CF32", 1, 127, False), (8, "CF32", 3, 128 * 9, False)])
+                                                      (8, "CF32", 2, 4097, False), (8, "CF32", 1, 127, False), (8, "CF32", 3, 128 * 9, False),
+                                                      (48, "CF32", 1, 2999, False), (96, "S32", 2, 1030, False), (48, "S32", 1, 640, False)])
 def test_interpolator_takes_the_keying_count_in_the_same_pass(oracle, L, fmt, nchan, n_in, generic):
     """sxfir_interpolate_keyed: outputs bit-identical to sxfir_interpolate, and the counter grows by the number of
     channel-0 samples inside the given range whose I word carries the keying bits in the oracle's convert_tx_buffer

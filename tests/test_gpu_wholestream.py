@@ -117,11 +117,13 @@ def test_whole_stream_config4_slice_eight_channels(fast_oracle):
     print("config 4 slice: %d outputs compared bit for bit" % compared)
 
 
-def test_whole_stream_interpolator_config3_tx(fast_oracle):
+@pytest.mark.parametrize("name,ratio", [("config 3 TX", 8), ("master clock / 768: interpolate by 48", 48),
+                                        ("master clock / 1536: interpolate by 96", 96)])
+def test_whole_stream_interpolator_config3_tx(fast_oracle, name, ratio):
     import torch
     _enough_memory(8)
     orc = fast_oracle
-    ratio, ntaps = 8, 256
+    ntaps = 32 * ratio
     n_in = (1 << LOG2N) // ratio
     threads = orc.max_threads()
     h = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, float(ratio))
@@ -136,9 +138,9 @@ def test_whole_stream_interpolator_config3_tx(fast_oracle):
     xs = orc.synth_iq_mt(SEED, 1, 0, n_in, threads)
     assert np.array_equal(x.cpu().numpy().view(np.uint64), xs.view(np.uint64)), "source"
     ref = orc.interp_f32_mt(h, ratio, xs, plan.contract[0], threads=threads).view(np.uint64)
-    compared = _compare_blocks(got, ref, "config 3 TX")
-    assert compared == 1 << LOG2N
-    print("config 3 TX: %d outputs compared bit for bit" % compared)
+    compared = _compare_blocks(got, ref, name)
+    assert compared == n_in * ratio
+    print("%s: %d outputs compared bit for bit" % (name, compared))
 
 
 def test_whole_stream_decimator_cf16_config5(fast_oracle):
