@@ -300,8 +300,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const void *k = nullptr;
         if (p->blocks) {
             const bool w = fmt == SXFIR_S32;
-            k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true> : (const void *)sxfir::decim_blocks_kernel<3, false>)
-                               : (w ? (const void *)sxfir::decim_blocks_kernel<6, true> : (const void *)sxfir::decim_blocks_kernel<6, false>);
+            k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true, true> : (const void *)sxfir::decim_blocks_kernel<3, false, true>)
+                               : (w ? (const void *)sxfir::decim_blocks_kernel<6, true, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true>);
         } else if (p->dense32 && fmt == SXFIR_CF16) {
             k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>
                 : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 2, false, false, true>

@@ -156,6 +156,20 @@ def test_shipped_code_object():
     assert [r["name"] for r in wa] == ["decim4_wide_kernel<0, false, 24, true, false, 0, true, true>"], [r["name"] for r in wa]
     assert wa[0]["vgpr"] <= 256 and wa[0]["typed_lds_dma"] == 68 and wa[0]["v_pk_fma_f32"] == 1024
     assert not [r for r in rows if r["name"].startswith("decim_multi_kernel<")]
+    # /48 and /96 (the reference's 50 kS/s and 25 kS/s rates): sixteen-column blocks of whole input lines, two passes of 512 packed
+    # FMAs per step, every one with a scalar tap; 70 704 B of LDS (two workgroups per CU), 17 DMA instructions per wave and
+    # staging site (two sites), 15 of them non-temporal (the rows no other tile reads); CF32 and wire-word input
+    bk = [r for r in rows if r["name"].startswith("decim_blocks_kernel<")]
+    assert sorted(r["name"] for r in bk) == ["decim_blocks_kernel<%d, %s, true>" % (nb, w) for nb in (3, 6) for w in ("false", "true")], bk
+    for r in bk:
+        assert r["lds_bytes"] == 70704 and r["vgpr"] <= 128 and r["v_pk_fma_f32"] == 1024 and r["scalar_tap_fmas"] == 1024, r
+        assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["s_barrier"] == 4, r
+        assert r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
+    # x48 and x96: phase blocks of the x16 tile kernel (with / without the keying count, CF32 / wire-word output)
+    ib = [r for r in rows if r["name"].startswith("interp_tile_kernel<16, ") and r["name"].rstrip(">").endswith((" 48", " 96"))]
+    assert len(ib) == 8, [r["name"] for r in ib]
+    for r in ib:
+        assert r["lds_bytes"] == 6144 and r["vgpr"] <= 168 and r["v_pk_fma_f32"] >= 256, r       # three waves per SIMD
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<2, ")]
     assert len(ip) == 4, ip                                 # with / without the keying count, CF32 / wire-word output
     for r in ip:

@@ -14,7 +14,7 @@ LOG2N = int(os.environ.get("RB_LOG2N", "28"))
 def run(mode, ratio):
     n_wide = (1 << LOG2N) // (512 * ratio) * (512 * ratio)       # whole tiles of every kernel
     taps = sxxcvr_amd.design_lowpass(32 * ratio, ratio, 8.0, 1.0 if mode == DECIMATE else float(ratio))
-    p = sxxcvr_amd.Resampler(mode, taps, ratio, fmt=fmt)
+    p = sxxcvr_amd.Resampler(mode, taps, ratio, fmt=fmt, profiling=bool(os.environ.get("RB_PROF")))
     dt = {"CF32": torch.complex64, "CF16": torch.int32}[fmt]        # CF16: one 32-bit word (two halves) per sample
     per = 1
     n_in = n_wide if mode == DECIMATE else n_wide // ratio
@@ -36,8 +36,10 @@ def run(mode, ratio):
            n_wide / t / 1e9, byt / t / 8e12), flush=True)
 
 
-for mode in (DECIMATE, INTERPOLATE):
-    for ratio in (4, 8, 16, 32, 48, 96):
+RATIOS = [int(v) for v in os.environ.get("RB_RATIOS", "4,8,16,32,48,96").split(",")]
+MODES = {"rx": (DECIMATE,), "tx": (INTERPOLATE,)}.get(os.environ.get("RB_MODE", ""), (DECIMATE, INTERPOLATE))
+for mode in MODES:
+    for ratio in RATIOS:
         try:
             run(mode, ratio)
         except Exception as e:
