@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X resampling hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3rx|3tx|5|5h]
+    python bench.py --gpus N --steps K --warmup W [--config 2|3rx|3tx|5|5h|rx16|rx48|rx96|tx4|tx16|tx32|tx48|tx96]
 
 One "step" = one streaming pass of the configuration's polyphase FIR (sxfir_decimate / sxfir_interpolate
 through the C ABI: one kernel launch, history carry-over fused) over the rank's resident synthetic IQ block
@@ -63,6 +63,22 @@ CONFIGS = {
                kernel="sxfir::decim_dense_kernel<32, CF16 storage: typed LDS-DMA converts half -> float on the way into the image>",
                name="1024-tap decim-by-32, 1 ch CF16 storage, fp32 arithmetic (BASELINE config 5, fp16 IQ leg)"),
 }
+# The reference's rate table (SoapySX.cpp:180-208: master clock / {64, 128, 256, 512, 768, 1536}; the converters run at master
+# clock / 16, so ratio = divider / 16, 32 taps per phase): the rows the BASELINE configs above do not already cover.  Not
+# bench lines of the driver: `--config rx48` etc. time, verify and profile these kernels the same way.
+for _ratio, _rxk, _txk in ((4, None, "sxfir::interp_tile_kernel<4>"), (16, "sxfir::decim_dense_kernel<16>", "sxfir::interp_tile_kernel<16>"),
+                           (32, None, "sxfir::interp_tile_kernel<32>"),
+                           (48, "sxfir::decim_blocks_kernel<3 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<16, 3 phase blocks>"),
+                           (96, "sxfir::decim_blocks_kernel<6 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<16, 6 phase blocks>")):
+    _khz = 38400.0 / 16 / _ratio
+    if _rxk:
+        CONFIGS["rx%d" % _ratio] = dict(mode="decim", ntaps=32 * _ratio, ratio=_ratio, fmt="CF32", bytes=8 + 8 / _ratio, flop=128, gain=1.0,
+                                        kernel=_rxk, name="%d-tap decim-by-%d RX, 1 ch CF32 streaming (the reference's %g kS/s rate)"
+                                        % (32 * _ratio, _ratio, _khz))
+    CONFIGS["tx%d" % _ratio] = dict(mode="interp", ntaps=32 * _ratio, ratio=_ratio, fmt="CF32", bytes=8 + 8 / _ratio, flop=128,
+                                    gain=float(_ratio), kernel=_txk,
+                                    name="%d-tap interp-by-%d TX, 1 ch CF32 streaming (the reference's %g kS/s rate)"
+                                    % (32 * _ratio, _ratio, _khz))
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -257,9 +273,10 @@ def cpu_baseline(cfg, seconds_target=10.0):
             break
     if cfg["mode"] == "decim":
         js, cw = 2, 4
+        rot = 1 if ratio in (48, 96) else 0                     # the contract's rotation (sxfir_contract_rotation)
 
         def run(x, nthr):
-            orc.decim_f32(taps, ratio, x, js, cw, threads=nthr)
+            orc.decim_f32(taps, ratio, x, js, cw, threads=nthr, rot=rot)
         n_probe, n = 1 << 21, 1 << 26
         wide = lambda m: m                                      # wideband samples per call
     else:
@@ -370,7 +387,7 @@ def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc, base=0
             if cfg["fmt"] == "CF16":
                 xw = orc.f16_to_f32(orc.f32_to_f16(xw.view(np.float32))).view(np.complex64)
             if decim:
-                ref = orc.decim_f32(h, ratio, xw, js, cw, m0=pad // ratio, n_out=win)
+                ref = orc.decim_f32(h, ratio, xw, js, cw, m0=pad // ratio, n_out=win, rot=plan.contract.rot)
             else:
                 ref = orc.interp_f32(h, ratio, xw, js, n0=pad * ratio + (o0 % ratio), n_out=win)
             if cfg["fmt"] == "CF16":
@@ -1026,6 +1043,8 @@ def main():
 
     ratio, ntaps, decim = cfg["ratio"], cfg["ntaps"], cfg["mode"] == "decim"
     wide_per_gpu = 1 << args.log2_samples
+    if ratio & (ratio - 1):
+        wide_per_gpu -= wide_per_gpu % (512 * ratio)         # ratios 48, 96: whole tiles, and a block that ends on an output
     if world == 1:
         nchan_local, total_channels = 1, 1
         workload = "1xMI355X: " + cfg["name"]

@@ -75,7 +75,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             // /48, /96: sixteen-column blocks, scalar taps from the block-major table of the rotated taps
             if (int rc = need_tap_table(p, TAPS_BLOCKS16, "decim_blocks_kernel")) return rc;
             a.taps = p->taps_scaled_dev;
-            // the lines no other tile reads as non-temporal loads: 2-3 % less time (profiles/round5_blocks_ab.txt)
+            // the lines no other tile reads as non-temporal loads: 2-3 % less time (profiles/round5_rates.txt)
 #ifdef SXFIR_PROFILING
             if (getenv("SXFIR_BLOCKS_NT") && !atoi(getenv("SXFIR_BLOCKS_NT")) && p->fmt == SXFIR_CF32) {     // A/B: plain staging loads
                 if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, false>), grid, dim3(256), 0, st, a);

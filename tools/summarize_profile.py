@@ -24,6 +24,11 @@ os.makedirs(dst, exist_ok=True)
 KERNELS = {"2": "decim4_", "3rx": "decim_dense_kernel<8", "3tx": "interp8_pass_kernel", "5": "decim_dense_kernel<32",
            "5h": "decim_dense_kernel<32, 0, false, 0, false, false, true"}
 BYTES = {"2": 10.0, "3rx": 9.0, "3tx": 9.0, "5": 8.25, "5h": 4.125}
+# the reference's other rates (bench.py --config rx16 ... tx96)
+for _r in (4, 16, 32, 48, 96):
+    KERNELS["rx%d" % _r] = "decim_blocks_kernel<%d" % (_r // 16) if _r > 32 else "decim_dense_kernel<%d" % _r
+    KERNELS["tx%d" % _r] = "interp_tile_kernel<16, false, false, %d" % _r if _r > 32 else "interp_tile_kernel<%d" % _r
+    BYTES["rx%d" % _r] = BYTES["tx%d" % _r] = 8.0 + 8.0 / _r
 
 
 def code_object_registers():
@@ -173,6 +178,11 @@ for cfg in configs:
         pm.update({k: sum(v) / len(v) for k, v in acc.items()})
     out["pmc_mean_per_launch"] = pm
     algorithmic = BYTES[cfg] * (1 << 28)
+    try:    # the bench line's own figure (ratios 48 and 96 filter a whole number of tiles, a little under 2^28 samples)
+        _bl = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
+        algorithmic = float(json.loads(_bl[-1])["roofline"]["algorithmic_bytes_per_launch"])
+    except Exception:
+        pass
     out["algorithmic_bytes_per_launch"] = algorithmic
     if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of
