@@ -69,7 +69,7 @@ CONFIGS = {
 for _ratio, _rxk, _txk in ((4, None, "sxfir::interp_tile_kernel<4>"), (16, "sxfir::decim_dense_kernel<16>", "sxfir::interp_tile_kernel<16>"),
                            (32, None, "sxfir::interp_tile_kernel<32>"),
                            (48, "sxfir::decim_blocks_kernel<3 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<16, 3 phase blocks>"),
-                           (96, "sxfir::decim_blocks_kernel<6 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<16, 6 phase blocks>")):
+                           (96, "sxfir::decim_blocks_kernel<6 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<32, 3 phase blocks>")):
     _khz = 38400.0 / 16 / _ratio
     if _rxk:
         CONFIGS["rx%d" % _ratio] = dict(mode="decim", ntaps=32 * _ratio, ratio=_ratio, fmt="CF32", bytes=8 + 8 / _ratio, flop=128, gain=1.0,

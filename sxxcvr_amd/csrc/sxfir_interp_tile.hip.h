@@ -75,16 +75,18 @@ struct InterpTile {
 // KEYED: the transmitter-keying count of the call's input is taken from the staged tile (every input sample is in
 // LDS exactly once as a tile's own sample), so a pass that reads its input over PCIe reads it once, not twice
 // LT (round 5): the plan's ratio when it is a multiple of L -- x48 and x96 (the reference's rates master clock / 768 and / 1536,
-// SoapySX.cpp:180-208) as LT / 16 PHASE BLOCKS of the x16 kernel.  An interpolator's phases never meet, so block pb -- phases
-// [16 pb, 16 pb + 16) -- is the x16 problem with the taps h[j LT + 16 pb + r] and outputs that lie LT apart per input: every
-// eight lanes of a store instruction then write one whole 128-byte line (an input's sixteen outputs of the block) instead
-// of 64 lanes one kilobyte.  The phase block is the fastest-varying part of the workgroup index (blocks of one tile are
-// dispatched together and complete each other's DRAM pages); the tiny input tile is staged by each of them.
+// SoapySX.cpp:180-208) as three PHASE BLOCKS of the x16 and of the x32 kernel.  An interpolator's phases never meet, so block
+// pb -- phases [L pb, L pb + L) -- is the xL problem with the taps h[j LT + L pb + r] and outputs that lie LT apart per input:
+// an input's L outputs of the block are one (x16) or two (x32) whole 128-byte lines, so every store instruction still writes
+// whole lines.  The phase block is the fastest-varying part of the workgroup index (blocks of one tile are dispatched
+// together and complete each other's DRAM pages); the tiny input tile is staged by each of them.  (x96 as six blocks of the
+// x16 kernel: 5 % slower, profiles/round5_rates.txt; phase blocks of eight on the scalar-tap pass kernel -- half-line stores --
+// 20-30 % slower.)
 template <int L, bool S32OUT = false, bool KEYED = false, int LT = L>
 __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 {
     using C = InterpTile<L>;
-    static_assert(LT % L == 0 && (LT == L || L == 16), "phase blocks of the x16 kernel");
+    static_assert(LT % L == 0 && (LT == L || L == 16 || L == 32), "phase blocks of the x16 / x32 kernel");
     constexpr int NPB = LT / L;
     const int pb = NPB == 1 ? 0 : (int)(blockIdx.x % NPB);
     const int vb = NPB == 1 ? (int)blockIdx.x : (int)(blockIdx.x / NPB);          // workgroup index among a block's

@@ -408,8 +408,14 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.in_stride = (long long)in_stride;
         t.out_stride = (long long)out_stride;
         t.hist_stride = p->hist_len;
-        const int npb = p->ratio > 32 ? p->ratio / 16 : 1;     // x48, x96: phase blocks of the x16 kernel
-        const int qt = 4 * 4 * (32 / ((npb > 1 ? 16 : p->ratio) / 4));          // InterpTile<L>::TILE_IN
+        // x48: three phase blocks of the x16 kernel; x96: three of the x32 kernel (two whole lines per input and block; six blocks
+        // of the x16 kernel -- SXFIR_IBLOCK16=1 in the profiling build -- measured 5 % slower, profiles/round5_rates.txt)
+        int base_l = p->ratio == 96 ? 32 : (p->ratio == 48 ? 16 : p->ratio);
+#ifdef SXFIR_PROFILING
+        if (p->ratio == 96 && getenv("SXFIR_IBLOCK16") && atoi(getenv("SXFIR_IBLOCK16")) && !key && p->fmt == SXFIR_CF32) base_l = 16;
+#endif
+        const int npb = p->ratio / base_l;
+        const int qt = 4 * 4 * (32 / (base_l / 4));            // InterpTile<L>::TILE_IN
         const long long n_tiles = ((long long)n_in + qt - 1) / qt;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
         long long groups = ((long long)p->compute_units * 16 * p->oversub) / p->nchan;
@@ -426,8 +432,12 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
 #define SXFIR_IBLOCKS(SS, KK) \
             do { \
                 if (p->ratio == 48) hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, SS, KK, 48>), grid, dim3(64), 0, st, t); \
-                else hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, SS, KK, 96>), grid, dim3(64), 0, st, t); \
+                else hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, SS, KK, 96>), grid, dim3(64), 0, st, t); \
             } while (0)
+#ifdef SXFIR_PROFILING
+            if (base_l == 16 && p->ratio == 96) hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, false, 96>), grid, dim3(64), 0, st, t);
+            else
+#endif
             if (key && p->fmt == SXFIR_S32) SXFIR_IBLOCKS(true, true);
             else if (key) SXFIR_IBLOCKS(false, true);
             else if (p->fmt == SXFIR_S32) SXFIR_IBLOCKS(true, false);

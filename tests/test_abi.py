@@ -165,11 +165,11 @@ def test_shipped_code_object():
         assert r["lds_bytes"] == 70704 and r["vgpr"] <= 128 and r["v_pk_fma_f32"] == 1024 and r["scalar_tap_fmas"] == 1024, r
         assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["s_barrier"] == 4, r
         assert r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
-    # x48 and x96: phase blocks of the x16 tile kernel (with / without the keying count, CF32 / wire-word output)
-    ib = [r for r in rows if r["name"].startswith("interp_tile_kernel<16, ") and r["name"].rstrip(">").endswith((" 48", " 96"))]
-    assert len(ib) == 8, [r["name"] for r in ib]
+    # x48 and x96: three phase blocks of the x16 / of the x32 tile kernel (with / without the keying count, CF32 / wire-word output)
+    ib = [r for r in rows if r["name"].startswith("interp_tile_kernel<") and r["name"].rstrip(">").endswith((" 48", " 96"))]
+    assert sorted(r["name"].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ib) == ["interp_tile_kernel<16 48>"] * 4 + ["interp_tile_kernel<32 96>"] * 4, ib
     for r in ib:
-        assert r["lds_bytes"] == 6144 and r["vgpr"] <= 168 and r["v_pk_fma_f32"] >= 256, r       # three waves per SIMD
+        assert r["lds_bytes"] <= 6144 and r["vgpr"] <= 168 and r["v_pk_fma_f32"] >= 256, r       # three waves per SIMD
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<2, ")]
     assert len(ip) == 4, ip                                 # with / without the keying count, CF32 / wire-word output
     for r in ip:
