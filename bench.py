@@ -399,6 +399,50 @@ def verify(cfg, plan, x, y, n_in, first_channel, history_from_block, orc, base=0
     return ok, compared
 
 
+def rate_table(orc, dev, log2n=28, launches=40):
+    """Every rate of the reference's table (SoapySX.cpp:180-208: master clock / {64 .. 1536}; ratio = divider / 16, 32 taps per
+    phase), RX and TX: each plan filters a block of the synthetic stream once from a reset and is checked against the oracle
+    (three windows), then its kernel is timed over `launches` back-to-back passes with events on the launch stream.  Reported
+    beside `value`, never part of it: fewer launches than the headline's and no settling phase, so a coarser figure."""
+    import torch
+    import sxxcvr_amd
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE
+    rows, ok_all = {}, True
+    for mode in ("decim", "interp"):
+        for ratio in (4, 8, 16, 32, 48, 96):
+            ntaps = 32 * ratio
+            wide = (1 << log2n) - (1 << log2n) % (512 * ratio)
+            cfg = dict(mode=mode, ntaps=ntaps, ratio=ratio, fmt="CF32", gain=1.0 if mode == "decim" else float(ratio))
+            taps = sxxcvr_amd.design_lowpass(ntaps, ratio, 8.0, cfg["gain"])
+            plan = sxxcvr_amd.Resampler(DECIMATE if mode == "decim" else INTERPOLATE, taps, ratio)
+            n_in = wide if mode == "decim" else wide // ratio
+            n_out = wide // ratio if mode == "decim" else wide
+            x = torch.empty(n_in, dtype=torch.complex64, device=dev)
+            sxxcvr_amd.synth_fill(x, SEED, first_channel=0, start=0, fmt="CF32")
+            y = torch.empty(n_out, dtype=torch.complex64, device=dev)
+            plan.process(x, out=y)
+            torch.cuda.synchronize()
+            ok, compared = verify(cfg, plan, x, y, n_in, 0, False, orc)
+            ok_all = ok_all and ok
+            for _ in range(30):
+                plan.process(x, out=y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(launches):
+                plan.process(x, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / launches
+            byt = (8 + 8 / ratio) * wide
+            rows[("rx" if mode == "decim" else "tx") + str(ratio)] = {
+                "ms_per_2^28": round(ms * (1 << 28) / wide, 4), "frac_of_8TBs": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "verified": bool(ok), "outputs_compared": compared}
+            del plan, x, y
+    return {"note": "every rate of the reference's table (ratio = divider / 16, 32 taps per phase), kernel time scaled to 2^28 wideband "
+                    "samples from 2^%d-sample blocks, %d launches each; bit-exact windows against the oracle; never part of value" % (log2n, launches),
+            "verified": ok_all, "rows": rows}
+
+
 def through_device():
     """API-parity figures through the SoapySDR-style Device (readStream / writeStream incl. PCIe, staging and
     launch overheads), decimate-by-4 / interpolate-by-4 at 600 kS/s; never part of `value`."""
@@ -963,6 +1007,7 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=28, help="wideband-side samples per GPU (log2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-through-device", action="store_true")
+    ap.add_argument("--no-rate-table", action="store_true", help="skip the table of the reference's other rates (config 2 only)")
     ap.add_argument("--gather", default="torch", choices=["torch", "capi"],
                     help="N > 1: the gather of the decimated output through torch.distributed (nccl = RCCL) or through the "
                          "C ABI (sxfir_comm_gather over librccl directly)")
@@ -1335,6 +1380,11 @@ def main():
                 line["through_device"] = through_device()
             except Exception as e:                               # reported beside the value, never able to take it down
                 line["through_device"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and args.config == "2" and not args.no_rate_table and not args.asymmetric_taps:
+            try:
+                line["rate_table"] = rate_table(orc, dev, log2n=args.log2_samples)
+            except Exception as e:
+                line["rate_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline:
             # rank 0's host cores, at every N: a SCALE line at N > 1 is self-contained
             line["cpu_baseline"] = cpu_baseline(cfg)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "3", "--warmup", "2", "--settle", "4", "--log2-samples", "22", "--no-cpu-baseline",
-         "--no-through-device", "--alone-seconds", "0.05"]
+         "--no-through-device", "--no-rate-table", "--alone-seconds", "0.05"]
 
 
 def check_multi_rank_fields(line, world, backend):
@@ -61,7 +61,7 @@ def run_bench(extra, env=None, timeout=600):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("config", ["2", "3rx", "3tx", "5", "5h"])
+@pytest.mark.parametrize("config", ["2", "3rx", "3tx", "5", "5h", "rx16", "rx48", "rx96", "tx4", "tx16", "tx32", "tx48", "tx96"])
 def test_bench_line_every_config(config):
     line = run_bench(["--config", config] + SMALL)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -83,6 +83,20 @@ def test_bench_line_every_config(config):
         < 0.02 * r["frac_back_to_back_after_idle"]
     assert r["frac_while_sampled"] is None or r["frac_while_sampled"] > 0
     assert line["config"]["gpus"] and line["config"]["distinct_gpus"] == 1 and line["config"]["gpu_arch"].startswith("gfx950")
+
+
+def test_bench_line_carries_the_table_of_the_references_rates():
+    """The default line (config 2) reports every rate of the reference's table beside the value: twelve rows, each checked
+    against the oracle before it is timed."""
+    line = run_bench([a for a in SMALL if a != "--no-rate-table"])
+    t = line["rate_table"]
+    assert "error" not in t and t["verified"] is True, t
+    assert sorted(t["rows"]) == sorted(d + str(r) for d in ("rx", "tx") for r in (4, 8, 16, 32, 48, 96))
+    for name, row in t["rows"].items():
+        assert row["verified"] is True and row["outputs_compared"] >= 2048 and row["ms_per_2^28"] > 0, (name, row)
+    # the two slowest rates run LDS-tiled kernels like the others (they ran the generic kernels, 80 x slower, until round 5)
+    assert t["rows"]["rx96"]["ms_per_2^28"] < 4 * t["rows"]["rx32"]["ms_per_2^28"]
+    assert t["rows"]["tx96"]["ms_per_2^28"] < 4 * t["rows"]["tx32"]["ms_per_2^28"]
 
 
 def test_bench_times_the_kernel_of_non_symmetric_taps():

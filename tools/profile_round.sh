@@ -12,9 +12,9 @@ export TMPDIR=/tmp
 for C in $CONFIGS; do
   OUT=$R/gpurun_out/$TAG/$C
   mkdir -p $OUT
-  ARGS="bench.py --config $C --steps 50 --warmup 50 --no-cpu-baseline --no-through-device"
+  ARGS="bench.py --config $C --steps 50 --warmup 50 --no-cpu-baseline --no-through-device --no-rate-table"
   rocm-smi --showbus --showuniqueid --showserial > $OUT/box.txt 2>&1
-  python3 bench.py --config $C --no-cpu-baseline --no-through-device > $OUT/bench.json 2> $OUT/bench.err
+  python3 bench.py --config $C --no-cpu-baseline --no-through-device --no-rate-table > $OUT/bench.json 2> $OUT/bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
