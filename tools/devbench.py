@@ -4,9 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sxxcvr_amd.soapy as SoapySDR
+RATE = float(os.environ.get("DB_RATE", "600000"))          # any rate of the reference's table: 600e3 .. 25e3 (decim = interp = auto)
 for blk in (256, 4096, 65536, 1 << 20):
-    dev = SoapySDR.Device({"driver": "sx", "clock": "virtual"})
-    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 600000.0)
+    dev = SoapySDR.Device({"driver": "sx", "clock": "virtual", "decim": "auto", "interp": "auto"})
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, RATE)
+    dev.setSampleRate(SoapySDR.SOAPY_SDR_TX, 0, RATE)
+    ratio = int(dev.readSetting("RX_DECIM"))
     rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CF32", [0], {"period": str(min(blk, 65536))})
     tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(min(blk, 65536))})
     dev.activateStream(rx); dev.activateStream(tx)
@@ -23,5 +26,5 @@ for blk in (256, 4096, 65536, 1 << 20):
         r = dev.writeStream(tx, [buf], blk)
         assert r.ret == blk, r
     dt_tx = (time.perf_counter() - t0) / n
-    print("block %8d: readStream %.1f us/call = %.2f MS/s out (%.2f MS/s wideband in) | writeStream %.1f us/call = %.2f MS/s" % (
-        blk, dt_rx * 1e6, blk / dt_rx / 1e6, 4 * blk / dt_rx / 1e6, dt_tx * 1e6, blk / dt_tx / 1e6))
+    print("rate %g (ratio %d) block %8d: readStream %.1f us/call = %.2f MS/s out (%.2f MS/s wideband in) | writeStream %.1f us/call = %.2f MS/s" % (
+        RATE, ratio, blk, dt_rx * 1e6, blk / dt_rx / 1e6, ratio * blk / dt_rx / 1e6, dt_tx * 1e6, blk / dt_tx / 1e6))
