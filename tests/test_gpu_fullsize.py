@@ -148,7 +148,7 @@ def test_full_size_eight_channels(oracle):
         assert_bit_exact(to_cpu(y[c, :300]), ref, "channel %d" % c)
 
 
-@pytest.mark.parametrize("mode,ratio", [("decim", 4), ("decim", 32), ("interp", 8)])
+@pytest.mark.parametrize("mode,ratio", [("decim", 4), ("decim", 32), ("interp", 8), ("decim", 48), ("decim", 96), ("interp", 48), ("interp", 96)])
 def test_offsets_beyond_4_gib(oracle, mode, ratio):
     """One call over a buffer four times the benchmark's (2^30 wide-rate samples = 8 GiB): byte offsets no
     longer fit 32 bits anywhere in the stream.  The last outputs must still be the oracle's."""
