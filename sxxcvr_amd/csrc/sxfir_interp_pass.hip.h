@@ -48,16 +48,19 @@ namespace sxfir {
 // QI = inputs per lane: 4 (tile of 256 inputs, 16 KiB of outputs, 8 waves per CU -- the form described above) or 2 (tile
 // of 128 inputs, 8 KiB of outputs, 10 KB of LDS: 16 waves per CU when the registers allow, at 17 instead of 18 window
 // reads per HALF as many FMAs).
-template <int QI>
+// L = 8 (two phase groups, four passes) or, round 5, L = 4 (one phase group, two passes; four inputs per lane: a lane's sixteen
+// outputs are one 128-byte line, and 18 window reads serve 512 packed FMAs -- with two inputs per lane they would serve 256).
+template <int QI, int LL = 8>
 struct InterpPass8 {
     static_assert(QI == 2 || QI == 4, "inputs per lane");
-    static constexpr int L = 8;
+    static_assert(LL == 8 || (LL == 4 && QI == 4), "x8, or x4 with four inputs per lane");
+    static constexpr int L = LL;
     static constexpr int TILE_IN = 64 * QI;               // inputs per tile
     static constexpr int HIST = 32;
     static constexpr int CHUNKS = (TILE_IN + HIST) / 2;   // staged chunks: samples [q0 - 32, q0 + TILE_IN)
     static constexpr int NLOAD = (CHUNKS + 63) / 64;      // DMA instructions
     static constexpr int IMG = NLOAD * 64;
-    static constexpr int CPL = 4 * QI;                    // output chunks per lane (QI inputs x 8 outputs x 8 bytes / 16)
+    static constexpr int CPL = QI * LL / 2;               // output chunks per lane (QI inputs x L outputs x 8 bytes / 16)
     static constexpr int OBUF = 64 * CPL;                 // output chunks per tile
     static constexpr int NW = (QI + 16) / 2;              // window chunks of one pass
     static constexpr int NWU = NW + 8;                    // ... of both row halves together (the lane reads these once)
@@ -106,10 +109,10 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
 // instead of the counted form below -- slower, and free of the counted form's premises (exactly CPL stores behind the
 // next tile's DMAs, no other VMEM instruction between them); tests/test_gpu_variants.py holds the two bit-identical,
 // tests/test_abi.py::test_shipped_code_object checks the premises in the shipped disassembly.
-template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true>
+template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true, int LL = 8>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {
-    using C = InterpPass8<QI>;
+    using C = InterpPass8<QI, LL>;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::IMG + C::OBUF];
     f32x4 *obuf = lds + C::IMG;
 
@@ -190,7 +193,8 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         // s_waitcnt vmcnt counts loads and stores together, in issue order: with the next tile's three DMAs issued
         // BEFORE this tile's sixteen stores, "at most 16 outstanding" means the DMAs have landed
         if (COUNTED && counted) {
-            if constexpr (QI == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            static_assert(C::CPL == 16 || C::CPL == 8, "stores per tile behind the next tile's DMAs");
+            if constexpr (C::CPL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -235,9 +239,9 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         counted = false;
         if (next < a.n_tiles) counted = stage(next);
 
-        // ---- four passes: phase group c (outer), row half p (inner)
+        // ---- four passes (x4: two): phase group c (outer), row half p (inner)
 #pragma unroll 1
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < C::L / 4; ++c) {
             f32x2 y[QI][4];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -257,10 +261,10 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
                         else y[qi][rr] = (f32x2){__fadd_rn(y[qi][rr].x, acc[qi][rr].x), __fadd_rn(y[qi][rr].y, acc[qi][rr].y)};
                     }
             }
-            // phases 4c..4c+3 of the lane's inputs: chunks k = 4 qi + 2c + {0, 1} of its CPL
+            // phases 4c..4c+3 of the lane's inputs: chunks k = (L / 2) qi + 2c + {0, 1} of its CPL
 #pragma unroll
             for (int qi = 0; qi < QI; ++qi) {
-                const int k = 4 * qi + 2 * c;
+                const int k = (C::L / 2) * qi + 2 * c;
                 obuf[C::CPL * lane + (k ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][0].x, y[qi][0].y, y[qi][1].x, y[qi][1].y};
                 obuf[C::CPL * lane + ((k + 1) ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][2].x, y[qi][2].y, y[qi][3].x, y[qi][3].y};
             }

@@ -378,6 +378,13 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.key_lo = key ? key->lo : 0;
         t.key_hi = key ? key->hi : 0;
         const dim3 pgrid((unsigned)groups, (unsigned)p->nchan);
+        if (p->ratio == 4) {
+            // x4: four inputs per lane, two passes
+            if (p->fmt == SXFIR_S32 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true, true, true, 4>), pgrid, dim3(64), 0, st, t);
+            else if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, false, true, true, 4>), pgrid, dim3(64), 0, st, t);
+            else if (key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true, false, true, 4>), pgrid, dim3(64), 0, st, t);
+            else hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, false, false, true, 4>), pgrid, dim3(64), 0, st, t);
+        } else
 #ifdef SXFIR_PROFILING
         if (p->ipass_qi == 4 && p->fmt == SXFIR_S32) return fail(SXFIR_EUNSUPPORTED, "four inputs per lane: CF32 only");
         else if (p->ipass_qi == 4 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true>), pgrid, dim3(64), 0, st, t);
@@ -445,7 +452,11 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
 #undef SXFIR_IBLOCKS
         } else if (key && p->fmt == SXFIR_S32) {
             switch (p->ratio) {
+#ifdef SXFIR_PROFILING
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 4: return fail(SXFIR_EUNSUPPORTED, "x4 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
 #ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true, true>), grid, dim3(64), 0, st, t); break;
 #else
@@ -456,7 +467,11 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
             }
         } else if (key) {
             switch (p->ratio) {
+#ifdef SXFIR_PROFILING
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, false, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 4: return fail(SXFIR_EUNSUPPORTED, "x4 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
 #ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, false, true>), grid, dim3(64), 0, st, t); break;
 #else
@@ -467,7 +482,11 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
             }
         } else if (p->fmt == SXFIR_S32) {
             switch (p->ratio) {
+#ifdef SXFIR_PROFILING
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, true>), grid, dim3(64), 0, st, t); break;
+#else
+            case 4: return fail(SXFIR_EUNSUPPORTED, "x4 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
 #ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, true>), grid, dim3(64), 0, st, t); break;
 #else
@@ -478,7 +497,11 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
             }
         } else {
             switch (p->ratio) {
+#ifdef SXFIR_PROFILING
             case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4>), grid, dim3(64), 0, st, t); break;
+#else
+            case 4: return fail(SXFIR_EUNSUPPORTED, "x4 runs interp8_pass_kernel");   // (unreachable: p->ipass)
+#endif
 #ifdef SXFIR_PROFILING
             case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8>), grid, dim3(64), 0, st, t); break;
 #else

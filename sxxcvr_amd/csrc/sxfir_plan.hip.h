@@ -247,12 +247,22 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // (64 taps and the DMA offset table per lane) is heavier than the tile kernel's, 8 beats 16; the
     // interpolator is flat between 2 and 16 (tools/ibench.py)
     if (p->multi_capable) p->oversub = 8;
-    if (p->itile_capable) p->oversub = 4;
+    if (p->itile_capable) p->oversub = ratio > 32 ? 2 : 4;     // (x48, x96: 2 measured 1-2 % ahead of 4 .. 32, profiles/round5_rates.txt)
     if (p->itile_capable && ratio == 8 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
         p->ipass = true;
         p->oversub = 8;                                 // measured (tools/ibench2.py): 4 / 8 / 16 generations within 0.3 %
         int nbi = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<2>, 64, 0) == hipSuccess && nbi > 0)
+            p->occ_ipass = nbi;
+    }
+    // x4, 128 taps (round 5): the same scalar-tap pass form with four inputs per lane (two passes; a lane's sixteen outputs are
+    // one line)
+    if (p->itile_capable && ratio == 4 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
+        p->ipass = true;
+        p->ipass_qi = 4;
+        p->oversub = 8;
+        int nbi = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<4, false, false, true, 4>, 64, 0) == hipSuccess && nbi > 0)
             p->occ_ipass = nbi;
     }
 #ifdef SXFIR_PROFILING
@@ -267,7 +277,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     if (const char *v = getenv("SXFIR_DENSE")) p->dense32 = p->dense32 && atoi(v) != 0;
     if (const char *v = getenv("SXFIR_IPASS")) {     // 0: interp_tile_kernel at x8 too (A/B); 4: four inputs per lane
         p->ipass = p->ipass && atoi(v) != 0;
-        if (p->ipass && atoi(v) == 4) {
+        if (p->ipass && atoi(v) == 4 && ratio == 8) {
             p->ipass_qi = 4;
             int nbi = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<4>, 64, 0) == hipSuccess && nbi > 0)
@@ -466,11 +476,11 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                     taps[(slot + 1) % ntaps] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);
                             }
         } else if (p->tap_table == TAPS_PASS8) {
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < ratio / 4; ++c)                 // x8: two phase groups; x4: one
                 for (int ph = 0; ph < 2; ++ph)
                     for (int jj = 0; jj < 16; ++jj)
                         for (int rr = 0; rr < 4; ++rr)
-                            scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] = taps[(16 * ph + jj) * 8 + 4 * c + rr];
+                            scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] = taps[(16 * ph + jj) * ratio + 4 * c + rr];
         } else {
             for (float &t : scaled) t *= 4.656612873077393e-10f;      // 2^-31: exact
         }

@@ -170,12 +170,15 @@ def test_shipped_code_object():
     assert sorted(r["name"].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ib) == ["interp_tile_kernel<16 48>"] * 4 + ["interp_tile_kernel<32 96>"] * 4, ib
     for r in ib:
         assert r["lds_bytes"] <= 6144 and r["vgpr"] <= 168 and r["v_pk_fma_f32"] >= 256, r       # three waves per SIMD
-    ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<2, ")]
-    assert len(ip) == 4, ip                                 # with / without the keying count, CF32 / wire-word output
+    # the scalar-tap pass kernel: x8 (two inputs per lane, four passes) and, round 5, x4 (four inputs per lane, two passes)
+    ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<")]
+    assert sorted(r["name"].split("<")[1].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ip) == ["2 8>"] * 4 + ["4 4>"] * 4, ip
     for r in ip:
-        wire = r["name"].rstrip(">").endswith("true")            # <QI, KEYED, S32OUT>: the wire-word conversion holds more masks
-        assert r["vgpr"] <= 128 and r["lds_bytes"] == 10240 and r["v_pk_fma_f32"] == 256, r
-        assert r["sgpr_spill_lane_ops"] <= (40 if wire else 8), r
+        targs = [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")]      # <QI, KEYED, S32OUT, COUNTED, L>
+        wire, x4 = targs[2] == "true", targs[4] == "4"               # the wire-word conversion holds more masks
+        assert targs[3] == "true", r                                 # the counted form ships
+        assert r["vgpr"] <= (168 if x4 else 128) and r["lds_bytes"] == (11264 if x4 else 10240) and r["v_pk_fma_f32"] == (512 if x4 else 256), r
+        assert r["sgpr_spill_lane_ops"] <= (72 if wire else 16), r
         # the counted wait (s_waitcnt vmcnt(8), sxfir_interp_pass.hip.h): safe only if the tile loop issues the next tile's
         # image DMAs, then exactly eight stores and nothing else that counts as VMEM -- no scratch access (checked above), no
         # load, and the keying count's atomic in FRONT of the DMAs.  Read off the shipped disassembly:
@@ -184,5 +187,5 @@ def test_shipped_code_object():
         assert cw["dma_loads"] >= 2 and cw["atomics_after_first_dma"] == 0, r
         assert cw["last_block_vmem"] == ["global_store_dwordx4"] * 8, r          # the full-tile path that loops back
         assert cw["non_store_vmem_after_last_dma"] == [], r
-    keyed = [r for r in ip if "<2, true" in r["name"]]
-    assert len(keyed) == 2
+    keyed = [r for r in ip if "<2, true" in r["name"] or "<4, true" in r["name"]]
+    assert len(keyed) == 4

@@ -199,6 +199,31 @@ def test_x8_interpolator_forms_match_oracle(oracle, monkeypatch, ipass, oversub)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ipass,oversub", [("0", "4"), ("0", "16"), ("1", "1"), ("1", "8"), ("1", "16")])
+def test_x4_interpolator_forms_match_oracle(oracle, monkeypatch, ipass, oversub):
+    """x4, 128 taps: interp8_pass_kernel<4 inputs per lane, L = 4> (scalar taps, two passes: shipped since round 5) and
+    interp_tile_kernel<4> (taps in VGPRs, SXFIR_IPASS=0: its A/B partner) give the oracle's bits: streaming over three calls --
+    a first tile that takes its history from the plan, interior tiles with the prefetch and its counted wait, a ragged
+    last tile -- and several channels."""
+    for k in KNOBS + ("SXFIR_IPASS", "SXFIR_IPASS_WAIT0"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_IPASS", ipass)
+    monkeypatch.setenv("SXFIR_OVERSUB", oversub)
+    h = sxxcvr_amd.design_lowpass(128, 4, 8.0, 4.0)
+    nchan, lens = 2, [256 * 300 + 77, 5, 256 * 64 + 130]
+    x = np.stack([oracle.synth_iq(0x51255, 33 + c, 0, sum(lens)) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, 4, nchan=nchan, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        outs.append(to_cpu(plan.process(to_gpu(np.ascontiguousarray(x[:, pos:pos + n])))))
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert_bit_exact(y[c], oracle.interp_f32(h, 4, x[c], 2), "x4 form %s channel %d" % (ipass, c))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("subset", ["1", "0"])
 @pytest.mark.parametrize("nchan,lens", [(1, [512 * 40 + 8 * 3, 8 * 5, 512 * 9]), (3, [512 * 7 + 8 * 77, 1 << 17])])
 def test_div8_forms_match_oracle(oracle, monkeypatch, nchan, lens, subset):
