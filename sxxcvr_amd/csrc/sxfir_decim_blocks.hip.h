@@ -1,4 +1,4 @@
-// Decimate-by-48 and -by-96, 32 taps per phase (1536 / 3072 taps), CF32 or S32 wire words: the two slowest rates of the
+// Decimate-by-48 and -by-96, 32 taps per phase (1536 / 3072 taps), CF32, S32 wire words or CF16 storage: the two slowest rates of the
 // reference's table (SoapySX.cpp:180-208: master clock / 768 and / 1536; the device's converters run at master clock / 16,
 // so the ratio is divider / 16).  New code: the reference programs the SX1255's own decimator for these rates (:1192-1208).
 //
@@ -59,13 +59,21 @@ struct DecimBlocks16 {
 };
 
 // NB = blocks per row (3: /48, 6: /96).  NTLD: the lines no other tile reads (image rows 32 .. 511) as non-temporal loads.
-template <int NB, bool S32IN = false, bool NTLD = false>
+// HALFIN: CF16 storage (IQ as half pairs in HBM, fp32 arithmetic, outputs rounded to half once) through the typed LDS-DMA front
+// end of decim_dense_kernel<.., HALFIN>: the image is the same CF32 image, the texture path converts on the way in.  One
+// buffer_load_format_x ... lds moves two rows of the block (lanes 0-31: the 32 halves of row r, lanes 32-63: of row r + 1; 64
+// floats = 16 slots): four per 128-byte-line instruction of the CF32 form.  A block's piece of a row is 64 bytes here -- half a
+// line, the other half the neighbouring block's -- so each line crosses the L2's memory side twice: the bytes of the CF32 form,
+// not half of them (the kernel is arithmetic-bound at either).
+template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false>
 __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs a)
 {
     static_assert(NB == 3 || NB == 6, "ratios 48 and 96");
+    static_assert(!(HALFIN && S32IN), "one storage format");
     using C = DecimBlocks16;
     constexpr int D = 16 * NB;
     constexpr int NT = 32 * D;
+    constexpr int SB = HALFIN ? 4 : 8;                  // bytes per complex sample in HBM
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::LDS_SLOTS];
 
     const int tid = threadIdx.x;
@@ -75,8 +83,8 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     const int G = lane;                                 // output group of the lane
     const int ch = blockIdx.y;
 
-    const char *in = reinterpret_cast<const char *>(a.in) + 8ll * a.in_stride * ch;
-    char *out = reinterpret_cast<char *>(a.out) + 8ll * a.out_stride * ch;
+    const char *in = reinterpret_cast<const char *>(a.in) + (long long)SB * a.in_stride * ch;
+    char *out = reinterpret_cast<char *>(a.out) + (long long)SB * a.out_stride * ch;
     const __attribute__((address_space(4))) f32x2 *tq = (const __attribute__((address_space(4))) f32x2 *)a.taps;
 
     // Window of pass A: rows 8u .. 8u + 22 of the image (u = G + 2 - 2p), chunks CPR - 2 - 2 c0 + {0, 1} of each; slot = chunk
@@ -103,11 +111,13 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     auto tile_of = [&](int r) __attribute__((always_inline)) { return r < R ? r * NG + perm : R * NG + (int)blockIdx.x; };
     // fused history carry-over (by the owner of the call's last tile): the tail of (hist ++ in) becomes the next history
     if ((rem ? (int)blockIdx.x == rem - 1 : perm == NG - 1) && ww == C::W - 1) {
-        float2 *ho = reinterpret_cast<float2 *>(a.hist_out) + a.hist_stride * ch;
-        const float2 *hi = reinterpret_cast<const float2 *>(a.hist) + a.hist_stride * ch;
+        char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)SB * a.hist_stride * ch;
+        const char *hi = reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch;
         for (int j = lane; j < NT; j += 64) {
             const long long s = a.n_in - NT + j;
-            ho[j] = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : hi[s + NT];
+            const char *src = s >= 0 ? in + SB * s : hi + SB * (s + NT);
+            if constexpr (HALFIN) reinterpret_cast<unsigned *>(ho)[j] = *reinterpret_cast<const unsigned *>(src);
+            else reinterpret_cast<float2 *>(ho)[j] = *reinterpret_cast<const float2 *>(src);
         }
     }
 
@@ -121,10 +131,44 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     // HBM -> LDS for one (tile, block) step: instruction i = ww + 4 i0 moves image rows [8 i, 8 i + 8) -- eight lines, D
     // samples apart -- to the slots from 65 i on.  Block b's line of aligned row q is samples D q - 16 (b + 1) .. D q - 16 b - 1.
     const unsigned lane_off = (unsigned)(8 * D) * (unsigned)(lane >> 3) + 16u * (unsigned)(lane & 7);
+    // (HALFIN) LDS byte address of the wave's first staging slot, a scalar: M0 of the typed DMA = this + a constant
+    const unsigned lds_wave_base = HALFIN ? __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + 65 * ww)) : 0u;
     auto stage = [&](int tile, int blk) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         const long long s_first = D * (M0 - 31) - 16 * (blk + 1);         // first sample of the block image
         const bool interior = tile >= 1 && tile <= tile_hi;
+        if constexpr (HALFIN) {
+            if (interior) {
+                // the descriptor is based at the wave's first byte of THIS step (64-bit base, rebuilt per step from scalars), so
+                // every offset is a small constant and a call may be as long as it likes; {DATA_FORMAT 16, NUM_FORMAT FLOAT, X <- R}
+                const unsigned long long wb = (unsigned long long)(in + SB * s_first + (SB * D * C::RPI) * ww);
+                v4i32 rs;
+                rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+                rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(wb >> 32)) & 0xffff;    // stride 0
+                rs.z = 1 << 20;                                                               // bytes addressable from the base
+                rs.w = 4 | (7 << 12) | (2 << 15);
+                // lanes 0-31: the 32 halves of a row's piece, lanes 32-63: of the next row's
+                unsigned voff = (unsigned)(SB * D) * (unsigned)(lane >> 5) + 2u * (unsigned)(lane & 31);
+                asm volatile("" : "+v"(voff));
+#pragma unroll
+                for (int i0 = 0; i0 < C::NIW; ++i0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned soff = (unsigned)(SB * D * C::RPI * 4) * i0 + (unsigned)(2 * SB * D) * j;   // bytes from the wave's base
+                        static_assert((SB * D * C::RPI * 4) * (C::NIW - 1) + (2 * SB * D) * 3 + SB * D + 64 < (1 << 20), "inside the descriptor");
+                        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base + 16u * (unsigned)(C::dma_slot(4 * i0) + 16 * j));
+                        // (M0 is a reserved register to the compiler: writing it here needs, and admits, no clobber entry)
+                        if (NTLD && i0 >= 1 && i0 < 16)
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen nt lds"
+                                         :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                        else
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen lds"
+                                         :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                    }
+                }
+                return;
+            }
+        }
         if (interior) {
             const char *base = in + 8 * s_first + (8 * D * C::RPI) * ww;
 #pragma unroll
@@ -141,7 +185,7 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
             // edge tiles (first / last of a call): through registers, sample by sample
             const auto *ap = rare_args();
             const long long last = ap->n_in - 1;
-            const char *hist = reinterpret_cast<const char *>(ap->hist) + 8ll * ap->hist_stride * ch;
+            const char *hist = reinterpret_cast<const char *>(ap->hist) + (long long)SB * ap->hist_stride * ch;
 #pragma nounroll
             for (int i0 = 0; i0 < C::NIW; ++i0) {
                 const int i = ww + 4 * i0;
@@ -150,9 +194,16 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const long long s = s_first + (long long)D * (cidx >> 3) + 2 * (cidx & 7) + e;
-                    const char *src = s >= 0 ? in + 8 * (s <= last ? s : last) : hist + 8 * (s + NT >= 0 ? s + NT : 0);
-                    wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
-                    wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
+                    const char *src = s >= 0 ? in + SB * (s <= last ? s : last) : hist + SB * (s + NT >= 0 ? s + NT : 0);
+                    if constexpr (HALFIN) {
+                        // (v_cvt_f32_f16: what the typed DMA of the interior tiles does, for every non-NaN half)
+                        const unsigned w = reinterpret_cast<const unsigned *>(src)[0];
+                        wds[2 * e] = __float_as_uint(half_lo_to_float(w));
+                        wds[2 * e + 1] = __float_as_uint(half_hi_to_float(w));
+                    } else {
+                        wds[2 * e] = reinterpret_cast<const unsigned *>(src)[0];
+                        wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
+                    }
                 }
                 lds[C::dma_slot(i) + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]), __uint_as_float(wds[2]),
                                                      __uint_as_float(wds[3])};
@@ -260,13 +311,13 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
             // store still covers one kilobyte of consecutive bytes
             const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
             const long long m = M0 + 8 * Gq + 2 * kq;
-            char *dst = out + 8 * m;
+            char *dst = out + SB * m;
             if (tile < n_full) {
-                store_pair<false>(dst, r.x, r.y, r.z, r.w);
+                store_pair<HALFIN>(dst, r.x, r.y, r.z, r.w);
             } else {
                 const long long n_out = rare_args()->n_out;     // the call's last tile
-                if (m + 2 <= n_out) store_pair<false>(dst, r.x, r.y, r.z, r.w);
-                else if (m < n_out) store_one<false>(dst, r.x, r.y);
+                if (m + 2 <= n_out) store_pair<HALFIN>(dst, r.x, r.y, r.z, r.w);
+                else if (m < n_out) store_one<HALFIN>(dst, r.x, r.y);
             }
         }
         if (ntile < 0) break;

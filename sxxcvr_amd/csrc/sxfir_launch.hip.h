@@ -82,7 +82,11 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, false>), grid, dim3(256), 0, st, a);
             } else
 #endif
-            if (p->blocks == 3) {
+            if (p->fmt == SXFIR_CF16) {
+                // CF16 storage: the typed LDS-DMA front end
+                if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true, true>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, true, true>), grid, dim3(256), 0, st, a);
+            } else if (p->blocks == 3) {
                 if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, true, true>), grid, dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true>), grid, dim3(256), 0, st, a);
             } else {

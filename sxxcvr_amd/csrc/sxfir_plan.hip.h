@@ -179,7 +179,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         // decim_blocks_kernel, sixteen-column blocks of whole input lines under the ROTATED contract (slot k' holds tap
         // (k' + 1) mod ntaps: sxfir_contract_rotation); 12 / 24 column groups meet in the adjacent-pair tree whose odd element
         // at the end of a level moves up unchanged (oracle B and the generic kernel state the same tree and rotation)
-        p->blocks = (ntaps == 32 * ratio && (ratio == 48 || ratio == 96) && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) ? ratio / 16 : 0;
+        p->blocks = (ntaps == 32 * ratio && (ratio == 48 || ratio == 96)) ? ratio / 16 : 0;      // CF32, S32 words, CF16 storage
         if (p->blocks) {
             p->multi_capable = true;
             p->rot = 1;
@@ -312,6 +312,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             const bool w = fmt == SXFIR_S32;
             k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true, true> : (const void *)sxfir::decim_blocks_kernel<3, false, true>)
                                : (w ? (const void *)sxfir::decim_blocks_kernel<6, true, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true>);
+            if (fmt == SXFIR_CF16)
+                k = p->blocks == 3 ? (const void *)sxfir::decim_blocks_kernel<3, false, true, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true, true>;
         } else if (p->dense32 && fmt == SXFIR_CF16) {
             k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>
                 : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 2, false, false, true>

@@ -160,11 +160,17 @@ def test_shipped_code_object():
     # FMAs per step, every one with a scalar tap; 70 704 B of LDS (two workgroups per CU), 17 DMA instructions per wave and
     # staging site (two sites), 15 of them non-temporal (the rows no other tile reads); CF32 and wire-word input
     bk = [r for r in rows if r["name"].startswith("decim_blocks_kernel<")]
-    assert sorted(r["name"] for r in bk) == ["decim_blocks_kernel<%d, %s, true>" % (nb, w) for nb in (3, 6) for w in ("false", "true")], bk
+    # <NB, S32IN, NTLD, HALFIN>: CF32, wire words, CF16 storage (typed LDS-DMA: four per line instruction of the CF32 form)
+    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s>" % (nb, w, hf) for nb in (3, 6)
+                                                   for w, hf in (("false", "false"), ("true", "false"), ("false", "true"))), bk
     for r in bk:
+        half = r["name"].endswith("true>")
         assert r["lds_bytes"] == 70704 and r["vgpr"] <= 128 and r["v_pk_fma_f32"] == 1024 and r["scalar_tap_fmas"] == 1024, r
-        assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["s_barrier"] == 4, r
-        assert r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
+        if half:
+            assert r["typed_lds_dma"] == 2 * 4 * 17 and r["global_load_lds_dwordx4"] == 0 and r["v_cvt_f32_f16"] <= 8, r
+        else:
+            assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["typed_lds_dma"] == 0, r
+        assert r["s_barrier"] == 4 and r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
     # x48 and x96: three phase blocks of the x16 / of the x32 tile kernel (with / without the keying count, CF32 / wire-word output)
     ib = [r for r in rows if r["name"].startswith("interp_tile_kernel<") and r["name"].rstrip(">").endswith((" 48", " 96"))]
     assert sorted(r["name"].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ib) == ["interp_tile_kernel<16 48>"] * 4 + ["interp_tile_kernel<32 96>"] * 4, ib

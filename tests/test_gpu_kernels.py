@@ -128,10 +128,11 @@ def test_cf16_storage_path(oracle, golden_dir):
     assert np.array_equal(to_cpu(s16).view(np.uint16), oracle.f32_to_f16(x[:4096].view(np.float32)))
 
 
-@pytest.mark.parametrize("D,nchan,skew", [(32, 1, 0), (32, 3, 1), (16, 1, 3), (16, 2, 0), (8, 1, 1), (8, 3, 2), (4, 1, 1), (4, 3, 0)])
+@pytest.mark.parametrize("D,nchan,skew", [(32, 1, 0), (32, 3, 1), (16, 1, 3), (16, 2, 0), (8, 1, 1), (8, 3, 2), (4, 1, 1), (4, 3, 0),
+                                          (48, 1, 1), (48, 2, 0), (96, 1, 0), (96, 3, 3)])
 def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
     """decim_dense_kernel<D, HALFIN> (round 5: CF16 storage at /8, /16, /32 through typed LDS-DMA -- the texture path converts
-    half -> float on the way into the CF32 image) at its seams, with asymmetric random taps: calls of two outputs, of one tile
+    half -> float on the way into the CF32 image) and decim_blocks_kernel<.., HALFIN> (/48, /96) at their seams, with asymmetric random taps: calls of two outputs, of one tile
     minus / plus two, of many tiles plus a tail, several channels with a stride that is not the block length, an input view that
     starts `skew` samples into its buffer (the typed loads want 2-byte alignment only, the descriptor base a sample's), history
     carried from call to call in CF16.  Bit-exact against the oracle on the half-rounded input, output rounded to half once.
@@ -143,7 +144,7 @@ def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
     if D == 4:
         # /4: decim4_wide_kernel<..., HALFIN> (8 outputs per lane, scalar taps) takes bit-symmetric taps; 512-output tiles
         h[64:] = h[:64][::-1]
-    T = 4096 // D if D != 4 else 512
+    T = 4096 // D if D not in (4, 48, 96) else 512
     outs = (2, T - 2, T, T + 2, 2, 40 * T + 78, T * 3, 30, 2 * T)
     if nchan > 1:                                       # CF16: the tiled kernels take an output stride that is a multiple of 4 samples
         outs = (4, T - 4, T, T + 4, 4, 40 * T + 76, T * 3, 28, 2 * T)
@@ -170,7 +171,7 @@ def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
             got[c].append(y[c])
         pos += n
     for c in range(nchan):
-        want = oracle.f32_to_f16(oracle.decim_f32(h, D, xs[c], 2, 4).view(np.float32))
+        want = oracle.f32_to_f16(oracle.decim_f32(h, D, xs[c], 2, 4, rot=plan.contract.rot).view(np.float32))
         assert np.array_equal(np.concatenate(got[c]).view(np.uint16), want), "CF16 dense /%d, channel %d of %d" % (D, c, nchan)
     # infinities and NaNs, one channel, one call of many tiles: +inf, -inf and a NaN deep inside interior tiles and in the first
     # (edge) tile
@@ -186,7 +187,7 @@ def test_cf16_dense_kernel_edges(oracle, D, nchan, skew):
         y = to_cpu(plan2.process(to_gpu(xb.view(np.uint32).view(np.int32)))).view(np.uint16)
         xq = oracle.f16_to_f32(xb).view(np.complex64)
         with np.errstate(invalid="ignore", over="ignore"):
-            want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, 2, 4).view(np.float32))
+            want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, 2, 4, rot=plan2.contract.rot).view(np.float32))
         gf, wf = oracle.f16_to_f32(y), oracle.f16_to_f32(want)
         assert np.array_equal(np.isnan(gf), np.isnan(wf))                      # the same outputs are NaN (NaN, and inf - inf) ...
         ok = ~np.isnan(wf)
@@ -288,7 +289,7 @@ def test_interpolator_takes_the_keying_count_in_the_same_pass(oracle, L, fmt, nc
         b.interpolate_keyed_ptr(blk.data_ptr(), n_in, n_in, out.data_ptr(), n_in * L, 1, n_in, counter.data_ptr(), st)
 
 
-@pytest.mark.parametrize("D,n_in", [(32, 1 << 18), (32, 4096 * 5 + 32 * 3), (8, 1 << 17), (4, 1 << 16), (16, 50000)])
+@pytest.mark.parametrize("D,n_in", [(32, 1 << 18), (32, 4096 * 5 + 32 * 3), (8, 1 << 17), (4, 1 << 16), (16, 50000), (48, 48 * 3000), (96, 96 * 1100)])
 def test_cf16_tiled_decimators(oracle, D, n_in):
     """CF16 storage through the LDS-tiled multi-column kernel: bit-exact against the oracle applied
     to the half-rounded input, output rounded to half once (RNE)."""
@@ -305,7 +306,7 @@ def test_cf16_tiled_decimators(oracle, D, n_in):
     y2 = plan.process(words[n_in:].clone())                        # fused history carry-over, CF16
     _sync()
     got = np.concatenate([to_cpu(y1), to_cpu(y2)]).view(np.uint16)
-    want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, *plan.contract).view(np.float32))
+    want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, *plan.contract, rot=plan.contract.rot).view(np.float32))
     assert np.array_equal(got, want), "CF16 tiled D=%d" % D
     gen = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
     gen.set_kernel(KERNEL_GENERIC)
