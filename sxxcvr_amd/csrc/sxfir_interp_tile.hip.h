@@ -26,6 +26,7 @@
 
 #include "sxfir_decim_tile.hip.h"
 #include "sxfir_kernels.hip.h"
+#include "sxfir_decim_dense.hip.h"       // CF16 storage: v4i32, half_lo_to_float / half_hi_to_float, pack_half2
 
 namespace sxfir {
 
@@ -82,10 +83,18 @@ struct InterpTile {
 // together and complete each other's DRAM pages); the tiny input tile is staged by each of them.  (x96 as six blocks of the
 // x16 kernel: 5 % slower, profiles/round5_rates.txt; phase blocks of eight on the scalar-tap pass kernel -- half-line stores --
 // 20-30 % slower.)
-template <int L, bool S32OUT = false, bool KEYED = false, int LT = L>
+// HALF (round 5): CF16 storage on both sides (IQ as half pairs in HBM, fp32 arithmetic, outputs rounded to half once).  The
+// image in LDS is the same CF32 image: interior tiles are staged by typed LDS-DMA (buffer_load_format_x ... lds with a
+// {16, FLOAT} descriptor: 32 samples per instruction, the texture path converts on the way in; sxfir_decim_dense.hip.h),
+// edge tiles convert in registers; a store instruction writes 512 consecutive bytes (x48: an input's sixteen outputs of a
+// phase block are 64 bytes there -- half lines).
+template <int L, bool S32OUT = false, bool KEYED = false, int LT = L, bool HALF = false>
 __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
 {
     using C = InterpTile<L>;
+    static_assert(!HALF || (!S32OUT && !KEYED), "CF16 storage: CF16 out, no keying count (the rule is defined on CF32 input)");
+    static_assert(!HALF || (C::TILE_IN + 32) % 32 == 0, "whole typed instructions per tile");
+    constexpr int SF = HALF ? 1 : 2;                    // 32-bit words per complex sample in HBM
     static_assert(LT % L == 0 && (LT == L || L == 16 || L == 32), "phase blocks of the x16 / x32 kernel");
     constexpr int NPB = LT / L;
     const int pb = NPB == 1 ? 0 : (int)(blockIdx.x % NPB);
@@ -100,9 +109,18 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
     const int g = (lane >> C::CB) & (C::GW - 1);
     const int ch = blockIdx.y;
 
-    const float *in = a.in + 2 * a.in_stride * ch;
-    const float *hist = a.hist + 2 * a.hist_stride * ch;
-    float *out = a.out + 2 * a.out_stride * ch;
+    const float *in = a.in + SF * a.in_stride * ch;
+    const float *hist = a.hist + SF * a.hist_stride * ch;
+    float *out = a.out + SF * a.out_stride * ch;
+    // one sample of the stream as CF32, whatever the storage
+    auto sample = [&](const float *base, long long s) __attribute__((always_inline)) {
+        if constexpr (HALF) {
+            const unsigned w = reinterpret_cast<const unsigned *>(base)[s];
+            return make_float2(half_lo_to_float(w), half_hi_to_float(w));
+        } else {
+            return reinterpret_cast<const float2 *>(base)[s];
+        }
+    };
 
     // lane taps: h[4*jj + rr] = taps[(16p + jj)*L + 4c + rr], held as pairs hp[k] = {h[2k], h[2k+1]}
     f32x2 hp[32];          // 64-bit register pairs for the packed FMAs
@@ -121,17 +139,45 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
     const int first_tile = (NGR % 8 == 0) ? (vb % 8) * (NGR / 8) + vb / 8 : vb;
     if (first_tile == (a.n_tiles - 1) % NGR && lane < C::HIST && pb == 0) {
         const long long s = a.n_in - C::HIST + lane;
-        const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
-                                : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
-        reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
+        if constexpr (HALF) {
+            const unsigned v = s >= 0 ? reinterpret_cast<const unsigned *>(in)[s] : reinterpret_cast<const unsigned *>(hist)[s + C::HIST];
+            reinterpret_cast<unsigned *>(a.hist_out + SF * a.hist_stride * ch)[lane] = v;
+        } else {
+            const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s]
+                                    : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
+            reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
+        }
     }
 
     for (int tile = first_tile; tile < a.n_tiles; tile += a.n_groups) {
         const long long q0 = (long long)tile * C::TILE_IN;
         const bool interior = (q0 >= 32) && (q0 + C::TILE_IN <= a.n_in);
         // ---- stage samples [q0 - 32, q0 + TILE_IN) ----------------------------
+        if constexpr (HALF) {
+            if (interior) {
+                // typed LDS-DMA: instruction t moves samples [32 t, 32 t + 32) of the image: 128 source bytes -> 16 slots
+                const unsigned long long wb = (unsigned long long)(reinterpret_cast<const unsigned *>(in) + (q0 - 32));
+                v4i32 rs;
+                rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+                rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(wb >> 32)) & 0xffff;    // stride 0
+                rs.z = 1 << 16;
+                rs.w = 4 | (7 << 12) | (2 << 15);                                             // {DATA_FORMAT 16, NUM_FORMAT FLOAT, X <- R}
+                unsigned voff = 2u * (unsigned)lane;
+                asm volatile("" : "+v"(voff));
+                const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+#pragma unroll
+                for (int t = 0; t < (C::TILE_IN + 32) / 32; ++t) {
+                    const unsigned soff = 128u * t;
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_base + 256u * t);
+                    // (M0 is a reserved register to the compiler: writing it here needs, and admits, no clobber entry)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_format_x %1, %2, %3 offen lds"
+                                 :: "s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < C::NLOAD; ++i) {
+            if (HALF && interior) break;
             // chunk index as an opaque 32-bit value: the DMA takes the SGPR-base + VGPR-offset form and no
             // 64-bit per-lane address is kept across the tile loop
             unsigned cc = 64 * i + lane;
@@ -143,10 +189,10 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
             } else {
                 float2 v0, v1;
                 const long long last = a.n_in - 1;
-                if (s >= 0) v0 = reinterpret_cast<const float2 *>(in)[s <= last ? s : last];
-                else v0 = reinterpret_cast<const float2 *>(hist)[s + C::HIST];
-                if (s + 1 >= 0) v1 = reinterpret_cast<const float2 *>(in)[s + 1 <= last ? s + 1 : last];
-                else v1 = reinterpret_cast<const float2 *>(hist)[s + 1 + C::HIST];
+                if (s >= 0) v0 = sample(in, s <= last ? s : last);
+                else v0 = sample(hist, s + C::HIST);
+                if (s + 1 >= 0) v1 = sample(in, s + 1 <= last ? s + 1 : last);
+                else v1 = sample(hist, s + 1 + C::HIST);
                 lds[64 * i + lane] = (f32x4){v0.x, v0.y, v1.x, v1.y};
             }
         }
@@ -240,7 +286,13 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
             }
             // chunk oc of the sub-tile: input oc / (L / 2), chunk oc % (L / 2) of its L outputs
             const long long o = NPB == 1 ? o0 + 2 * oc : o0 + (long long)(oc / (L / 2)) * LT + 2 * (oc % (L / 2));
-            if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
+            if constexpr (HALF) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                if (o + 2 <= o_end)
+                    __builtin_nontemporal_store((u32x2){pack_half2(v.x, v.y), pack_half2(v.z, v.w)}, reinterpret_cast<u32x2 *>(out + o));
+            } else {
+                if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
+            }
         }
         }   // kt
     }

@@ -439,7 +439,18 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.key_lo = key ? key->lo : 0;
         t.key_hi = key ? key->hi : 0;
         dim3 grid((unsigned)(groups * npb), (unsigned)p->nchan);
-        if (npb > 1) {
+        if (p->fmt == SXFIR_CF16) {
+            // CF16 storage: the tile kernel with the typed LDS-DMA front end and half stores, at every ratio
+            if (key) return fail(SXFIR_EUNSUPPORTED, "the keying count is defined on CF32 input");
+            switch (p->ratio) {
+            case 4: hipLaunchKernelGGL((sxfir::interp_tile_kernel<4, false, false, 4, true>), grid, dim3(64), 0, st, t); break;
+            case 8: hipLaunchKernelGGL((sxfir::interp_tile_kernel<8, false, false, 8, true>), grid, dim3(64), 0, st, t); break;
+            case 16: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, false, 16, true>), grid, dim3(64), 0, st, t); break;
+            case 32: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, false, false, 32, true>), grid, dim3(64), 0, st, t); break;
+            case 48: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, false, 48, true>), grid, dim3(64), 0, st, t); break;
+            default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, false, false, 96, true>), grid, dim3(64), 0, st, t); break;
+            }
+        } else if (npb > 1) {
 #define SXFIR_IBLOCKS(SS, KK) \
             do { \
                 if (p->ratio == 48) hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, SS, KK, 48>), grid, dim3(64), 0, st, t); \

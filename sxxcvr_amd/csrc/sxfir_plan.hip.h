@@ -197,7 +197,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         p->tile_capable = false;
         p->multi_capable = false;
         // (x48, x96 -- the reference's rates master clock / 768 and / 1536 -- as three / six phase blocks of the x16 kernel)
-        p->itile_capable = ((fmt == SXFIR_CF32 || fmt == SXFIR_S32) && ntaps == 32 * ratio &&
+        // (CF16 storage, round 5: interp_tile_kernel<.., HALF> at every one of these ratios)
+        p->itile_capable = ((fmt == SXFIR_CF32 || fmt == SXFIR_S32 || fmt == SXFIR_CF16) && ntaps == 32 * ratio &&
                             (ratio == 4 || ratio == 8 || ratio == 16 || ratio == 32 || ratio == 48 || ratio == 96));
         p->jsplit = (jt % 2 == 0) ? 2 : 1;
         p->cw = 1;

@@ -171,11 +171,24 @@ def test_shipped_code_object():
         else:
             assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["typed_lds_dma"] == 0, r
         assert r["s_barrier"] == 4 and r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
-    # x48 and x96: three phase blocks of the x16 / of the x32 tile kernel (with / without the keying count, CF32 / wire-word output)
-    ib = [r for r in rows if r["name"].startswith("interp_tile_kernel<") and r["name"].rstrip(">").endswith((" 48", " 96"))]
-    assert sorted(r["name"].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ib) == ["interp_tile_kernel<16 48>"] * 4 + ["interp_tile_kernel<32 96>"] * 4, ib
+    # x48 and x96: three phase blocks of the x16 / of the x32 tile kernel (with / without the keying count, CF32 / wire-word output),
+    # and CF16 storage (HALF: typed LDS-DMA front end, half stores) at every ratio of the rate table
+    it = [r for r in rows if r["name"].startswith("interp_tile_kernel<")]
+    targs = {r["name"]: [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")] for r in it}     # <L, S32OUT, KEYED, LT, HALF>
+    ib = [r for r in it if targs[r["name"]][3] in ("48", "96") and targs[r["name"]][4] == "false"]
+    assert sorted((targs[r["name"]][0], targs[r["name"]][3]) for r in ib) == [("16", "48")] * 4 + [("32", "96")] * 4, ib
     for r in ib:
         assert r["lds_bytes"] <= 6144 and r["vgpr"] <= 168 and r["v_pk_fma_f32"] >= 256, r       # three waves per SIMD
+    hf = [r for r in it if targs[r["name"]][4] == "true"]
+    assert sorted((int(targs[r["name"]][0]), int(targs[r["name"]][3])) for r in hf) == [(4, 4), (8, 8), (16, 16), (16, 48), (32, 32), (32, 96)], hf
+    for r in hf:
+        L = int(targs[r["name"]][0])
+        tile_in = 16 * (128 // L)                                   # InterpTile<L>::TILE_IN
+        assert targs[r["name"]][1:3] == ["false", "false"] and r["typed_lds_dma"] == (tile_in + 32) // 32 and r["global_load_lds_dwordx4"] == 0, r
+        nload = ((tile_in + 32) // 2 + 63) // 64                    # the edge tiles' register path: four conversions per chunk and lane
+        assert r["v_cvt_f32_f16"] <= 4 * nload and r["v_pk_fma_f32"] == 256, r
+    # (the x4 and x8 tile kernels ship for CF16 storage only: CF32 / wire words run the pass kernel there)
+    assert not [r for r in it if targs[r["name"]][0] in ("4", "8") and targs[r["name"]][4] == "false"]
     # the scalar-tap pass kernel: x8 (two inputs per lane, four passes) and, round 5, x4 (four inputs per lane, two passes)
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<")]
     assert sorted(r["name"].split("<")[1].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ip) == ["2 8>"] * 4 + ["4 4>"] * 4, ip

@@ -289,6 +289,39 @@ def test_interpolator_takes_the_keying_count_in_the_same_pass(oracle, L, fmt, nc
         b.interpolate_keyed_ptr(blk.data_ptr(), n_in, n_in, out.data_ptr(), n_in * L, 1, n_in, counter.data_ptr(), st)
 
 
+@pytest.mark.parametrize("L,nchan,lens", [(4, 1, [512 * 9 + 77, 3, 2048]), (8, 2, [256 * 20 + 5, 256, 1]), (16, 1, [128 * 33 + 64, 129]),
+                                          (32, 3, [64 * 70 + 31, 64 * 3]), (48, 1, [128 * 25 + 3, 700]), (96, 2, [64 * 41 + 9, 64, 200])])
+def test_cf16_tiled_interpolators(oracle, L, nchan, lens):
+    """CF16 storage on the TX side (round 5): interp_tile_kernel<.., HALF> at every ratio of the rate table -- typed LDS-DMA stages
+    the input tile (the texture path converts half -> float), outputs leave as half pairs rounded once; x48 / x96 as phase blocks.
+    Streaming over several calls (history carried in CF16; first, interior and ragged last tiles), several channels; bit-exact
+    against the oracle on the half-rounded input, and equal to the generic kernel."""
+    from sxxcvr_amd.resampler import KERNEL_GENERIC, KERNEL_TILED
+    h = sxxcvr_amd.design_lowpass(32 * L, L, 8.0, float(L))
+    total = sum(lens)
+    xs, x16 = [], []
+    for c in range(nchan):
+        x = oracle.synth_iq(SEED, 60 + c, 0, total)
+        h16 = oracle.f32_to_f16(x.view(np.float32))
+        x16.append(h16.view(np.uint32).view(np.int32))
+        xs.append(oracle.f16_to_f32(h16).view(np.complex64))
+    x16 = np.stack(x16)
+    for kern in (KERNEL_TILED, KERNEL_GENERIC):
+        plan = sxxcvr_amd.Resampler(INTERPOLATE, h, L, nchan=nchan, fmt="CF16")
+        plan.set_kernel(kern)
+        outs, pos = [], 0
+        for n in lens:
+            blk = to_gpu(np.ascontiguousarray(x16[:, pos:pos + n]))
+            y = plan.process(blk if nchan > 1 else blk[0])
+            _sync()
+            outs.append(to_cpu(y).reshape(nchan, -1))
+            pos += n
+        got = np.concatenate(outs, axis=1)
+        for c in range(nchan):
+            want = oracle.f32_to_f16(oracle.interp_f32(h, L, xs[c], plan.contract[0]).view(np.float32))
+            assert np.array_equal(got[c].view(np.uint16), want), "CF16 x%d kernel %d channel %d" % (L, kern, c)
+
+
 @pytest.mark.parametrize("D,n_in", [(32, 1 << 18), (32, 4096 * 5 + 32 * 3), (8, 1 << 17), (4, 1 << 16), (16, 50000), (48, 48 * 3000), (96, 96 * 1100)])
 def test_cf16_tiled_decimators(oracle, D, n_in):
     """CF16 storage through the LDS-tiled multi-column kernel: bit-exact against the oracle applied
