@@ -13,6 +13,7 @@ LOG2N = int(os.environ.get("RB_LOG2N", "28"))
 
 def run(mode, ratio):
     n_wide = (1 << LOG2N) // (512 * ratio) * (512 * ratio)       # whole tiles of every kernel
+    n_wide += int(os.environ.get("RB_ADD_TILES", "0")) * 512 * ratio      # ... plus a partial round of them (schedule tails)
     taps = sxxcvr_amd.design_lowpass(32 * ratio, ratio, 8.0, 1.0 if mode == DECIMATE else float(ratio))
     p = sxxcvr_amd.Resampler(mode, taps, ratio, fmt=fmt, profiling=bool(os.environ.get("RB_PROF")))
     dt = {"CF32": torch.complex64, "CF16": torch.int32}[fmt]        # CF16: one 32-bit word (two halves) per sample
