@@ -632,6 +632,20 @@ def test_ratio_follows_sample_rate(oracle):
     assert_bit_exact(buf, oracle.decim_f32(h, 48, oracle.synth_iq(SEED, 0, 0, 700 * 48), 2, 4, rot=1), "rx at 50 kS/s")
     dev.deactivateStream(rx)
     dev.closeStream(rx)
+    # ... and the TX side of the two slowest rates: x48 / x96 as phase blocks of the tile kernels
+    for rate, ratio in ((50000.0, 48), (25000.0, 96)):
+        dev.setSampleRate(SoapySDR.SOAPY_SDR_TX, 0, rate)
+        assert dev.readSetting("TX_INTERP") == str(ratio)
+        tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, SoapySDR.SOAPY_SDR_CF32, [0], {"threshold": "0"})
+        dev.activateStream(tx)
+        block = oracle.synth_iq(5, 2, 0, 1500) * np.float32(0.25)
+        assert dev.writeStream(tx, [block], 1500).ret == 1500
+        first = int(dev.readSetting("TX_POSITION")) - 1500
+        out = dev.txCapture(first * ratio, 1500 * ratio)
+        stream = np.concatenate([np.zeros(32, dtype=np.complex64), block])
+        assert_bit_exact(out, tx_reference(oracle, ratio, stream)[32 * ratio:], "tx at %g S/s" % rate)
+        dev.deactivateStream(tx)
+        dev.closeStream(tx)
     # 25 kS/s = master clock / 1536 -> ratio 96, 3072 taps: the carried-over history (3072 samples) is longer
     # than one workgroup used to hold; read enough for several RX batches so that the history is carried
     dev.setSampleRate(SoapySDR.SOAPY_SDR_RX, 0, 25000.0)
