@@ -317,7 +317,8 @@ def test_history_longer_than_2048_samples(oracle, mode):
 
 @pytest.mark.parametrize("mode,ntaps,ratio,fmt", [("decim", 128, 4, "CF32"), ("decim", 256, 8, "CF32"), ("interp", 256, 8, "CF32"),
                                                    ("decim", 1024, 32, "CF16"), ("decim", 128, 4, "S32"),
-                                                   ("decim", 1024, 32, "CF32")])
+                                                   ("decim", 1024, 32, "CF32"), ("decim", 1536, 48, "CF32"), ("interp", 1536, 48, "CF32"),
+                                                   ("decim", 3072, 96, "CF16"), ("interp", 3072, 96, "CF16")])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_set_history_and_pipelined_passes_equal_one_plan(oracle, mode, ntaps, ratio, fmt, ragged):
     """sxfir_set_history seeds a plan from the tail of the previous INPUT block, so consecutive blocks of one stream
