@@ -66,10 +66,10 @@ CONFIGS = {
 # The reference's rate table (SoapySX.cpp:180-208: master clock / {64, 128, 256, 512, 768, 1536}; the converters run at master
 # clock / 16, so ratio = divider / 16, 32 taps per phase): the rows the BASELINE configs above do not already cover.  Not
 # bench lines of the driver: `--config rx48` etc. time, verify and profile these kernels the same way.
-for _ratio, _rxk, _txk in ((4, None, "sxfir::interp8_pass_kernel<4 inputs per lane, x4: scalar taps, two passes>"), (16, "sxfir::decim_dense_kernel<16>", "sxfir::interp_tile_kernel<16>"),
-                           (32, None, "sxfir::interp_tile_kernel<32>"),
-                           (48, "sxfir::decim_blocks_kernel<3 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<16, 3 phase blocks>"),
-                           (96, "sxfir::decim_blocks_kernel<6 blocks of 16 columns, scalar taps>", "sxfir::interp_tile_kernel<32, 3 phase blocks>")):
+for _ratio, _rxk, _txk in ((4, None, "sxfir::interp8_pass_kernel<4 inputs per lane, x4: scalar taps, two passes>"), (16, "sxfir::decim_dense_kernel<16>", "sxfir::interp8_pass_kernel<2 inputs per lane, one phase block of sixteen>"),
+                           (32, None, "sxfir::interp8_pass_kernel<2 inputs per lane, two phase blocks of sixteen>"),
+                           (48, "sxfir::decim_blocks_kernel<3 blocks of 16 columns, scalar taps>", "sxfir::interp8_pass_kernel<2 inputs per lane, three phase blocks of sixteen>"),
+                           (96, "sxfir::decim_blocks_kernel<6 blocks of 16 columns, scalar taps>", "sxfir::interp8_pass_kernel<2 inputs per lane, six phase blocks of sixteen>")):
     _khz = 38400.0 / 16 / _ratio
     if _rxk:
         CONFIGS["rx%d" % _ratio] = dict(mode="decim", ntaps=32 * _ratio, ratio=_ratio, fmt="CF32", bytes=8 + 8 / _ratio, flop=128, gain=1.0,

@@ -53,7 +53,7 @@ namespace sxfir {
 template <int QI, int LL = 8>
 struct InterpPass8 {
     static_assert(QI == 2 || QI == 4, "inputs per lane");
-    static_assert(LL == 8 || (LL == 4 && QI == 4), "x8, or x4 with four inputs per lane");
+    static_assert(LL == 8 || (LL == 4 && QI == 4) || (LL == 16 && QI == 2), "x8; x4 with four inputs per lane; x16 with two");
     static constexpr int L = LL;
     static constexpr int TILE_IN = 64 * QI;               // inputs per tile
     static constexpr int HIST = 32;
@@ -109,10 +109,17 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
 // instead of the counted form below -- slower, and free of the counted form's premises (exactly CPL stores behind the
 // next tile's DMAs, no other VMEM instruction between them); tests/test_gpu_variants.py holds the two bit-identical,
 // tests/test_abi.py::test_shipped_code_object checks the premises in the shipped disassembly.
-template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true, int LL = 8>
+// LL = 16 (trial, round 5): four phase groups, eight passes, a lane's 2 x 16 outputs = two whole lines, 16 KiB of outputs per tile
+// (8 waves per CU, as QI = 4 at x8).  LT: the plan's ratio, a multiple of LL -- x32, x48, x96 as LT / 16 PHASE BLOCKS walked
+// inside the tile loop over the SAME window (an interpolator's phases never meet; block pb is the x16 problem on the taps
+// h[j LT + 16 pb + r], pass-major table, block pb at 512 pb; an input's sixteen outputs of a block are one whole line).  The next
+// tile's DMAs are awaited behind the FIRST block's stores (the same counted wait, one block earlier).
+template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true, int LL = 8, int LT = LL>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {
     using C = InterpPass8<QI, LL>;
+    static_assert(LT % LL == 0 && (LT == LL || LL == 16), "phase blocks of sixteen");
+    constexpr int NPB = LT / LL;
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::IMG + C::OBUF];
     f32x4 *obuf = lds + C::IMG;
 
@@ -130,7 +137,12 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
     // to HBM: 1.028 x the algorithmic bytes, profiles/round4_3tx_summary.json of the first build)
     const int G = a.n_groups;
     const int first_tile = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    if (first_tile == (a.n_tiles - 1) % G && lane < C::HIST) {
+    // (x16 blocks: tiles are 128 inputs x up to 96 outputs each -- few per workgroup -- so the partial LAST round is dealt plainly,
+    // tile R G + blockIdx.x: XCD-blocked it falls to the first XCDs alone, x96 0.55 against 0.46 ms; the x4 / x8 instances keep
+    // their schedule)
+    constexpr bool PLAIN_TAIL = LL == 16;
+    const int R = a.n_tiles / G, rem = a.n_tiles % G;          // G <= n_tiles: at least one whole round
+    if ((PLAIN_TAIL ? (rem ? (int)blockIdx.x == rem - 1 : first_tile == G - 1) : first_tile == (a.n_tiles - 1) % G) && lane < C::HIST) {
         const long long s = a.n_in - C::HIST + lane;
         const float2 v = s >= 0 ? reinterpret_cast<const float2 *>(in)[s] : reinterpret_cast<const float2 *>(hist)[s + C::HIST];
         reinterpret_cast<float2 *>(a.hist_out + 2 * a.hist_stride * ch)[lane] = v;
@@ -189,15 +201,21 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
     if (tile >= a.n_tiles) return;
     stage(tile);
     bool counted = false;                                       // the staged tile's DMAs sit in front of CPL stores
+    bool landed = false;                                        // (phase blocks) ... and have been awaited already
     while (true) {
         // s_waitcnt vmcnt counts loads and stores together, in issue order: with the next tile's three DMAs issued
         // BEFORE this tile's sixteen stores, "at most 16 outstanding" means the DMAs have landed
-        if (COUNTED && counted) {
-            static_assert(C::CPL == 16 || C::CPL == 8, "stores per tile behind the next tile's DMAs");
-            if constexpr (C::CPL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (NPB == 1) {
+            if (COUNTED && counted) {
+                static_assert(C::CPL == 16 || C::CPL == 8, "stores per tile behind the next tile's DMAs");
+                if constexpr (C::CPL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (phase blocks: awaited behind the previous tile's first block; the workgroup's first tile here)
+            if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const long long q0 = (long long)tile * C::TILE_IN;
 
@@ -235,11 +253,17 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             }
         }
         // the image is free: fetch the next tile behind the arithmetic of this one
-        const int next = tile + a.n_groups;
+        int next = tile + a.n_groups;
+        if constexpr (PLAIN_TAIL) {
+            const int r = tile / G + 1;                          // the round after this tile's
+            next = r < R ? r * G + first_tile : (r == R && (int)blockIdx.x < rem ? R * G + (int)blockIdx.x : a.n_tiles);
+        }
         counted = false;
         if (next < a.n_tiles) counted = stage(next);
 
-        // ---- four passes (x4: two): phase group c (outer), row half p (inner)
+#pragma unroll 1
+        for (int pb = 0; pb < NPB; ++pb) {
+        // ---- four passes (x4: two, x16: eight): phase group c (outer), row half p (inner)
 #pragma unroll 1
         for (int c = 0; c < C::L / 4; ++c) {
             f32x2 y[QI][4];
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             for (int p = 0; p < 2; ++p) {
                 f32x2 hs[32];
 #pragma unroll
-                for (int m = 0; m < 32; ++m) hs[m] = tq[32 * (2 * c + p) + m];
+                for (int m = 0; m < 32; ++m) hs[m] = tq[(16 * C::L) * pb + 32 * (2 * c + p) + m];
                 f32x4 wv[C::NW];
 #pragma unroll
                 for (int t = 0; t < C::NW; ++t) wv[t] = win[8 - 8 * p + t];
@@ -273,7 +297,11 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         // ---- store: instruction i moves slots 64i .. 64i+63 = the rows of lanes 4i .. 4i+3, each lane the chunk its
         // slot holds (a permutation inside the 256-byte row): four whole rows per instruction.  Always sixteen store
         // instructions per tile (lanes past the end of the call sit theirs out): the counted wait relies on it.
-        const long long o0 = q0 * C::L;                         // first output sample of the tile
+        const long long o0 = q0 * LT + C::L * pb;               // first output sample of the tile (of this phase block)
+        // chunk k2 of lane g2's row: input k2 / (L / 2), chunk k2 % (L / 2) of its L outputs of this block
+        auto out_sample = [&](int g2, int k2) __attribute__((always_inline)) {
+            return NPB == 1 ? o0 + 2 * (C::CPL * g2 + k2) : o0 + (long long)(QI * g2 + k2 / (C::L / 2)) * LT + 2 * (k2 % (C::L / 2));
+        };
         if (tile < n_full) {
             // all CPL reads in flight, then CPL stores back to back (decided per wave, not per lane and store)
             f32x4 v[C::CPL];
@@ -291,11 +319,11 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             for (int i = 0; i < C::CPL; ++i) {
                 const int slot = 64 * i + lane;
                 const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
-                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(out + 2 * (o0 + 2 * (C::CPL * g2 + k2))));
+                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(out + 2 * out_sample(g2, k2)));
             }
         } else {
             // the call's last tile (no counted wait follows it: the wave ends here)
-            const long long o_end = a.n_in * C::L;
+            const long long o_end = a.n_in * LT;
 #pragma unroll
             for (int i = 0; i < C::CPL; ++i) {
                 const int slot = 64 * i + lane;
@@ -306,12 +334,21 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
                     const int2 w0 = tx_words(v.x, v.y, thr2), w1 = tx_words(v.z, v.w, thr2);
                     v = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
                 }
-                const long long o = o0 + 2 * (C::CPL * g2 + k2);     // two output samples per chunk
+                const long long o = out_sample(g2, k2);              // two output samples per chunk
                 if (o + 2 <= o_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out + 2 * o));
             }
         }
-        // the next tile's output writes reuse the buffer only after these reads have returned
+        // the next block's / tile's output writes reuse the buffer only after these reads have returned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (NPB > 1) {
+            if (pb == 0) {
+                // the next tile's DMAs were issued before this block's CPL stores: at most CPL outstanding = they have landed
+                if (COUNTED && counted) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                landed = true;
+            }
+        }
+        }   // pb
         if (next >= a.n_tiles) break;
         tile = next;
     }

@@ -382,6 +382,22 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.key_lo = key ? key->lo : 0;
         t.key_hi = key ? key->hi : 0;
         const dim3 pgrid((unsigned)groups, (unsigned)p->nchan);
+        if (p->ratio >= 16) {
+            // x16 .. x96: two inputs per lane, ratio / 16 phase blocks of sixteen per tile
+#define SXFIR_IPASS16(KK, SS) \
+            switch (p->ratio) { \
+            case 16: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 16>), pgrid, dim3(64), 0, st, t); break; \
+            case 32: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 32>), pgrid, dim3(64), 0, st, t); break; \
+            case 48: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 48>), pgrid, dim3(64), 0, st, t); break; \
+            case 96: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 96>), pgrid, dim3(64), 0, st, t); break; \
+            default: return fail(SXFIR_EUNSUPPORTED, "internal: no pass kernel for x%d", p->ratio); \
+            }
+            if (p->fmt == SXFIR_S32 && key) { SXFIR_IPASS16(true, true) }
+            else if (p->fmt == SXFIR_S32) { SXFIR_IPASS16(false, true) }
+            else if (key) { SXFIR_IPASS16(true, false) }
+            else { SXFIR_IPASS16(false, false) }
+#undef SXFIR_IPASS16
+        } else
         if (p->ratio == 4) {
             // x4: four inputs per lane, two passes
             if (p->fmt == SXFIR_S32 && key) hipLaunchKernelGGL((sxfir::interp8_pass_kernel<4, true, true, true, 4>), pgrid, dim3(64), 0, st, t);
@@ -450,7 +466,13 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
             case 48: hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, false, false, 48, true>), grid, dim3(64), 0, st, t); break;
             default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32, false, false, 96, true>), grid, dim3(64), 0, st, t); break;
             }
-        } else if (npb > 1) {
+        }
+#ifndef SXFIR_PROFILING
+        // CF32 / wire-word output runs the scalar-tap pass kernels at every ratio since round 5 (p->ipass); the tile kernels'
+        // CF32 instances are their A/B partners in the profiling build (SXFIR_IPASS=0)
+        else return fail(SXFIR_EUNSUPPORTED, "internal: CF32 / wire-word interpolation outside the pass kernels");
+#else
+        else if (npb > 1) {
 #define SXFIR_IBLOCKS(SS, KK) \
             do { \
                 if (p->ratio == 48) hipLaunchKernelGGL((sxfir::interp_tile_kernel<16, SS, KK, 48>), grid, dim3(64), 0, st, t); \
@@ -526,6 +548,7 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
             default: hipLaunchKernelGGL((sxfir::interp_tile_kernel<32>), grid, dim3(64), 0, st, t); break;
             }
         }
+#endif
         HIPCHECK(hipGetLastError());
         *history_done = true;
         return SXFIR_OK;

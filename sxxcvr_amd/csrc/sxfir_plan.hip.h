@@ -256,6 +256,16 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<2>, 64, 0) == hipSuccess && nbi > 0)
             p->occ_ipass = nbi;
     }
+    // x16 .. x96 (round 5): the pass kernel over ratio / 16 phase blocks of sixteen per tile (a lane's sixteen outputs per input
+    // and block are one line): 8-9 % less time than interp_tile_kernel, which keeps CF16 storage (profiles/round5_rates.txt)
+    if (p->itile_capable && ratio >= 16 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
+        p->ipass = true;
+        p->ipass_qi = 2;
+        p->oversub = 8;
+        int nbi = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbi, (const void *)sxfir::interp8_pass_kernel<2, false, false, true, 16, 16>, 64, 0) == hipSuccess && nbi > 0)
+            p->occ_ipass = nbi;
+    }
     // x4, 128 taps (round 5): the same scalar-tap pass form with four inputs per lane (two passes; a lane's sixteen outputs are
     // one line)
     if (p->itile_capable && ratio == 4 && (fmt == SXFIR_CF32 || fmt == SXFIR_S32)) {
@@ -479,11 +489,13 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                                     taps[(slot + 1) % ntaps] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);
                             }
         } else if (p->tap_table == TAPS_PASS8) {
-            for (int c = 0; c < ratio / 4; ++c)                 // x8: two phase groups; x4: one
+            const int ll = ratio >= 16 ? 16 : ratio;            // phases per (block of the) pass kernel
+            for (int b = 0; b < ratio / ll; ++b)
+            for (int c = 0; c < ll / 4; ++c)                    // x8: two phase groups; x4: one; x16 blocks: four
                 for (int ph = 0; ph < 2; ++ph)
                     for (int jj = 0; jj < 16; ++jj)
                         for (int rr = 0; rr < 4; ++rr)
-                            scaled[(size_t)(64 * (2 * c + ph) + 4 * jj + rr)] = taps[(16 * ph + jj) * ratio + 4 * c + rr];
+                            scaled[(size_t)(32 * ll * b + 64 * (2 * c + ph) + 4 * jj + rr)] = taps[(16 * ph + jj) * ratio + ll * b + 4 * c + rr];
         } else {
             for (float &t : scaled) t *= 4.656612873077393e-10f;      // 2^-31: exact
         }

@@ -171,40 +171,47 @@ def test_shipped_code_object():
         else:
             assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["typed_lds_dma"] == 0, r
         assert r["s_barrier"] == 4 and r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
-    # x48 and x96: three phase blocks of the x16 / of the x32 tile kernel (with / without the keying count, CF32 / wire-word output),
-    # and CF16 storage (HALF: typed LDS-DMA front end, half stores) at every ratio of the rate table
+    # interp_tile_kernel ships for CF16 storage only (HALF: typed LDS-DMA front end, half stores) at every ratio of the rate table --
+    # x48 / x96 as three phase blocks of its x16 / x32 form; CF32 and wire-word output run the scalar-tap pass kernels
     it = [r for r in rows if r["name"].startswith("interp_tile_kernel<")]
     targs = {r["name"]: [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")] for r in it}     # <L, S32OUT, KEYED, LT, HALF>
-    ib = [r for r in it if targs[r["name"]][3] in ("48", "96") and targs[r["name"]][4] == "false"]
-    assert sorted((targs[r["name"]][0], targs[r["name"]][3]) for r in ib) == [("16", "48")] * 4 + [("32", "96")] * 4, ib
-    for r in ib:
-        assert r["lds_bytes"] <= 6144 and r["vgpr"] <= 168 and r["v_pk_fma_f32"] >= 256, r       # three waves per SIMD
-    hf = [r for r in it if targs[r["name"]][4] == "true"]
-    assert sorted((int(targs[r["name"]][0]), int(targs[r["name"]][3])) for r in hf) == [(4, 4), (8, 8), (16, 16), (16, 48), (32, 32), (32, 96)], hf
-    for r in hf:
+    assert not [r for r in it if targs[r["name"]][4] == "false"], [r["name"] for r in it]
+    assert sorted((int(targs[r["name"]][0]), int(targs[r["name"]][3])) for r in it) == [(4, 4), (8, 8), (16, 16), (16, 48), (32, 32), (32, 96)], it
+    for r in it:
         L = int(targs[r["name"]][0])
         tile_in = 16 * (128 // L)                                   # InterpTile<L>::TILE_IN
         assert targs[r["name"]][1:3] == ["false", "false"] and r["typed_lds_dma"] == (tile_in + 32) // 32 and r["global_load_lds_dwordx4"] == 0, r
         nload = ((tile_in + 32) // 2 + 63) // 64                    # the edge tiles' register path: four conversions per chunk and lane
         assert r["v_cvt_f32_f16"] <= 4 * nload and r["v_pk_fma_f32"] == 256, r
-    # (the x4 and x8 tile kernels ship for CF16 storage only: CF32 / wire words run the pass kernel there)
-    assert not [r for r in it if targs[r["name"]][0] in ("4", "8") and targs[r["name"]][4] == "false"]
-    # the scalar-tap pass kernel: x8 (two inputs per lane, four passes) and, round 5, x4 (four inputs per lane, two passes)
+    # the scalar-tap pass kernel <QI, KEYED, S32OUT, COUNTED, LL, LT>: x8 (two inputs per lane, four passes), x4 (four inputs, two
+    # passes) and x16 .. x96 (two inputs, eight passes per phase block of sixteen; LT / 16 blocks per tile)
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<")]
-    assert sorted(r["name"].split("<")[1].split(",")[0] + r["name"].rsplit(",", 1)[1] for r in ip) == ["2 8>"] * 4 + ["4 4>"] * 4, ip
+    pa = {r["name"]: [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")] for r in ip}
+    assert sorted((int(pa[n][0]), int(pa[n][4]), int(pa[n][5])) for n in pa) == sorted(
+        [(2, 8, 8)] * 4 + [(4, 4, 4)] * 4 + [(2, 16, lt) for lt in (16, 32, 48, 96) for _ in range(4)]), sorted(pa)
     for r in ip:
-        targs = [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")]      # <QI, KEYED, S32OUT, COUNTED, L>
-        wire, x4 = targs[2] == "true", targs[4] == "4"               # the wire-word conversion holds more masks
-        assert targs[3] == "true", r                                 # the counted form ships
-        assert r["vgpr"] <= (168 if x4 else 128) and r["lds_bytes"] == (11264 if x4 else 10240) and r["v_pk_fma_f32"] == (512 if x4 else 256), r
-        assert r["sgpr_spill_lane_ops"] <= (72 if wire else 16), r
+        t = pa[r["name"]]
+        wire, ll, lt = t[2] == "true", int(t[4]), int(t[5])          # the wire-word conversion holds more masks
+        assert t[3] == "true", r                                     # the counted form ships
+        assert r["lds_bytes"] == {4: 11264, 8: 10240, 16: 18432}[ll] and r["v_pk_fma_f32"] == (512 if ll == 4 else 256), r
+        assert r["vgpr"] <= {4: 168, 8: 128, 16: 256}[ll], r         # x16 blocks: LDS (18 KB per wave) holds the CU at 8 waves anyway
+        if ll != 16:
+            assert r["sgpr_spill_lane_ops"] <= (72 if wire else 16), r
+        if lt != ll:
+            # phase blocks: the next tile's DMAs are awaited behind the FIRST block's sixteen stores; between the loop's DMAs and that
+            # wait the disassembly has stores only (the full-tile path's sixteen and the guarded last-tile path's) and no atomic
+            pw = r["phase_block_wait"]
+            assert pw["n"] == 16 and pw["waits"] == 1 and pw["atomics_between_loop_dmas_and_wait"] == 0, r
+            assert pw["vmem_between_last_dma_and_wait"] == ["global_store_dwordx4"] * 32, r
+            continue
         # the counted wait (s_waitcnt vmcnt(8), sxfir_interp_pass.hip.h): safe only if the tile loop issues the next tile's
         # image DMAs, then exactly eight stores and nothing else that counts as VMEM -- no scratch access (checked above), no
         # load, and the keying count's atomic in FRONT of the DMAs.  Read off the shipped disassembly:
         cw = r["counted_wait"]
-        assert cw["n"] == 8 and cw["waits"] == 1, r
+        n = 16 if ll == 16 else 8                                    # stores per tile = output chunks per lane
+        assert cw["n"] == n and cw["waits"] == 1, r
         assert cw["dma_loads"] >= 2 and cw["atomics_after_first_dma"] == 0, r
-        assert cw["last_block_vmem"] == ["global_store_dwordx4"] * 8, r          # the full-tile path that loops back
+        assert cw["last_block_vmem"] == ["global_store_dwordx4"] * n, r          # the full-tile path that loops back
         assert cw["non_store_vmem_after_last_dma"] == [], r
-    keyed = [r for r in ip if "<2, true" in r["name"] or "<4, true" in r["name"]]
-    assert len(keyed) == 4
+    keyed = [r for r in ip if pa[r["name"]][1] == "true"]
+    assert len(keyed) == 12

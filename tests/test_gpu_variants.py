@@ -224,6 +224,32 @@ def test_x4_interpolator_forms_match_oracle(oracle, monkeypatch, ipass, oversub)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ratio", [16, 32, 48, 96])
+@pytest.mark.parametrize("ipass,oversub", [("0", "2"), ("1", "1"), ("1", "8"), ("1", "16")])
+def test_x16_to_x96_interpolator_forms_match_oracle(oracle, monkeypatch, ratio, ipass, oversub):
+    """x16 .. x96: interp8_pass_kernel over phase blocks of sixteen (scalar taps, one window per tile for all blocks, the partial last
+    round of tiles dealt plainly: shipped since round 5) and interp_tile_kernel (taps in VGPRs; x48 / x96 as three phase blocks;
+    SXFIR_IPASS=0: the A/B partner) give the oracle's bits: streaming over calls with first, interior and ragged last tiles at
+    several generation counts (whole and partial rounds of tiles), two channels."""
+    for k in KNOBS + ("SXFIR_IPASS", "SXFIR_IPASS_WAIT0"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_IPASS", ipass)
+    monkeypatch.setenv("SXFIR_OVERSUB", oversub)
+    h = sxxcvr_amd.design_lowpass(32 * ratio, ratio, 8.0, float(ratio))
+    nchan, lens = 2, [128 * 2500 + 77, 5, 128 * 64 + 130, 1]
+    x = np.stack([oracle.synth_iq(0x51255, 36 + c, 0, sum(lens)) for c in range(nchan)])
+    plan = sxxcvr_amd.Resampler(INTERPOLATE, h, ratio, nchan=nchan, profiling=True)
+    plan.set_kernel(KERNEL_TILED)
+    outs, pos = [], 0
+    for n in lens:
+        outs.append(to_cpu(plan.process(to_gpu(np.ascontiguousarray(x[:, pos:pos + n])))))
+        pos += n
+    y = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert_bit_exact(y[c], oracle.interp_f32(h, ratio, x[c], 2), "x%d form %s channel %d" % (ratio, ipass, c))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("subset", ["1", "0"])
 @pytest.mark.parametrize("nchan,lens", [(1, [512 * 40 + 8 * 3, 8 * 5, 512 * 9]), (3, [512 * 7 + 8 * 77, 1 << 17])])
 def test_div8_forms_match_oracle(oracle, monkeypatch, nchan, lens, subset):

@@ -71,9 +71,14 @@ def kernels(lib=None):
             r["scalar_tap_fmas"] = len(fm)
             r["adjacent_fmas_sharing_sample_pair"] = round(sum(1 for a, b in zip(fm, fm[1:]) if a[1] == b[1]) / (len(fm) - 1), 3)
         # (the compiler emits vmcnt(N > 0) waits of its own elsewhere: those count its own loads; this one is hand-written)
-        cw = counted_wait(body) if "interp8_pass_kernel" in r["name"] else None
-        if cw:
-            r["counted_wait"] = cw
+        if "interp8_pass_kernel" in r["name"]:
+            targs = [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")]      # <QI, KEYED, S32OUT, COUNTED, LL, LT>
+            if targs[4] == targs[5]:
+                cw = counted_wait(body)
+                if cw:
+                    r["counted_wait"] = cw
+            else:
+                r["phase_block_wait"] = phase_block_wait(body)
         rows.append(r)
     return rows
 
@@ -103,6 +108,29 @@ def counted_wait(body):
             "atomics_after_first_dma": sum(1 for i in atom if dma and i > min(dma)),
             "last_block_vmem": last_block,
             "non_store_vmem_after_last_dma": [o for o in after_dma if not o.startswith("global_store")]}
+
+
+def phase_block_wait(body):
+    """interp8_pass_kernel over phase blocks (x32, x48, x96): the next tile's image DMAs are awaited behind the FIRST block's
+    stores with `s_waitcnt vmcnt(16)`.  In code order the tile loop is: window reads, [keying atomic], the DMAs, then the block
+    loop -- passes, the block's stores (a full-tile path of sixteen and a guarded last-tile path), the wait.  Returns the VMEM
+    mnemonics between the loop's last DMA and the hand-written wait -- they must all be stores, sixteen per path -- and the
+    atomics between the loop's DMAs and the wait (none: the keying count's atomic sits in front of the DMAs)."""
+    lines = [l.split("//")[0].strip() for l in body.splitlines()]
+    lines = [l for l in lines if l]
+    w = [i for i, l in enumerate(lines) if re.match(r"s_waitcnt vmcnt\(16\)$", l)]
+    dma = [i for i, l in enumerate(lines) if l.startswith("global_load_lds")]
+    if not w or not dma:
+        return None
+    after = [i for i in w if i > max(dma)]
+    if not after:
+        return None
+    between = [l.split()[0] for l in lines[max(dma) + 1:after[0]] if re.match(r"(global|buffer|scratch|flat)_", l)]
+    atom = [i for i, l in enumerate(lines) if l.startswith(("global_", "flat_", "buffer_")) and "atomic" in l.split()[0]]
+    # the tile loop's own DMAs are the last group in code order (the first group stages the workgroup's first tile)
+    loop_dma = [i for i in dma if i > max(atom)] if atom else dma[len(dma) // 2:]
+    return {"n": 16, "waits": len(w), "dma_loads": len(dma), "vmem_between_last_dma_and_wait": between,
+            "atomics_between_loop_dmas_and_wait": sum(1 for i in atom if loop_dma and min(loop_dma) < i < after[0])}
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ BYTES = {"2": 10.0, "3rx": 9.0, "3tx": 9.0, "5": 8.25, "5h": 4.125}
 # the reference's other rates (bench.py --config rx16 ... tx96)
 for _r in (4, 16, 32, 48, 96):
     KERNELS["rx%d" % _r] = "decim_blocks_kernel<%d" % (_r // 16) if _r > 32 else "decim_dense_kernel<%d" % _r
-    KERNELS["tx%d" % _r] = "interp_tile_kernel<%d, false, false, %d" % (32 if _r == 96 else 16, _r) if _r > 32 else "interp_tile_kernel<%d" % _r
+    KERNELS["tx%d" % _r] = "interp8_pass_kernel<2, false, false, true, 16, %d" % _r
     BYTES["rx%d" % _r] = BYTES["tx%d" % _r] = 8.0 + 8.0 / _r
 KERNELS["tx4"] = "interp8_pass_kernel<4"
 
