@@ -1,0 +1,15 @@
+import os, sys, time
+sys.path.insert(0, "/root/repo")
+import torch, sxxcvr_amd
+from sxxcvr_amd.resampler import DECIMATE
+for ratio in (4, 8, 16, 32, 48, 96):
+    wide = (1 << 28) // (512 * ratio) * (512 * ratio)
+    taps = sxxcvr_amd.design_lowpass(32 * ratio, ratio)
+    p = sxxcvr_amd.Resampler(DECIMATE, taps, ratio, fmt="S32")
+    x = torch.randint(-2**31, 2**31 - 1, (wide, 2), dtype=torch.int32, device="cuda")
+    y = torch.empty(wide // ratio, dtype=torch.complex64, device="cuda")
+    for _ in range(30): p.process(x, out=y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(40): p.process(x, out=y)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 40
+    print("RX /%-2d S32 words in  %.3f ms per 2^28 samples" % (ratio, t * 1e3 * (1 << 28) / wide), flush=True)
