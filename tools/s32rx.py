@@ -2,10 +2,10 @@ import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch, sxxcvr_amd
 from sxxcvr_amd.resampler import DECIMATE
-for ratio in (4, 8, 16, 32, 48, 96):
+for ratio in [int(v) for v in os.environ.get("RB_RATIOS", "4,8,16,32,48,96").split(",")]:
     wide = (1 << 28) // (512 * ratio) * (512 * ratio)
     taps = sxxcvr_amd.design_lowpass(32 * ratio, ratio)
-    p = sxxcvr_amd.Resampler(DECIMATE, taps, ratio, fmt="S32")
+    p = sxxcvr_amd.Resampler(DECIMATE, taps, ratio, fmt="S32", profiling=bool(os.environ.get("RB_PROF")))
     x = torch.randint(-2**31, 2**31 - 1, (wide, 2), dtype=torch.int32, device="cuda")
     y = torch.empty(wide // ratio, dtype=torch.complex64, device="cuda")
     for _ in range(30): p.process(x, out=y)
