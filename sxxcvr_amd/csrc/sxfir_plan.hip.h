@@ -421,6 +421,15 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                     p->wide_nb = 24;
                     p->wide_pol = (int)strtol(v + 7, nullptr, 16);
                 }
+                // SXFIR_LDS_PAD: dynamic LDS bytes on top of the kernel's own image: fewer waves fit a CU (a probe: what would a
+                // form with a larger tile per wave -- 16 outputs per lane, 34 KB -- have left of the latency hiding?)
+                if (const char *lp = getenv("SXFIR_LDS_PAD")) {
+                    p->lds_pad = atoi(lp) > 0 ? atoi(lp) : 0;
+                    int nbw = 0;
+                    if (p->lds_pad && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbw, (const void *)sxfir::decim4_wide_kernel<0, false, 24, true>, 64,
+                                                                                     (size_t)p->lds_pad) == hipSuccess && nbw > 0)
+                        p->occ_wide = nbw;
+                }
             }
             // "pair": decim4_pair_kernel (sxfir_decim_pair.hip.h)
             if (strncmp(v, "pair", 4) == 0 && ntaps == 128) {
