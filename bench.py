@@ -1068,14 +1068,23 @@ def main():
     if world > 1:
         ctl, ctl_name = dist.group.WORLD, backend_name
         if not host_collectives:
+            gloo, why = None, ""
             try:
-                ctl = dist.new_group(backend="gloo")
-                dist.barrier(group=ctl)
-                ctl_name = "gloo"
+                gloo = dist.new_group(backend="gloo")
+                dist.barrier(group=gloo)
             except Exception as e:
+                gloo, why = None, "%s: %s" % (type(e).__name__, str(e)[:120])
+            # every rank decides the SAME way: a rank whose gloo group came up while another's did not would otherwise wait
+            # on a group its peer never joins (until the watchdog).  One all-reduce (min) of "mine works" over the data
+            # communicator, which exists on every rank.
+            ok = torch.tensor([1 if gloo is not None else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                ctl, ctl_name = gloo, "gloo"
+            else:
                 # no host-side group on this node (gloo could not connect the ranks): the control traffic rides the data
                 # communicator instead -- waiting ranks then park RCCL's barrier kernel on their GPUs, which the line says
-                ctl, ctl_name = dist.group.WORLD, "nccl (no gloo group: %s: %s)" % (type(e).__name__, str(e)[:120])
+                ctl, ctl_name = dist.group.WORLD, "nccl (no gloo group on every rank%s)" % ((": " + why) if why else "")
         identities = [None] * world
         dist.all_gather_object(identities, ident, group=ctl)
         comm_ranks = dist.get_world_size()

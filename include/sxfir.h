@@ -53,8 +53,13 @@ extern "C" {
  * 3: sxfir_set_position added (round 3); nothing removed or changed.
  * 4: sxfir_interpolate_keyed and the sxfir_comm_* gather over RCCL added (round 4); nothing removed or changed.
  * 5: sxfir_device_pci_bus_id, sxfir_comm_query and sxfir_contract_rotation added (round 5); the sxfir_comm_* calls now leave the calling thread's
- *    current GPU as they found it; nothing removed. */
-#define SXFIR_ABI_VERSION 5
+ *    current GPU as they found it; nothing removed.  ONE BEHAVIOUR CHANGE: for the decimators by 48 and 96 with 32 taps per phase
+ *    sxfir_contract() now reports (2, 4) where ABI 4 reported (1, ratio), and the pair alone no longer states the contract for
+ *    them: it holds under the rotation sxfir_contract_rotation() reports (1 for these two shapes, 0 elsewhere).  A caller that
+ *    feeds only (jsplit, cw) to its own order-matched check gets other bits for /48 and /96, without an error: read the rotation.
+ * 6: sxfir_launch_geometry added (round 6); decim_blocks_kernel (/48, /96) deals (tile, block) work items when a call has
+ *    fewer tiles than the chip has workgroup slots -- same contract, same bits; nothing removed or changed. */
+#define SXFIR_ABI_VERSION 6
 
 enum {
     SXFIR_OK = 0,
@@ -260,6 +265,21 @@ int sxfir_comm_gather(sxfir_comm *comm, const void *send_dev, void *recv_dev, si
 int sxfir_comm_gather_all(sxfir_comm *const *comms, int ndev, const void *const *send_dev, void *recv_dev,
                           size_t bytes, size_t recv_stride_bytes, int root, size_t chunk_bytes,
                           void *const *streams);
+
+/* What a call with n_in new input samples would launch NOW (16-byte aligned output assumed): kernel family, tiles, workgroups
+ * and how many of those the chip holds at once.  For callers that size their batches (the Device's chains), for
+ * tools/sizebench.py, and for the Device's log line when a plan falls to the generic one-output-per-thread kernels
+ * (tiled == 0: any ratio outside {4, 8, 16, 32, 48, 96} or taps_per_phase != 32 -- two orders of magnitude slower). */
+typedef struct sxfir_geometry {
+    char kernel[64];          /* kernel family, e.g. "decim_blocks_kernel"; "*_generic_kernel" when tiled == 0 */
+    int tiled;                /* 1: an LDS-tiled kernel runs this call; 0: the generic kernel */
+    int split;                /* work items per tile (decim_blocks_kernel's (tile, block) dealing), else 1 */
+    long long tile_samples;   /* wideband samples per tile (a decimator's inputs, an interpolator's outputs) */
+    long long n_tiles;        /* tiles per channel */
+    long long workgroups;     /* workgroups launched, all channels */
+    long long resident;       /* workgroups the chip holds at once (compute units x occupancy) */
+} sxfir_geometry;
+int sxfir_launch_geometry(const sxfir_plan *plan, size_t n_in, sxfir_geometry *geometry);
 
 /* Timed launches for bench.py: runs `iters` back-to-back decimate passes of
  * the same buffers on `stream` bracketed by hipEvents ON THAT STREAM and

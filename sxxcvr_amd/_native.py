@@ -74,6 +74,7 @@ def load_sxfir(profiling=False):
         "sxfir_contract_rotation": (ci, [vp, P(ci)]),
         "sxfir_position": (ci, [vp, P(i64), P(i64)]),
         "sxfir_outputs_for": (ci, [vp, sz, P(sz)]),
+        "sxfir_launch_geometry": (ci, [vp, sz, vp]),
         "sxfir_decimate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
         "sxfir_interpolate": (ci, [vp, vp, sz, sz, vp, sz, P(sz), vp]),
         "sxfir_comm_unique_id": (ci, [vp]),

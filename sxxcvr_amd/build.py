@@ -89,10 +89,25 @@ TARGETS = {
 }
 
 
+def git_commit():
+    """HEAD as the reference's version.sh prints it (SoapySX/version.sh: `git rev-parse HEAD`, "-dirty" when the index
+    differs): what getHardwareInfo()["soapysx_commit"] and makeDevice's log line report (SoapySX.cpp:1577-1581, :1649).
+    None where there is no git checkout (the GPU box's snapshot): the library built in the container is kept."""
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.call(["git", "-C", ROOT, "diff-index", "--quiet", "HEAD", "--"], stderr=subprocess.DEVNULL) != 0
+        return head + ("-dirty" if dirty else "")
+    except (OSError, subprocess.CalledProcessError):
+        return None
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     common = _deps(CSRC, os.path.join(ROOT, "include"))
     built = []
+    commit = git_commit()
+    stamp_file = os.path.join(LIBDIR, ".soapysx_commit")
+    stamped = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
     for name, spec in TARGETS.items():
         srcs = [s if os.path.isabs(s) else os.path.join(CSRC, s) for s in spec["sources"]]
         if not all(os.path.exists(s) for s in srcs):
@@ -100,19 +115,24 @@ def build(force=False, verbose=False):
         out = os.path.join(LIBDIR, name)
         # sources outside csrc/ (the C caller under tools/) are dependencies of their own target only
         deps = common + [s for s in srcs if not s.startswith(CSRC + os.sep)]
-        if not (force or _newer(out, deps)):
+        restamp = name == "libSXSupport.so" and commit is not None and commit != stamped
+        if not (force or restamp or _newer(out, deps)):
             continue
         if spec.get("executable"):
             cmd = [shutil.which("gcc") or "gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-Wall",
                    "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + ["-o", out] + spec.get("libs", [])
         else:
             cc = hipcc() if spec["compiler"] == "hipcc" else (shutil.which("g++") or "g++")
+            stamp = ['-DSOAPYSX_COMMIT="%s"' % (commit or "unknown")] if name == "libSXSupport.so" else []
             cmd = [cc, "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-                   "-I" + os.path.join(ROOT, "include")] + spec["flags"] + srcs + ["-o", out] + spec.get("libs", [])
+                   "-I" + os.path.join(ROOT, "include")] + spec["flags"] + stamp + srcs + ["-o", out] + spec.get("libs", [])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         built.append(out)
+        if name == "libSXSupport.so":
+            with open(stamp_file, "w") as f:
+                f.write(commit or "unknown")
     return built
 
 

@@ -224,7 +224,10 @@ class RxChain {
 public:
     static constexpr size_t kMinBatch = 4096;          // stream samples per channel and GPU pass
     static constexpr size_t kMaxBatchCap = 1u << 20;   // ... at most (large reads), and never more than
-    static constexpr size_t kMaxSource = 1u << 24;     // this many wideband samples per pass over all channels
+    // this many wideband samples per pass over all channels (1 GiB of synthetic source in HBM; round 6: was 2^24, which held the
+    // slow rates to passes of 2^17 (/96) and 2^18 (/48) stream samples -- 256 and 512 tiles of decim_blocks_kernel, half a
+    // round and one round of the chip's workgroup slots per pass, eight and four passes per 2^20-sample read)
+    static constexpr size_t kMaxSource = size_t(1) << 27;
     static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long are DMA-copied straight into page-locked caller memory
     // A pass whose output is at least this large lands in HBM and crosses PCIe as ONE DMA-engine copy behind the
     // kernel (57 GB/s on the boxes measured); smaller ones are stored across PCIe by the kernel itself, into the
@@ -274,6 +277,13 @@ public:
     int ntaps() const { return ntaps_; }
     int channels() const { return nchan_; }
     int64_t direct_samples() const { return direct_samples_; }
+    // what one pass of the smallest batch launches (kernel family, tiled or the generic fallback): sxfir_launch_geometry
+    sxfir_geometry geometry() const
+    {
+        sxfir_geometry g;
+        gpu_check(sxfir_launch_geometry(plan_, kMinBatch * (size_t)decim_, &g), "sxfir_launch_geometry");
+        return g;
+    }
 
     void reset()
     {
@@ -657,6 +667,12 @@ public:
 
     int interp() const { return interp_; }
     int channels() const { return nchan_; }
+    sxfir_geometry geometry() const
+    {
+        sxfir_geometry g;
+        gpu_check(sxfir_launch_geometry(plan_, 4096, &g), "sxfir_launch_geometry");
+        return g;
+    }
     int64_t written() const { return written_; }
     int64_t direct_samples() const { return direct_samples_; }
     size_t slot_frames() const { return slot_frames_; }

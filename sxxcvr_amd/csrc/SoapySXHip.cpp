@@ -40,6 +40,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "GpuChains.hpp"
 #include "Sx1255Shadow.hpp"
@@ -47,7 +48,12 @@
 #include "SynthPcm.hpp"
 
 const char *SoapySXHip_tag = "sx-mi355x";
-const char *SoapySXHip_commit = "round1";
+// (the reference stamps its build with `git describe` / `git rev-parse` through CMake, SoapySX/CMakeLists.txt:18-43; here
+// sxxcvr_amd/build.py and CMakeLists.txt pass -DSOAPYSX_COMMIT="<git rev-parse --short HEAD>"; a tree without git: "unknown")
+#ifndef SOAPYSX_COMMIT
+#define SOAPYSX_COMMIT "unknown"
+#endif
+const char *SoapySXHip_commit = SOAPYSX_COMMIT;
 
 namespace {
 
@@ -101,6 +107,8 @@ private:
     std::unique_ptr<sx::RxChain> rx_chain;
     std::unique_ptr<sx::TxChain> tx_chain;
     sx::Sx1255Shadow chip;      // RF front-end control surface: register values only, no SPI
+    std::vector<long> generic_logged;   // (ratio, taps per phase) shapes already reported by log_generic_once
+    std::string pa_mode = "AUTO";   // writeSetting("PA", ON | OFF | AUTO), :1478-1491; AUTO = the state init leaves (:1487-1490)
 
     int64_t timestamp_to_samples(long long timestamp) const { return SoapySDR::timeNsToTicks(timestamp, sampleRate); }
     long long samples_to_timestamp(int64_t samples) const { return SoapySDR::ticksToTimeNs(samples, sampleRate); }
@@ -122,6 +130,24 @@ private:
             tx_chain.reset(new sx::TxChain(gpu, interp, taps_per_phase, ring_frames, nchan, wire_s32));
             tx_chain->set_threshold2(tx_threshold2);
         }
+        // The LDS-tiled kernels exist for the ratios of the reference's rate table (4 .. 96, SoapySX.cpp:180-208) with
+        // 32 taps per phase; any other `decim` / `interp` / `taps_per_phase` -- arguments this build added -- runs the
+        // generic one-output-per-thread kernels: same bits, about 7 G wideband samples/s where the tiled ones run 500
+        // (DESIGN.md section 5).  Said once per shape, not per call.
+        if (rx) log_generic_once("RX decimator", decim, rx_chain->geometry());
+        if (tx) log_generic_once("TX interpolator", interp, tx_chain->geometry());
+    }
+
+    void log_generic_once(const char *what, int ratio, const sxfir_geometry &g)
+    {
+        if (g.tiled) return;
+        const long key = (long)ratio * 65536 + taps_per_phase;
+        if (std::find(generic_logged.begin(), generic_logged.end(), key) != generic_logged.end()) return;
+        generic_logged.push_back(key);
+        SoapySDR_logf(SOAPY_SDR_INFO,
+                      "%s: ratio %d with %d taps per phase has no LDS-tiled kernel (those cover ratios 4, 8, 16, 32, 48, 96 "
+                      "with 32 taps per phase); it runs %s: the same results, roughly 80 times slower",
+                      what, ratio, taps_per_phase, g.kernel);
     }
 
     void reset_streams()
@@ -174,13 +200,7 @@ public:
     SoapySDR::Stream *setupStream(const int direction, const std::string &format, const std::vector<size_t> &channels,
                                   const SoapySDR::Kwargs &args) override
     {
-        // The reference has one channel and ignores the list (:747).  With `channels=N` a stream carries
-        // all N channels, buffs[c] = channel c: the list may be empty ("automatic") or name exactly those.
-        if (!channels.empty()) {
-            bool ok = channels.size() == (size_t)nchan;
-            for (size_t i = 0; ok && i < channels.size(); ++i) ok = channels[i] == i;
-            if (!ok) throw std::runtime_error("A stream carries all channels of the device: 0.." + std::to_string(nchan - 1));
-        }
+        // The reference's order (:750-764): both locks, format, running, already set up.
         std::scoped_lock lock(pcm_rx.mutex, pcm_tx.mutex);
 
         if (format != "CF32") throw std::runtime_error("Only CF32 format is currently supported");
@@ -189,6 +209,15 @@ public:
 
         auto *stream = direction == SOAPY_SDR_RX ? &pcm_rx : &pcm_tx;
         if (stream->setup_done) throw std::runtime_error("Stream has been setup already");
+
+        // The reference has one channel and ignores the list (:747): so does a one-channel device here, whatever the
+        // list holds.  Only with the build's own `channels=N` (N > 1) does the list mean something: a stream carries all
+        // N channels, buffs[c] = channel c, and the list may be empty ("automatic") or name exactly those.
+        if (nchan > 1 && !channels.empty()) {
+            bool ok = channels.size() == (size_t)nchan;
+            for (size_t i = 0; ok && i < channels.size(); ++i) ok = channels[i] == i;
+            if (!ok) throw std::runtime_error("A stream carries all channels of the device: 0.." + std::to_string(nchan - 1));
+        }
 
         if (stream->is_tx()) {
             const float tx_threshold_default = 1.0e-3;
@@ -586,15 +615,19 @@ public:
         if (key == "CLOCK_ADVANCE") {
             clock.advance(std::stoll(value));
         } else if (key == "PA") {
-            if (value != "ON" && value != "OFF" && value != "AUTO") throw std::runtime_error("Unknown PA setting");
+            // the reference drives two GPIO lines for ON / OFF / AUTO and does nothing for any other value (:1478-1491);
+            // no GPIO here: the mode is remembered (readSetting("PA"), a key of this build), other values change nothing
+            if (value == "ON" || value == "OFF" || value == "AUTO") {
+                std::scoped_lock lock(reg_mutex);
+                pa_mode = value;
+            }
         } else if (key == "TX_CAPTURE_CHANNEL") {
             const int c = std::stoi(value);
             if (c < 0 || c >= nchan) throw std::runtime_error("No such channel");
             std::scoped_lock lock(pcm_tx.mutex);               // txCapture reads it under the TX mutex
             capture_channel = c;
-        } else {
-            throw std::runtime_error("Unknown setting");
         }
+        // any other key: ignored without a word, as the reference does (:1472-1493 has no else branch)
     }
 
     std::string readSetting(const std::string &key) const override
@@ -630,7 +663,12 @@ public:
             std::scoped_lock lock(const_cast<sx::SynthPcm &>(pcm_tx).mutex);
             return std::to_string(capture_channel);
         }
-        throw std::runtime_error("Unknown setting");
+        if (key == "PA") {
+            std::scoped_lock lock(reg_mutex);
+            return pa_mode;
+        }
+        // the reference does not override readSetting (:1495 "TODO"): SoapySDR's default answers "" for every key
+        return "";
     }
 
     // Synthetic sink inspection (used by the C ABI, include/sx_device.h)

@@ -256,29 +256,36 @@ public:
     // write starts the (linked) PCMs (start_threshold = 1).
     int64_t begin_write(int64_t frames, int64_t *first)
     {
-        int64_t target = 0;
-        bool running;
-        {
+        for (;;) {
+            int64_t target = 0;
+            bool running;
+            {
+                std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
+                check_xrun();
+                if (state_ == XRUN) return -EPIPE;
+                running = state_ == RUNNING;
+                if (running) target = start_clock_ + appl_ + frames - (int64_t)hwp_buffer_size;
+            }
+            if (running) clock_->wait_until(target);
             std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
-            check_xrun();
-            if (state_ == XRUN) return -EPIPE;
-            running = state_ == RUNNING;
-            if (running) target = start_clock_ + appl_ + frames - (int64_t)hwp_buffer_size;
+            if (running) {
+                // (no xrun evaluation of its own here: a call that waited for room has by construction not run dry; but a
+                // linked capture PCM that overflowed meanwhile has stopped this one too)
+                if (state_ == XRUN) return -EPIPE;
+            } else if (state_ == RUNNING) {
+                // the linked capture thread's first read started both PCMs between the two looks: this call neither waited
+                // for room (it saw PREPARED) nor may it take the not-running clamp below (the ring drains now) -- look again
+                // and wait as a running PCM does, where ALSA would block
+                continue;
+            } else {
+                const int64_t room = (int64_t)hwp_buffer_size - appl_;
+                if (frames > room) frames = room > 0 ? room : 0;   // not running: cannot drain
+            }
+            *first = appl_;
+            appl_ += frames;
+            if (state_ == PREPARED && frames > 0 && stream_mode == STREAM_MODE_LINK) start();
+            return frames;
         }
-        if (running) clock_->wait_until(target);
-        std::lock_guard<std::recursive_mutex> lk(clock_->link_mutex());
-        if (running) {
-            // (no xrun evaluation of its own here: a call that waited for room has by construction not run dry; but a
-            // linked capture PCM that overflowed meanwhile has stopped this one too)
-            if (state_ == XRUN) return -EPIPE;
-        } else if (state_ != RUNNING) {
-            const int64_t room = (int64_t)hwp_buffer_size - appl_;
-            if (frames > room) frames = room > 0 ? room : 0;   // not running: cannot drain
-        }
-        *first = appl_;
-        appl_ += frames;
-        if (state_ == PREPARED && frames > 0 && stream_mode == STREAM_MODE_LINK) start();
-        return frames;
     }
 
 private:

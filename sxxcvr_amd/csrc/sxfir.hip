@@ -15,7 +15,10 @@
 #include <vector>
 
 #include "sxfir_decim_tile.hip.h"
-#include "sxfir_decim_multi.hip.h"
+#include "sxfir_common.hip.h"
+#ifdef SXFIR_PROFILING
+#include "sxfir_decim_multi.hip.h"              // A/B partner of decim_dense_kernel: no instance in the production library since round 5
+#endif
 
 // Instantiated (ratio, waves per workgroup, CF16, row split) variants of the multi-column decimator: one list
 // for the occupancy query in sxfir_create and the launch in launch_decim.  The production library carries
@@ -57,9 +60,9 @@
 #include "sxfir_decim_blocks.hip.h"             // /48, /96: sixteen-column blocks (whole input lines), scalar taps (round 5)
 #include "sxfir_interp_tile.hip.h"
 #include "sxfir_interp_pass.hip.h"
-#include "sxfir_decim_tile2.hip.h"
 #include "sxfir_decim_wide.hip.h"               // /4, 128 symmetric taps: the shipped form since round 4
 #ifdef SXFIR_PROFILING
+#include "sxfir_decim_tile2.hip.h"              // round 3's /4 form and its variants: A/B partners of the wide kernel, no instance in the production library since round 4
 #include "experiments/sxfir_decim_pair.hip.h"   // measured variant, not shipped (LABBOOK.md 5.1)
 #endif
 #ifdef SXFIR_PROFILING

@@ -34,6 +34,17 @@
 //     exchanged, behind the arithmetic of the CU's other workgroup.
 //
 // Edge tiles (first / last of a call), the fused history carry-over and the ragged last stores follow the dense kernel.
+//
+// SPLIT (round 6): calls the API really issues are small -- readStream / writeStream blocks are 256 .. 8192 samples
+// (SoapySX.cpp:868-1105; the Device's chains batch them into passes of 2^17 .. 2^24 wideband samples) -- and a tile here is
+// 512 outputs x 48 / 96 inputs: a 2^22-sample call at /96 is 86 tiles for 512 workgroup slots, each walking its six blocks one
+// after the other.  The SPLIT instance deals (tile, block) ITEMS instead: one workgroup per item, NB times the workgroups, one
+// step each.  The block values of a tile then meet through HBM: every item writes its block value (4 KiB) to the plan's
+// scratch with device-scope stores and counts itself in; the item that finds NB - 1 others before it reads all NB values back
+// (device-scope loads) and adds them in the contract's order -- (B0 + B1) + B2, ((B0 + B1) + (B2 + B3)) + (B4 + B5): the
+// order is fixed by the block numbers, not by who arrives when, so the bits are those of the walking form.  sxfir_launch
+// chooses SPLIT while a call has at most twice as many tiles as the chip has slots (beyond that the walking form's rounds are
+// as full, and it keeps a tile's blocks on one XCD).
 #pragma once
 
 #include "sxfir_decim_dense.hip.h"
@@ -65,8 +76,13 @@ struct DecimBlocks16 {
 // floats = 16 slots): four per 128-byte-line instruction of the CF32 form.  A block's piece of a row is 64 bytes here -- half a
 // line, the other half the neighbouring block's -- so each line crosses the L2's memory side twice: the bytes of the CF32 form,
 // not half of them (the kernel is arithmetic-bound at either).
-template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false>
-__global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs a)
+struct DecimBlocksJoin {
+    f32x4 *partials;        // [channel][tile][block][256 lanes]: a block value, two outputs per lane
+    unsigned *arrived;      // [channel][tile]: items of the tile that have written theirs; the last one resets it to 0
+};
+
+template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false, bool SPLIT = false>
+__global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs a, const DecimBlocksJoin jn)
 {
     static_assert(NB == 3 || NB == 6, "ratios 48 and 96");
     static_assert(!(HALFIN && S32IN), "one storage format");
@@ -107,10 +123,27 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     // samples, 5462 tiles on 4096 workgroups, 0.67 ms against 0.53 ms balanced).
     const int perm = (NG % 8 == 0) ? (int)(blockIdx.x % 8) * (NG / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int R = a.n_tiles / NG, rem = a.n_tiles % NG;
-    const int n_rounds = R + ((int)blockIdx.x < rem ? 1 : 0);
+    const int n_rounds = SPLIT ? 1 : R + ((int)blockIdx.x < rem ? 1 : 0);
     auto tile_of = [&](int r) __attribute__((always_inline)) { return r < R ? r * NG + perm : R * NG + (int)blockIdx.x; };
+    // SPLIT: NG = n_tiles * NB items, one per workgroup, in dispatch order (workgroups start in blockIdx order; HIP does not
+    // promise it, and nothing but speed depends on it): FIRST the items of the call's edge tiles -- the last tile and tile 0,
+    // whose images go through registers sample by sample and take the longest -- then the interior tiles block-major.  (With
+    // the edge items last, the four workgroups that did not fit the first round of a 2^22-sample call at /96 -- 516 items
+    // on 512 slots -- were exactly the slow ones: 22 us against 15 for one round.)
+    int split_tile = 0, split_blk = 0;
+    if constexpr (SPLIT) {
+        const int bx = (int)blockIdx.x, ne = a.n_tiles < 2 ? a.n_tiles : 2;
+        if (bx < ne * NB) {
+            split_blk = bx / ne;
+            split_tile = (bx % ne) ? 0 : a.n_tiles - 1;
+        } else {
+            const int j = bx - ne * NB, ni = a.n_tiles - ne;
+            split_blk = j / ni;
+            split_tile = 1 + j % ni;
+        }
+    }
     // fused history carry-over (by the owner of the call's last tile): the tail of (hist ++ in) becomes the next history
-    if ((rem ? (int)blockIdx.x == rem - 1 : perm == NG - 1) && ww == C::W - 1) {
+    if ((SPLIT ? blockIdx.x == 0 : (rem ? (int)blockIdx.x == rem - 1 : perm == NG - 1)) && ww == C::W - 1) {
         char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)SB * a.hist_stride * ch;
         const char *hi = reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch;
         for (int j = lane; j < NT; j += 64) {
@@ -169,7 +202,9 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
                 return;
             }
         }
-        if (interior) {
+        // (structural, not left to the optimizer: an instance whose typed front end writes M0 from inline asm holds no
+        // compiler-managed LDS-DMA at all -- LLVM may hoist or merge ITS M0 set-up across an asm statement it cannot see into)
+        if constexpr (!HALFIN) if (interior) {
             const char *base = in + 8 * s_first + (8 * D * C::RPI) * ww;
 #pragma unroll
             for (int i0 = 0; i0 < C::NIW; ++i0) {
@@ -181,16 +216,19 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
                 if (NTLD && i0 >= 1 && i0 < 16) glds16<2>(bi + lo, lds + (65 * ww + C::dma_slot(4 * i0)));
                 else glds16(bi + lo, lds + (65 * ww + C::dma_slot(4 * i0)));
             }
-        } else {
+            return;
+        }
+        {
             // edge tiles (first / last of a call): through registers, sample by sample
             const auto *ap = rare_args();
             const long long last = ap->n_in - 1;
             const char *hist = reinterpret_cast<const char *>(ap->hist) + (long long)SB * ap->hist_stride * ch;
-#pragma nounroll
-            for (int i0 = 0; i0 < C::NIW; ++i0) {
+            // SPLIT (a small call's latency IS its edge items'): every load of the step in flight before the first LDS write --
+            // 34 (17 with half pairs: 8 bytes hold both samples) independent loads instead of 17 round trips to memory one
+            // after the other; the walking form keeps the loop (an edge tile is one of thousands there, registers matter more)
+            auto edge_chunk = [&](int i0, unsigned (&wds)[4]) __attribute__((always_inline)) {
                 const int i = ww + 4 * i0;
                 const int cidx = 64 * i + lane;                          // chunk of the image: row cidx / 8, chunk cidx % 8
-                unsigned wds[4];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const long long s = s_first + (long long)D * (cidx >> 3) + 2 * (cidx & 7) + e;
@@ -205,8 +243,23 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
                         wds[2 * e + 1] = reinterpret_cast<const unsigned *>(src)[1];
                     }
                 }
-                lds[C::dma_slot(i) + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]), __uint_as_float(wds[2]),
-                                                     __uint_as_float(wds[3])};
+            };
+            if constexpr (SPLIT) {
+                unsigned wall[C::NIW][4];
+#pragma unroll
+                for (int i0 = 0; i0 < C::NIW; ++i0) edge_chunk(i0, wall[i0]);
+#pragma unroll
+                for (int i0 = 0; i0 < C::NIW; ++i0)
+                    lds[C::dma_slot(ww + 4 * i0) + lane] = (f32x4){__uint_as_float(wall[i0][0]), __uint_as_float(wall[i0][1]),
+                                                                   __uint_as_float(wall[i0][2]), __uint_as_float(wall[i0][3])};
+            } else {
+#pragma nounroll
+                for (int i0 = 0; i0 < C::NIW; ++i0) {
+                    unsigned wds[4];
+                    edge_chunk(i0, wds);
+                    lds[C::dma_slot(ww + 4 * i0) + lane] = (f32x4){__uint_as_float(wds[0]), __uint_as_float(wds[1]), __uint_as_float(wds[2]),
+                                                                   __uint_as_float(wds[3])};
+                }
             }
         }
     };
@@ -216,8 +269,8 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     };
 
     if (n_rounds == 0) return;
-    int round = 0, tile = tile_of(0), blk = 0;
-    stage(tile, 0);
+    int round = 0, tile = SPLIT ? split_tile : tile_of(0), blk = SPLIT ? split_blk : 0;
+    stage(tile, blk);
     f32x4 lv0, lv1, lv2;                                // waiting block sums of 1, 2, 4 blocks
     lv0 = lv1 = lv2 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     while (true) {
@@ -286,6 +339,54 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) col[cc] = add4(lds[256 * (2 * cc) + 64 * ww + lane], lds[256 * (2 * cc + 1) + 64 * ww + lane]);
             y = add4(add4(col[0], col[1]), add4(col[2], col[3]));
+        }
+        if constexpr (SPLIT) {
+            // ---- this item's block value to HBM; the tile's last item to arrive adds the NB values in the contract's order
+            // Device-scope (sc1) stores and loads, not fences: the eight XCDs' L2s are not coherent with each other, and a release /
+            // acquire fence pair at device scope writes back and INVALIDATES the issuing XCD's whole L2 -- once per workgroup that
+            // cost 150 ns per item and the halo lines every neighbour was about to reuse (first build: /96 at 2^24 samples 303 us
+            // against the walking form's 66).  A device-scope store goes through to memory, a device-scope load comes from there;
+            // the barrier's s_waitcnt vmcnt(0) sees the stores acknowledged before lane 0 counts the item in.
+            // (the form is row 1 of the hand-off table in MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup
+            // visibility": sc1 stores, every storing wave's vmcnt(0), a workgroup barrier, ONE lane's device-scope atomic add, the
+            // workgroup whose add came last -- told by the value the add returned -- loads sc1 behind a barrier that lane joins)
+            const long long slot = ((long long)ch * a.n_tiles + tile) * NB;
+            {
+                const f32x4 *q = jn.partials + (slot + blk) * 256 + tid;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(y) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned *arrived = jn.arrived + ((long long)ch * a.n_tiles + tile);
+            if (tid == 0) reinterpret_cast<unsigned *>(lds)[0] = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (reinterpret_cast<const unsigned *>(lds)[0] != (unsigned)(NB - 1)) return;
+            f32x4 bv[NB];
+            {
+                const f32x4 *q = jn.partials + slot * 256 + tid + 256;  // block b at q + 256 (b - 1): 4096 (b - 1) bytes on
+                static_assert(NB == 3 || NB == 6, "the load lists below");
+                if constexpr (NB == 3)
+                    asm volatile("global_load_dwordx4 %0, %3, off offset:-4096 sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:-4096 sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]) : "v"(q), "v"(q + 512) : "memory");
+                else
+                    asm volatile("global_load_dwordx4 %0, %6, off offset:-4096 sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
+                                 "global_load_dwordx4 %2, %7, off offset:-4096 sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\t"
+                                 "global_load_dwordx4 %4, %8, off offset:-4096 sc1\n\tglobal_load_dwordx4 %5, %8, off sc1\n\t"
+                                 "s_waitcnt vmcnt(0)"
+                                 : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]), "=&v"(bv[4]), "=&v"(bv[5])
+                                 : "v"(q), "v"(q + 512), "v"(q + 1024) : "memory");
+            }
+            if (tid == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts from zero
+            f32x4 r = add4(add4(bv[0], bv[1]), bv[2]);      // (B0 + B1) + B2
+            if constexpr (NB == 6) r = add4(add4(add4(bv[0], bv[1]), add4(bv[2], bv[3])), add4(bv[4], bv[5]));
+            const long long M0 = (long long)tile * C::TILE_OUT;
+            const int Gq = 16 * ww + (lane >> 2), kq = (lane & 3) ^ ((Gq >> 1) & 3);
+            const long long m = M0 + 8 * Gq + 2 * kq;
+            char *dst = out + SB * m;
+            if (m + 2 <= a.n_out) store_pair<HALFIN>(dst, r.x, r.y, r.z, r.w);
+            else if (m < a.n_out) store_one<HALFIN>(dst, r.x, r.y);
+            return;
         }
         __syncthreads();                                    // the exchange area may be overwritten by the next DMA
         int nblk = blk + 1, ntile = tile;

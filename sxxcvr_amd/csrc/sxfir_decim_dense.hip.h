@@ -32,8 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "sxfir_decim_multi.hip.h"
-#include "sxfir_decim_tile2.hip.h"       // pk_fma_s_lo / pk_fma_s_hi, rgrp_table
+#include "sxfir_common.hip.h"            // DecimMultiArgs, pk_fma_s_lo / pk_fma_s_hi, rgrp_table, half <-> float
 
 namespace sxfir {
 
@@ -291,7 +290,9 @@ decim_dense_kernel(const DecimMultiArgs a)
                 return;
             }
         }
-        if (interior) {
+        // (structural, not left to the optimizer: an instance whose typed front end writes M0 from inline asm holds no
+        // compiler-managed LDS-DMA at all -- LLVM may hoist or merge ITS M0 set-up across an asm statement it cannot see into)
+        if constexpr (!HALFIN) if (interior) {
             f32x4 hv[C::NIW - 8];
             if constexpr (HC) {
                 if (carry) {
@@ -341,7 +342,9 @@ decim_dense_kernel(const DecimMultiArgs a)
                     }
                 }
             }
-        } else {
+            return;
+        }
+        {
             // edge tiles (first / last of a call): through registers, sample by sample.  What only they need is read
             // from the kernel arguments here, not kept in registers across the tile loop.
             const auto *ap = rare_args();

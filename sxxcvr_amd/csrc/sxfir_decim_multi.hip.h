@@ -31,21 +31,9 @@
 #include <hip/hip_fp16.h>
 
 #include "sxfir_decim_tile.hip.h"
+#include "sxfir_common.hip.h"      // DecimMultiArgs, permlane16_swap, half <-> float (shared with the shipped kernels)
 
 namespace sxfir {
-
-struct DecimMultiArgs {
-    const void *in;         // channel 0, sample 0 of this call (aligned to one complex sample)
-    const void *hist;       // NT samples preceding `in`
-    void *hist_out;
-    void *out;              // 16-byte aligned
-    const float *taps;
-    long long n_in, n_out;
-    long long in_stride, out_stride, hist_stride;
-    int n_tiles;            // workgroup tiles per channel
-    int n_groups;           // workgroups per channel (strided passes over the tiles)
-    unsigned long long *stamps;   // diagnostic builds only (ABL 3): 5 counters per wave
-};
 
 template <int D, int W, bool HALF = false, int PS = 2>
 struct DecimMulti {
@@ -104,23 +92,6 @@ struct DecimMulti {
                     : r - (((r + 1) * 3856) >> 16);       // (r+1)/17
     }
 };
-
-__device__ __forceinline__ void permlane16_swap(float &vdst, float &src)
-{
-    // odd 16-lane rows of vdst <-> even rows of src (inline asm for the same reason as permlane32_swap)
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(vdst), "+v"(src));
-}
-
-__device__ __forceinline__ float half_bits_to_float(unsigned bits16)
-{
-    return __half2float(__ushort_as_half((unsigned short)bits16));
-}
-
-__device__ __forceinline__ unsigned pack_half2(float i, float q)
-{
-    const __half2 h = __floats2half2_rn(i, q);
-    return *reinterpret_cast<const unsigned *>(&h);
-}
 
 // ABL (profiling only): 1 = staging + stores without the FIR, 2 = FIR without staging, 3 = the real
 // kernel with s_memtime stamps around its phases (a.stamps)

@@ -46,6 +46,7 @@
 #include <utility>
 
 #include "sxfir_decim_tile.hip.h"
+#include "sxfir_common.hip.h"      // pk_fma_s_*, slot_source_offset, rgrp_table (shared with the shipped kernels)
 
 namespace sxfir {
 
@@ -85,35 +86,9 @@ enum { T2_DEFER = 1, T2_TAPSEP = 2, T2_DBUF = 4, T2_PLAINST = 8, T2_HCARRY = 16,
        T2_NTLD7 = 524288,
        T2_SHIPPED = T2_SCALAR | T2_XGROUP | T2_NTLD7 };
 
-// byte offset (from the tile's first staged chunk) of the chunk that lands in slot q of the image
-__device__ __forceinline__ unsigned slot_source_offset(unsigned q, unsigned chunks)
-{
-    unsigned off = q - (((q + 1u) * 3856u) >> 16);                        // (q+1)/17, exact for q < 4096
-    off = off < chunks ? off : chunks - 1u;
-    return 16u * off;
-}
-
 // HBM -> LDS for the slots [Q0, Q0 + 64*(NI-1) + LASTL) of one tile's image: DMA instruction j fills the slots
 // Q0 + 64j + lane from the per-lane byte offsets off[j] (tile-invariant, see slot_source_offset).  The last
 // instruction is issued for LASTL lanes.
-// output group r of lanes 8k..8k+7 of a half-wave, 5 bits each (see the kernel: conflict-free ds_read_b128 groups)
-constexpr unsigned long long rgrp_word(int k)
-{
-    unsigned long long w = 0;
-    for (int i = 0; i < 8; ++i) {
-        const int l5 = 8 * k + i;
-        const bool first = l5 < 4 || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
-        const int idx = first ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
-        w |= (unsigned long long)(2 * idx + (first ? 0 : 1)) << (5 * i);
-    }
-    return w;
-}
-__device__ __forceinline__ unsigned long long rgrp_table(int k)
-{
-    constexpr unsigned long long W0 = rgrp_word(0), W1 = rgrp_word(1), W2 = rgrp_word(2), W3 = rgrp_word(3);
-    return k == 0 ? W0 : (k == 1 ? W1 : (k == 2 ? W2 : W3));
-}
-
 // lanes of the DMA instruction that starts at slot q0 whose slot is a pad slot (never read)
 constexpr unsigned long long pad_lanes(int q0)
 {
@@ -203,26 +178,6 @@ __device__ __forceinline__ void fir_tile_pk(const f32x4 *win, const f32x2 (&hp)[
         oi[i] = __fadd_rn(a0, a1);
         oq[i] = __fadd_rn(b0, b1);
     }
-}
-
-// the same packed FMAs with the tap pair in SGPRs
-__device__ __forceinline__ void pk_fma_s_lo(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
-}
-__device__ __forceinline__ void pk_fma_s_hi(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
-}
-// the first FMA of a chain: acc = fmaf(tap, x, +0.0f) with the zero as an inline constant, so no register is cleared first
-// (a cleared register costs a v_mov_b64 per chain and tile: 0.6 of a packed FMA's energy each, profiles/round4z9_price_list.txt)
-__device__ __forceinline__ void pk_fma_s_lo_first(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(acc) : "s"(hpair), "v"(x));
-}
-__device__ __forceinline__ void pk_fma_s_hi_first(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "s"(hpair), "v"(x));
 }
 
 // FIR arithmetic of one tile for a symmetric 128-tap filter, taps hs[m] = {h[2m], h[2m+1]}, m < 32, in SGPRs.
@@ -334,15 +289,6 @@ __device__ __forceinline__ void fir_tile_sym(const f32x4 *w1, const f32x4 *w2, c
 // latency once per step, and only its neighbours on the SIMD hide it.  Here the reads are volatile loads and the
 // FMAs volatile asm, which keeps them in program order: the chunks of step T + PF are requested before the FMAs
 // of step T, and the compiler's own s_waitcnt becomes a counted lgkmcnt(2 * PF - ...) that finds the data there.
-__device__ __forceinline__ void pk_fma_sv_lo(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
-{
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
-}
-__device__ __forceinline__ void pk_fma_sv_hi(f32x2 &acc, const f32x2 &hpair, const f32x2 &x)
-{
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(hpair), "v"(x));
-}
-
 template <int WHICH, int S, int T>
 __device__ __forceinline__ void fir_sym_quad_v(const f32x2 &x, const f32x2 (&hs)[32], f32x2 (&acc)[4])
 {

@@ -30,7 +30,7 @@
 #include <utility>
 
 #include "sxfir_decim_tile.hip.h"
-#include "sxfir_decim_tile2.hip.h"
+#include "sxfir_common.hip.h"            // pk_fma_s_* / pk_fma_sv_*, slot_source_offset
 #include "sxfir_decim_dense.hip.h"      // v4i32, half_lo_to_float / half_hi_to_float, pack_half2 (the CF16 front end)
 
 namespace sxfir {

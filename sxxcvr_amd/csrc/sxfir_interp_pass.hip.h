@@ -41,7 +41,7 @@
 #include <utility>
 
 #include "sxfir_interp_tile.hip.h"
-#include "sxfir_decim_tile2.hip.h"       // pk_fma_s_lo / pk_fma_s_hi
+#include "sxfir_common.hip.h"            // pk_fma_s_lo / pk_fma_s_hi
 
 namespace sxfir {
 
@@ -114,12 +114,20 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
 // inside the tile loop over the SAME window (an interpolator's phases never meet; block pb is the x16 problem on the taps
 // h[j LT + 16 pb + r], pass-major table, block pb at 512 pb; an input's sixteen outputs of a block are one whole line).  The next
 // tile's DMAs are awaited behind the FIRST block's stores (the same counted wait, one block earlier).
-template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true, int LL = 8, int LT = LL>
+// PBSPLIT (round 6; x32, x48, x96): the calls the API really issues are small (writeStream blocks of 256 .. 8192 samples, SoapySX.cpp:969-1105,
+// batched by the Device's TX chain) and a tile here is 128 inputs x LT outputs walked block after block by one wave: a 2^22-output call
+// at x96 is 342 tiles for 2048 wave slots.  An interpolator's phases never meet, so the PBSPLIT instance deals (tile, phase block) ITEMS:
+// the launch passes n_tiles = tiles x LT / 16 items, item v is block v % NPB of tile v / NPB (a tile's blocks next to each other in the
+// schedule: its 1 KiB of input is fetched from HBM once), one block per loop iteration -- the x16 kernel's loop with a block's tap table
+// and output stride.  No join, same bits.  sxfir_launch chooses it while a call has at most twice as many tiles as the chip holds waves.
+template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true, int LL = 8, int LT = LL, bool PBSPLIT = false>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {
     using C = InterpPass8<QI, LL>;
     static_assert(LT % LL == 0 && (LT == LL || LL == 16), "phase blocks of sixteen");
-    constexpr int NPB = LT / LL;
+    static_assert(!PBSPLIT || LT > LL, "items are phase blocks");
+    constexpr int NPBT = LT / LL;                 // phase blocks per tile
+    constexpr int NPB = PBSPLIT ? 1 : NPBT;       // ... walked per loop iteration (per item)
     __shared__ __attribute__((aligned(16))) f32x4 lds[C::IMG + C::OBUF];
     f32x4 *obuf = lds + C::IMG;
 
@@ -154,7 +162,8 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
     // (and store all their outputs), of those all but tile 0 have their history inside this call's input
     static_assert(C::TILE_IN >= C::HIST && (C::TILE_IN & (C::TILE_IN - 1)) == 0, "tile 0 is the only one that reaches into the history");
     const int n_full = (int)(a.n_in / C::TILE_IN);
-    auto stage = [&](int tile) __attribute__((always_inline)) {
+    auto stage = [&](int item) __attribute__((always_inline)) {
+        const int tile = PBSPLIT ? item / NPBT : item;
         const long long q0 = (long long)tile * C::TILE_IN;
         const bool interior = tile >= 1 && tile < n_full;
         if (interior) {
@@ -197,6 +206,29 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         return ap->thr2;
     };
 
+    // LL = 16: lane constants of the output path (round 6: 128 of the ~1200 VALU instructions per block of 1024 FMAs were address
+    // arithmetic).  The transposition slot of chunk k = 8 qi + 2 c + e of lane g is 16 g + (k ^ (g & 15)); qi, c, e occupy disjoint
+    // bits of k, so it is ((8 qi + e) ^ (g & 15)) ^ 2 c: four slots per lane once, one XOR with 2 c per pass pair.  The store of slot
+    // 64 i + lane goes to byte 64 LT i + voff[i & 3] of the block's output: g2 = 4 i + lane / 16, k2 = (lane & 15) ^ (g2 & 15) =
+    // kb ^ 4 (i & 3) with kb = (lane & 15) ^ (lane >> 4), and sample (2 g2 + k2 / 8) LT + 2 (k2 % 8) of the block.
+    unsigned wslot[QI][2], voff[4];
+    if constexpr (LL == 16) {
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                wslot[qi][e] = 16u * (unsigned)(C::CPL * lane + ((8 * qi + e) ^ (lane & 15)));       // in bytes
+                asm volatile("" : "+v"(wslot[qi][e]));
+            }
+        const unsigned kb = (unsigned)((lane & 15) ^ (lane >> 4));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned k2 = kb ^ (unsigned)(4 * t);
+            voff[t] = (unsigned)(8 * LT) * (2u * (unsigned)(lane >> 4) + (k2 >> 3)) + 16u * (k2 & 7u);
+            asm volatile("" : "+v"(voff[t]));
+        }
+    }
+
     int tile = first_tile;
     if (tile >= a.n_tiles) return;
     stage(tile);
@@ -217,7 +249,9 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             // (phase blocks: awaited behind the previous tile's first block; the workgroup's first tile here)
             if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const long long q0 = (long long)tile * C::TILE_IN;
+        const int rtile = PBSPLIT ? tile / NPBT : tile;             // (PBSPLIT: `tile` counts items)
+        const int pb0 = PBSPLIT ? tile % NPBT : 0;
+        const long long q0 = (long long)rtile * C::TILE_IN;
 
         // ---- the lane's window, once: samples q0 + QI g - 32 .. q0 + QI g + QI - 1  ->  image chunks (QI/2) g .. + NWU - 1
         // (pass p uses chunks 8 - 8p + t, t = 0 .. NW - 1, of these)
@@ -229,7 +263,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (KEYED) {
-            if (ch == 0) {
+            if (ch == 0 && pb0 == 0) {                                 // (PBSPLIT: a tile's inputs are counted by its first item)
                 const __attribute__((address_space(4))) InterpTileArgs *ap =
                     (const __attribute__((address_space(4))) InterpTileArgs *)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(ap));
@@ -262,7 +296,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         if (next < a.n_tiles) counted = stage(next);
 
 #pragma unroll 1
-        for (int pb = 0; pb < NPB; ++pb) {
+        for (int pb = pb0; pb < pb0 + NPB; ++pb) {
         // ---- four passes (x4: two, x16: eight): phase group c (outer), row half p (inner)
 #pragma unroll 1
         for (int c = 0; c < C::L / 4; ++c) {
@@ -288,9 +322,15 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             // phases 4c..4c+3 of the lane's inputs: chunks k = (L / 2) qi + 2c + {0, 1} of its CPL
 #pragma unroll
             for (int qi = 0; qi < QI; ++qi) {
-                const int k = (C::L / 2) * qi + 2 * c;
-                obuf[C::CPL * lane + (k ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][0].x, y[qi][0].y, y[qi][1].x, y[qi][1].y};
-                obuf[C::CPL * lane + ((k + 1) ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][2].x, y[qi][2].y, y[qi][3].x, y[qi][3].y};
+                if constexpr (LL == 16) {
+                    char *ob8 = reinterpret_cast<char *>(obuf);
+                    *reinterpret_cast<f32x4 *>(ob8 + (wslot[qi][0] ^ (unsigned)(32 * c))) = (f32x4){y[qi][0].x, y[qi][0].y, y[qi][1].x, y[qi][1].y};
+                    *reinterpret_cast<f32x4 *>(ob8 + (wslot[qi][1] ^ (unsigned)(32 * c))) = (f32x4){y[qi][2].x, y[qi][2].y, y[qi][3].x, y[qi][3].y};
+                } else {
+                    const int k = (C::L / 2) * qi + 2 * c;
+                    obuf[C::CPL * lane + (k ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][0].x, y[qi][0].y, y[qi][1].x, y[qi][1].y};
+                    obuf[C::CPL * lane + ((k + 1) ^ (lane & (C::CPL - 1)))] = (f32x4){y[qi][2].x, y[qi][2].y, y[qi][3].x, y[qi][3].y};
+                }
             }
         }
 
@@ -300,9 +340,9 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         const long long o0 = q0 * LT + C::L * pb;               // first output sample of the tile (of this phase block)
         // chunk k2 of lane g2's row: input k2 / (L / 2), chunk k2 % (L / 2) of its L outputs of this block
         auto out_sample = [&](int g2, int k2) __attribute__((always_inline)) {
-            return NPB == 1 ? o0 + 2 * (C::CPL * g2 + k2) : o0 + (long long)(QI * g2 + k2 / (C::L / 2)) * LT + 2 * (k2 % (C::L / 2));
+            return NPBT == 1 ? o0 + 2 * (C::CPL * g2 + k2) : o0 + (long long)(QI * g2 + k2 / (C::L / 2)) * LT + 2 * (k2 % (C::L / 2));
         };
-        if (tile < n_full) {
+        if (rtile < n_full) {
             // all CPL reads in flight, then CPL stores back to back (decided per wave, not per lane and store)
             f32x4 v[C::CPL];
 #pragma unroll
@@ -315,11 +355,22 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
                     v[i] = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
                 }
             }
+            if constexpr (LL == 16) {
+                // a scalar base per store (the block's first output byte + 64 LT i) and one of the lane's four constant offsets
+                // (written out: the compiler turns base + zext(offset) into 64-bit vector adds, two VALU instructions per store)
+                const unsigned long long ob = (unsigned long long)(uintptr_t)(out + 2 * o0);
+#pragma unroll
+                for (int i = 0; i < C::CPL; ++i) {
+                    const unsigned long long bi = ob + (unsigned long long)(64 * LT) * i;
+                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(voff[i & 3]), "v"(v[i]), "s"(bi) : "memory");
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < C::CPL; ++i) {
                 const int slot = 64 * i + lane;
                 const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
                 __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(out + 2 * out_sample(g2, k2)));
+            }
             }
         } else {
             // the call's last tile (no counted wait follows it: the wave ends here)

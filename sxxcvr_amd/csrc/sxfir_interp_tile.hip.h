@@ -184,8 +184,10 @@ __global__ __launch_bounds__(64) void interp_tile_kernel(const InterpTileArgs a)
             cc = cc < (unsigned)C::CHUNKS ? cc : (unsigned)C::CHUNKS - 1u;
             asm volatile("" : "+v"(cc));
             const long long s = q0 - 32 + 2 * (long long)cc;
-            if (interior) {
-                glds16(reinterpret_cast<const char *>(in + 2 * (q0 - 32)) + 16u * cc, lds + 64 * i);
+            bool dma = interior;
+            if constexpr (HALF) dma = false;       // structural: a HALF instance (M0 written from inline asm above) holds no compiler-managed LDS-DMA
+            if (dma) {
+                if constexpr (!HALF) glds16(reinterpret_cast<const char *>(in + 2 * (q0 - 32)) + 16u * cc, lds + 64 * i);
             } else {
                 float2 v0, v1;
                 const long long last = a.n_in - 1;

@@ -34,6 +34,95 @@ static int need_tap_table(const sxfir_plan *p, int layout, const char *kernel)
 #include "sxfir_prof_dispatch.inc"   // the A/B variants' launch tables: 0 = not mine, 1 = launched, < 0 = error
 #endif
 
+// Launch geometry of a call: which kernel family, how many tiles, how many workgroups, how many of them the chip holds at
+// once.  One statement of it for launch_decim / launch_interp and for sxfir_launch_geometry (tools/sizebench.py, the Device's
+// log line for plans that fall to the generic kernels).
+struct LaunchGeom {
+    int kind;                 // GEOM_*
+    const char *kernel;
+    long long tile_out;       // decimator: outputs per tile; interpolator: inputs per tile
+    long long n_tiles;        // per channel
+    long long groups;         // workgroups per channel (times phase blocks for the CF16 interpolator tile kernel)
+    long long resident;       // workgroups the chip holds at once, all channels
+    int split;                // work items per tile ((tile, block) dealing of decim_blocks_kernel), else 1
+};
+enum { GEOM_GENERIC = 0, GEOM_MULTI = 1, GEOM_WIDE = 2, GEOM_TILE = 3, GEOM_IPASS = 4, GEOM_ITILE = 5 };
+
+static long long clamp_groups(long long g, long long n_tiles)
+{
+    if (g < 1) g = 1;
+    return g > n_tiles ? n_tiles : g;
+}
+
+// `aligned`: the output is 16-byte aligned with an even channel stride (what the tiled kernels' stores need)
+static LaunchGeom decim_geom(const sxfir_plan *p, long long n_out, bool aligned, bool aligned_multi)
+{
+    LaunchGeom g{GEOM_GENERIC, "decim_generic_kernel", 256, (n_out + 255) / 256, (n_out + 255) / 256,
+                 (long long)p->compute_units * 8, 1};
+    const long long D = p->ratio;
+    const long long first = ((p->consumed + D - 1) / D) * D - p->consumed;
+    const bool want = p->kernel != SXFIR_KERNEL_GENERIC && first == 0;
+    if (p->multi_capable && want && aligned_multi) {
+        g.kind = GEOM_MULTI;
+        g.kernel = p->blocks ? "decim_blocks_kernel" : p->dense32 ? "decim_dense_kernel" : "decim_multi_kernel";
+        g.tile_out = p->blocks ? 512 : p->multi_waves * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
+        g.n_tiles = (n_out + g.tile_out - 1) / g.tile_out;
+        g.resident = (long long)p->compute_units * p->occ_multi;
+        g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles);
+        // /48, /96: while a call has at most twice as many tiles as the chip has workgroup slots, (tile, block) items are dealt,
+        // one workgroup each (decim_blocks_kernel<..., SPLIT>); the plan's scratch holds that many block values
+        if (p->blocks && p->join_partials && p->blocks_split && g.n_tiles * p->nchan <= p->join_tiles) {
+            g.split = p->blocks;
+            g.groups = g.n_tiles * p->blocks;
+        }
+        return g;
+    }
+    if (p->tile_capable && want && aligned) {
+        if (p->wide8 && p->sched != 1) {
+            g.kind = GEOM_WIDE;
+            g.kernel = "decim4_wide_kernel";
+            g.tile_out = 512;
+            g.n_tiles = (n_out + 511) / 512;
+            g.resident = (long long)p->compute_units * p->occ_wide;
+            g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles);
+            return g;
+        }
+        g.kind = GEOM_TILE;
+        g.kernel = "decim4_tile_kernel";
+        g.tile_out = 256;
+#ifdef SXFIR_PROFILING
+        if (p->sgpr_r && p->ntaps == 128) g.tile_out = 64 * p->sgpr_r;
+#endif
+        g.n_tiles = (n_out + g.tile_out - 1) / g.tile_out;
+        g.resident = (long long)p->compute_units * (p->tile_dbuf ? p->occ_db : p->occ_sb);
+        g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles);
+    }
+    return g;
+}
+
+static LaunchGeom interp_geom(const sxfir_plan *p, long long n_in, bool aligned)
+{
+    const long long n_out = n_in * p->ratio;
+    LaunchGeom g{GEOM_GENERIC, "interp_generic_kernel", 256, (n_out + 255) / 256, (n_out + 255) / 256,
+                 (long long)p->compute_units * 8, 1};
+    if (!(p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && aligned)) return g;
+    if (p->ipass) {
+        g.kind = GEOM_IPASS;
+        g.kernel = "interp8_pass_kernel";
+        g.tile_out = 64 * p->ipass_qi;
+        g.n_tiles = (n_in + g.tile_out - 1) / g.tile_out;
+        g.resident = (long long)p->compute_units * p->occ_ipass;
+        // x32, x48, x96: while a call has at most twice as many tiles as the chip holds waves, (tile, phase block) items are dealt
+        // (interp8_pass_kernel<..., PBSPLIT>: an interpolator's phases never meet, so nothing is joined)
+        if (p->ratio > 16 && p->ipass_split && g.n_tiles * p->nchan <= 2 * g.resident) g.split = p->ratio / 16;
+        g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles * g.split);
+        return g;
+    }
+    g.kind = GEOM_ITILE;
+    g.kernel = "interp_tile_kernel";
+    return g;        // (tile size and phase blocks: launch_interp, which alone knows the profiling knobs)
+}
+
 // Launch only the resampling kernel (no history update, no position change).
 static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t in_stride, void *out_dev,
                         size_t out_stride, long long n_out, hipStream_t st, bool *history_done)
@@ -43,11 +132,12 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     const long long first = ((p->consumed + D - 1) / D) * D - p->consumed;
     // LDS-DMA sources need no 16-byte alignment (verified on MI355X, tools/probe_unaligned.hip): only the
     // output, written with 16-byte stores, must be aligned
-    bool tiled = p->tile_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
-                 ((uintptr_t)out_dev % 16 == 0) && (p->nchan == 1 || out_stride % 2 == 0);
-    const bool multi = p->multi_capable && p->kernel != SXFIR_KERNEL_GENERIC && first == 0 &&
-                       ((uintptr_t)out_dev % 16 == 0) &&
-                       (p->nchan == 1 || out_stride % (p->fmt == SXFIR_CF16 ? 4 : 2) == 0);
+    const LaunchGeom geom = decim_geom(p, n_out, ((uintptr_t)out_dev % 16 == 0) && (p->nchan == 1 || out_stride % 2 == 0),
+                                       ((uintptr_t)out_dev % 16 == 0) &&
+                                           (p->nchan == 1 || out_stride % (p->fmt == SXFIR_CF16 ? 4 : 2) == 0));
+    (void)first;
+    const bool tiled = geom.kind == GEOM_WIDE || geom.kind == GEOM_TILE;
+    const bool multi = geom.kind == GEOM_MULTI;
     if (multi) {
         sxfir::DecimMultiArgs a;
         a.in = in_dev;
@@ -61,12 +151,9 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.out_stride = (long long)out_stride;
         a.hist_stride = p->hist_len;
         const int W = p->multi_waves;
-        const int tile_out = p->blocks ? 512 : W * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
-        const long long n_tiles = (n_out + tile_out - 1) / tile_out;
+        const long long n_tiles = geom.n_tiles;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
-        long long groups = ((long long)p->compute_units * p->occ_multi * p->oversub) / p->nchan;
-        if (groups < 1) groups = 1;
-        if (groups > n_tiles) groups = n_tiles;
+        const long long groups = geom.groups;
         a.n_tiles = (int)n_tiles;
         a.n_groups = (int)groups;
         dim3 grid((unsigned)groups, (unsigned)p->nchan);
@@ -75,24 +162,31 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             // /48, /96: sixteen-column blocks, scalar taps from the block-major table of the rotated taps
             if (int rc = need_tap_table(p, TAPS_BLOCKS16, "decim_blocks_kernel")) return rc;
             a.taps = p->taps_scaled_dev;
+            const sxfir::DecimBlocksJoin jn{(sxfir::f32x4 *)p->join_partials, p->join_arrived};
             // the lines no other tile reads as non-temporal loads: 2-3 % less time (profiles/round5_rates.txt)
+#define SXFIR_BLOCKS_LAUNCH(NB_, S32_, NT_, HALF_) \
+            do { \
+                if (geom.split > 1) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, true>), grid, dim3(256), 0, st, a, jn); \
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, false>), grid, dim3(256), 0, st, a, jn); \
+            } while (0)
 #ifdef SXFIR_PROFILING
             if (getenv("SXFIR_BLOCKS_NT") && !atoi(getenv("SXFIR_BLOCKS_NT")) && p->fmt == SXFIR_CF32) {     // A/B: plain staging loads
-                if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, false>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, false>), grid, dim3(256), 0, st, a);
+                if (p->blocks == 3) SXFIR_BLOCKS_LAUNCH(3, false, false, false);
+                else SXFIR_BLOCKS_LAUNCH(6, false, false, false);
             } else
 #endif
             if (p->fmt == SXFIR_CF16) {
                 // CF16 storage: the typed LDS-DMA front end
-                if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true, true>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, true, true>), grid, dim3(256), 0, st, a);
+                if (p->blocks == 3) SXFIR_BLOCKS_LAUNCH(3, false, true, true);
+                else SXFIR_BLOCKS_LAUNCH(6, false, true, true);
             } else if (p->blocks == 3) {
-                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, true, true>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true>), grid, dim3(256), 0, st, a);
+                if (p->fmt == SXFIR_S32) SXFIR_BLOCKS_LAUNCH(3, true, true, false);
+                else SXFIR_BLOCKS_LAUNCH(3, false, true, false);
             } else {
-                if (p->fmt == SXFIR_S32) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, true, true>), grid, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, true>), grid, dim3(256), 0, st, a);
+                if (p->fmt == SXFIR_S32) SXFIR_BLOCKS_LAUNCH(6, true, true, false);
+                else SXFIR_BLOCKS_LAUNCH(6, false, true, false);
             }
+#undef SXFIR_BLOCKS_LAUNCH
             HIPCHECK(hipGetLastError());
             *history_done = true;
             return SXFIR_OK;
@@ -185,11 +279,8 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         a.in_stride = (long long)in_stride;
         a.out_stride = (long long)out_stride;
         a.hist_stride = p->hist_len;
-        int tile_out = 256;
-#ifdef SXFIR_PROFILING
-        if (p->sgpr_r && p->ntaps == 128) tile_out = 64 * p->sgpr_r;
-#endif
-        const long long n_tiles = (n_out + tile_out - 1) / tile_out;
+        // (the 4-outputs-per-lane kernels' tiles; the wide kernel's own count follows below)
+        const long long n_tiles = geom.kind == GEOM_TILE ? geom.n_tiles : (n_out + 255) / 256;
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
         a.n_tiles = (int)n_tiles;
         a.sched = p->sched;
@@ -203,10 +294,8 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         if (p->wide8 && p->sched != 1) {
             // 128 symmetric taps: decim4_wide_kernel, tiles of 512 outputs, one wave (= one workgroup) per tile and pass;
             // G = CUs x 8 resident waves x 16 generations waves per launch, strided XCD-blocked passes
-            const long long n_tiles2 = (n_out + 511) / 512;
-            long long G = ((long long)p->compute_units * p->occ_wide * p->oversub) / p->nchan;
-            if (G < 1) G = 1;
-            if (G > n_tiles2) G = n_tiles2;
+            const long long n_tiles2 = geom.n_tiles;
+            const long long G = geom.groups;
             a.n_tiles = (int)n_tiles2;
             a.n_waves = (int)G;
             a.w8 = (G % 8 == 0) ? (int)(G / 8) : 0;
@@ -235,10 +324,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
         }
         // Short-lived waves in generations: W = CUs * resident waves * oversub waves per launch, each covering
         // n_tiles / W tiles in strided, XCD-blocked passes (sxfir_decim_tile.hip.h).
-        const bool dbuf = p->tile_dbuf;
-        long long per_chan = ((long long)p->compute_units * (dbuf ? p->occ_db : p->occ_sb) * p->oversub) / p->nchan;
-        if (per_chan < 1) per_chan = 1;
-        if (per_chan > n_tiles) per_chan = n_tiles;
+        long long per_chan = geom.groups;
         a.n_waves = (int)per_chan;
         {
             const int W = (int)per_chan, last = (int)n_tiles - 1;
@@ -257,7 +343,7 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
 #endif
         dim3 grid((unsigned)per_chan, (unsigned)p->nchan);
 #ifdef SXFIR_PROFILING
-        if (const int pr = prof_launch_tile_first_gen(p, a, grid, per_chan, dbuf, st)) return pr < 0 ? pr : SXFIR_OK;
+        if (const int pr = prof_launch_tile_first_gen(p, a, grid, per_chan, p->tile_dbuf, st)) return pr < 0 ? pr : SXFIR_OK;
 #endif
 #ifdef SXFIR_PROFILING
         // "t2s": round 3's shipped form (with one wave per workgroup both kernels take the same schedule constants)
@@ -352,8 +438,8 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
                          const KeyedRange *key = nullptr, bool *key_pending = nullptr)
 {
     *history_done = false;
-    const bool tiled = p->itile_capable && p->kernel != SXFIR_KERNEL_GENERIC && ((uintptr_t)out_dev % 16 == 0) &&
-                       (p->nchan == 1 || out_stride % 2 == 0);
+    const LaunchGeom geom = interp_geom(p, (long long)n_in, ((uintptr_t)out_dev % 16 == 0) && (p->nchan == 1 || out_stride % 2 == 0));
+    const bool tiled = geom.kind != GEOM_GENERIC;
     if (p->kernel == SXFIR_KERNEL_TILED && !tiled)
         return fail(SXFIR_EUNSUPPORTED, "tiled interpolator needs a 16-byte aligned output and even strides");
     if (tiled && p->ipass) {
@@ -369,12 +455,9 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         t.in_stride = (long long)in_stride;
         t.out_stride = (long long)out_stride;
         t.hist_stride = p->hist_len;
-        const int tile_in = 64 * p->ipass_qi;
-        const long long n_tiles = ((long long)n_in + tile_in - 1) / tile_in;
+        const long long n_tiles = geom.n_tiles * geom.split;        // (PBSPLIT: items)
         if (n_tiles > 0x7fffffffLL) return fail(SXFIR_EINVAL, "call too large");
-        long long groups = ((long long)p->compute_units * p->occ_ipass * p->oversub) / p->nchan;
-        if (groups < 1) groups = 1;
-        if (groups > n_tiles) groups = n_tiles;
+        const long long groups = geom.groups;
         t.n_tiles = (int)n_tiles;
         t.n_groups = (int)groups;
         t.thr2 = p->thr2;
@@ -385,11 +468,14 @@ static int launch_interp(sxfir_plan *p, const void *in_dev, size_t n_in, size_t 
         if (p->ratio >= 16) {
             // x16 .. x96: two inputs per lane, ratio / 16 phase blocks of sixteen per tile
 #define SXFIR_IPASS16(KK, SS) \
-            switch (p->ratio) { \
+            switch (p->ratio + (geom.split > 1 ? 1000 : 0)) { \
             case 16: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 16>), pgrid, dim3(64), 0, st, t); break; \
             case 32: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 32>), pgrid, dim3(64), 0, st, t); break; \
             case 48: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 48>), pgrid, dim3(64), 0, st, t); break; \
             case 96: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 96>), pgrid, dim3(64), 0, st, t); break; \
+            case 1032: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 32, true>), pgrid, dim3(64), 0, st, t); break; \
+            case 1048: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 48, true>), pgrid, dim3(64), 0, st, t); break; \
+            case 1096: hipLaunchKernelGGL((sxfir::interp8_pass_kernel<2, KK, SS, true, 16, 96, true>), pgrid, dim3(64), 0, st, t); break; \
             default: return fail(SXFIR_EUNSUPPORTED, "internal: no pass kernel for x%d", p->ratio); \
             }
             if (p->fmt == SXFIR_S32 && key) { SXFIR_IPASS16(true, true) }
@@ -643,6 +729,35 @@ int sxfir_interpolate_keyed(sxfir_plan *p, const void *in_dev, size_t n_in, size
     if (key_first > n_in || key_count > n_in - key_first) return fail(SXFIR_EINVAL, "keying range outside the block");
     const KeyedRange key{counter, (long long)key_first, (long long)(key_first + key_count)};
     return interpolate_impl(p, in_dev, n_in, in_stride, out_dev, out_stride, n_out_p, stream, key_count ? &key : nullptr);
+}
+
+int sxfir_launch_geometry(const sxfir_plan *p, size_t n_in, sxfir_geometry *out)
+{
+    if (!p || !out) return fail(SXFIR_EINVAL, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    LaunchGeom g;
+    if (p->mode == SXFIR_DECIMATE) {
+        g = decim_geom(p, outputs_for(p, (long long)n_in), true, true);
+    } else {
+        g = interp_geom(p, (long long)n_in, true);
+        if (g.kind == GEOM_ITILE) {
+            // CF16 storage: interp_tile_kernel, x48 / x96 as three phase blocks of its x16 / x32 form (launch_interp)
+            const int base_l = p->ratio == 96 ? 32 : (p->ratio == 48 ? 16 : p->ratio);
+            g.tile_out = 4 * 4 * (32 / (base_l / 4));
+            g.n_tiles = ((long long)n_in + g.tile_out - 1) / g.tile_out;
+            g.resident = (long long)p->compute_units * 16;
+            g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles) * (p->ratio / base_l);
+        }
+    }
+    snprintf(out->kernel, sizeof(out->kernel), "%s", g.kernel);
+    out->tiled = g.kind != GEOM_GENERIC;
+    out->split = g.split;
+    out->tile_samples = g.tile_out * p->ratio;       // wideband samples: a decimator's inputs, an interpolator's outputs
+    if (g.kind == GEOM_GENERIC) out->tile_samples = p->mode == SXFIR_DECIMATE ? 256LL * p->ratio : 256;
+    out->n_tiles = g.n_tiles;
+    out->workgroups = g.groups * p->nchan;
+    out->resident = g.resident;
+    return SXFIR_OK;
 }
 
 }  // extern "C"

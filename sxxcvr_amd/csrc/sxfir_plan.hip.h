@@ -12,6 +12,11 @@ struct sxfir_plan {
     int blocks;            // /48, /96: sixteen-column blocks of decim_blocks_kernel (3, 6), else 0
     int jsplit, cw;        // numeric contract
     int rot;               // ... and its rotation (0; 1 for /48, /96: sxfir_contract_rotation)
+    void *join_partials;   // /48, /96: scratch of decim_blocks_kernel<..., SPLIT>: join_tiles x blocks block values of 4 KiB
+    unsigned *join_arrived;   // ... and one arrival counter per (channel, tile); zero between launches
+    long long join_tiles;  // tiles (over all channels) the scratch holds = the largest call the SPLIT form takes
+    bool blocks_split;     // (profiling: SXFIR_BLOCKS_SPLIT=0 switches the (tile, block) dealing off)
+    bool ipass_split;      // x32, x48, x96: (tile, phase block) items for small calls (profiling: SXFIR_IPASS_SPLIT=0 switches it off)
     bool tile_capable;     // decim4_tile_kernel (ratio 4, 128 or 64 taps, CF32)
     bool multi_capable;    // decim_multi_kernel (ratio 8/16/32, 32 taps per phase, CF32)
     bool itile_capable;    // interp_tile_kernel (ratio 4/8/16/32, 32 taps per phase, CF32)
@@ -158,6 +163,11 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->itile_capable = false;
     p->blocks = 0;
     p->rot = 0;
+    p->join_partials = nullptr;
+    p->join_arrived = nullptr;
+    p->join_tiles = 0;
+    p->blocks_split = true;
+    p->ipass_split = true;
 
     if (mode == SXFIR_DECIMATE) {
         p->hist_len = (ntaps + 1) & ~1;
@@ -296,6 +306,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
     }
     if (const char *v = getenv("SXFIR_IPASS_WAIT0")) p->ipass_wait0 = atoi(v) != 0;
+    if (const char *v = getenv("SXFIR_IPASS_SPLIT")) p->ipass_split = atoi(v) != 0;
     if (const char *v = getenv("SXFIR_DENSE_NT")) { p->dense_nt = atoi(v); p->dense_nt_set = 1; }
     if (const char *v = getenv("SXFIR_DENSE_HC")) p->dense_hc = atoi(v) != 0;
     if (const char *v = getenv("SXFIR_DENSE_SUBSET")) p->dense_subset = p->dense_subset && atoi(v) != 0;     // 0: the VGPR-tap form (A/B)
@@ -353,6 +364,16 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
             return fail(SXFIR_EUNSUPPORTED, "no multi-column kernel for ratio %d with %d waves per workgroup", ratio, W);
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0) p->occ_multi = nb;
+    }
+    if (p->blocks) {
+        // calls of at most twice as many tiles as the chip has workgroup slots are dealt as (tile, block) items (SPLIT)
+        p->join_tiles = 2LL * p->compute_units * p->occ_multi;
+#ifdef SXFIR_PROFILING
+        if (const char *v = getenv("SXFIR_BLOCKS_SPLIT")) {     // 0: off; n >= 1: dealt while a call has at most n x slots tiles
+            p->blocks_split = atoi(v) != 0;
+            if (atoi(v) > 1) p->join_tiles = (long long)atoi(v) * p->compute_units * p->occ_multi;
+        }
+#endif
     }
     if (p->tile_capable) {
         int nb = 0;
@@ -510,6 +531,11 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         }
         e = hipMemcpy(p->taps_scaled_dev, scaled.data(), sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && p->blocks) {
+        e = hipMalloc(&p->join_partials, (size_t)p->join_tiles * (size_t)p->blocks * 4096);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->join_arrived, sizeof(unsigned) * (size_t)p->join_tiles);
+        if (e == hipSuccess) e = hipMemset(p->join_arrived, 0, sizeof(unsigned) * (size_t)p->join_tiles);
+    }
     if (e == hipSuccess) e = hipMalloc(&p->hist_dev, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e == hipSuccess) e = hipMalloc(&p->hist_alt, sample_bytes(fmt) * (size_t)p->hist_len * (size_t)nchan);
     if (e == hipSuccess) e = hipMemcpy(p->taps_dev, taps, sizeof(float) * (size_t)ntaps, hipMemcpyHostToDevice);
@@ -519,6 +545,8 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (p->taps_scaled_dev) (void)hipFree(p->taps_scaled_dev);
         if (p->hist_dev) (void)hipFree(p->hist_dev);
         if (p->hist_alt) (void)hipFree(p->hist_alt);
+        if (p->join_partials) (void)hipFree(p->join_partials);
+        if (p->join_arrived) (void)hipFree(p->join_arrived);
         delete p;
         return fail(SXFIR_EHIP, "plan allocation failed: %s", hipGetErrorString(e));
     }
@@ -533,6 +561,8 @@ int sxfir_destroy(sxfir_plan *p)
     (void)hipFree(p->taps_scaled_dev);
     (void)hipFree(p->hist_dev);
     (void)hipFree(p->hist_alt);
+    if (p->join_partials) (void)hipFree(p->join_partials);
+    if (p->join_arrived) (void)hipFree(p->join_arrived);
     delete p;
     return SXFIR_OK;
 }

@@ -17,11 +17,27 @@ _FMT = {"CF32": CF32, "CF16": CF16, "S32": S32, CF32: CF32, CF16: CF16, S32: S32
 
 
 class Contract(tuple):
-    """(jsplit, cw) with the rotation beside it: unpacks and compares as the pair it always was."""
+    """(jsplit, cw) with the rotation beside it: unpacks and compares as the pair it always was.  Under a rotation
+    (rot != 0: the decimators by 48 and 96) the pair ALONE does not state the summation order -- unpacking it without ever
+    having read .rot warns once (a caller written before ABI 5 would feed (2, 4) to its own check and get other bits)."""
     def __new__(cls, pair, rot=0):
         self = super().__new__(cls, pair)
-        self.rot = rot
+        self._rot = rot
+        self._rot_seen = rot == 0
         return self
+
+    @property
+    def rot(self):
+        self._rot_seen = True
+        return self._rot
+
+    def __iter__(self):
+        if not self._rot_seen:
+            import warnings
+            self._rot_seen = True
+            warnings.warn("this plan's contract (%d, %d) holds under rotation %d (sxfir_contract_rotation): read Contract.rot too"
+                          % (self[0], self[1], self._rot), stacklevel=2)
+        return super().__iter__()
 
 
 def check(rc, lib=None):
@@ -108,6 +124,12 @@ class ClockProbe:
         return mhz.value
 
 
+class Geometry(C.Structure):
+    """sxfir_geometry of include/sxfir.h: what a call would launch."""
+    _fields_ = [("kernel", C.c_char * 64), ("tiled", C.c_int), ("split", C.c_int), ("tile_samples", C.c_longlong),
+                ("n_tiles", C.c_longlong), ("workgroups", C.c_longlong), ("resident", C.c_longlong)]
+
+
 class Resampler:
     """One sxfir plan: `nchan` independent channels of one GPU."""
 
@@ -148,6 +170,14 @@ class Resampler:
         a, b = C.c_int64(), C.c_int64()
         self._ck(self._lib.sxfir_position(self._plan, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def geometry(self, n_in):
+        """What a call with n_in new input samples would launch now (sxfir_launch_geometry): kernel family, whether an
+        LDS-tiled kernel runs it, tiles, work items per tile, workgroups, and the workgroup slots of the chip."""
+        g = Geometry()
+        self._ck(self._lib.sxfir_launch_geometry(self._plan, n_in, C.byref(g)))
+        return {"kernel": g.kernel.decode(), "tiled": bool(g.tiled), "split": g.split, "tile_samples": g.tile_samples,
+                "n_tiles": g.n_tiles, "workgroups": g.workgroups, "resident": g.resident}
 
     def outputs_for(self, n_in):
         n = C.c_size_t()

@@ -381,6 +381,40 @@ static void scenario_rate_registers()
     }
 }
 
+// Where the reference is silent the module is silent (round 6): writeSetting has one key, "PA", three values and no else
+// branch (SoapySX.cpp:1472-1493); readSetting is not overridden, so SoapySDR's default answers "" (:1495); setupStream
+// ignores its one channel's list (:747) and checks lock, format, running, already-set-up in that order (:750-764).
+static void scenario_boundary()
+{
+    sx_device *d = sx_device_make("driver=sx,clock=virtual");
+    expect(d != nullptr, "make");
+    char out[64] = "x";
+    expect(sx_device_write_setting(d, "NO_SUCH_KEY", "1") == 0, "unknown key is ignored");
+    expect(sx_device_write_setting(d, "PA", "SOMETIMES") == 0, "unknown PA value is ignored");
+    expect(sx_device_read_setting(d, "PA", out, sizeof(out)) >= 0 && std::string(out) == "AUTO", "PA mode after construction");
+    expect(sx_device_write_setting(d, "PA", "OFF") == 0 && sx_device_read_setting(d, "PA", out, sizeof(out)) >= 0 &&
+               std::string(out) == "OFF", "PA OFF is remembered");
+    std::strcpy(out, "x");
+    expect(sx_device_read_setting(d, "NO_SUCH_KEY", out, sizeof(out)) >= 0 && out[0] == 0, "unknown key reads as the empty string");
+    const size_t odd[2] = {5, 7};
+    sx_stream *rx = sx_device_setup_stream(d, SX_SOAPY_SDR_RX, "CF32", odd, 2, "");
+    expect(rx != nullptr, "the channel list of the one channel is ignored");
+    expect(sx_device_setup_stream(d, SX_SOAPY_SDR_RX, "CS16", odd, 2, "") == nullptr &&
+               std::strstr(sx_device_last_error(), "Only CF32") != nullptr, "format is checked before already-set-up");
+    expect(sx_device_setup_stream(d, SX_SOAPY_SDR_RX, "CF32", odd, 1, "") == nullptr &&
+               std::strstr(sx_device_last_error(), "setup already") != nullptr, "second setup of a direction");
+    sx_device_close_stream(d, rx);
+    sx_device_unmake(d);
+    sx_device *d4 = sx_device_make("driver=sx,clock=virtual,channels=4");
+    expect(d4 != nullptr, "make channels=4");
+    const size_t one = 0;
+    expect(sx_device_setup_stream(d4, SX_SOAPY_SDR_RX, "CS16", &one, 1, "") == nullptr &&
+               std::strstr(sx_device_last_error(), "Only CF32") != nullptr, "format before the build's own list rule");
+    expect(sx_device_setup_stream(d4, SX_SOAPY_SDR_RX, "CF32", &one, 1, "") == nullptr &&
+               std::strstr(sx_device_last_error(), "all channels") != nullptr, "channels=N: the list names all or none");
+    sx_device_unmake(d4);
+}
+
 // usage: device_probe [calls [blocks [strict|lenient]]]   lenient (the sanitizer builds, which run several times slower
 // than the wall clock allows for): the RX thread may be skipped ahead by the overrun rule; the data checks stay
 int main(int argc, char **argv)
@@ -396,6 +430,7 @@ int main(int argc, char **argv)
         t0 = t1;
     };
     scenario_rate_registers();
+    scenario_boundary();
     scenario_threads("threads", 4096, nblk, false, lenient);
     lap("threads");
     scenario_threads("megabyte", (size_t)1 << 18, 6, true, true);

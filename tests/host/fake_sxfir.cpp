@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -297,6 +298,23 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     p->hist.assign((size_t)nchan * 2 * p->hist_len, 0.0f);
     p->thr2 = 0.0f;
     *out = p;
+    return SXFIR_OK;
+}
+
+int sxfir_launch_geometry(const sxfir_plan *p, size_t n_in, sxfir_geometry *g)
+{
+    // the real library's rule for which shapes have an LDS-tiled kernel (sxfir_plan.hip.h); one tile per 512 outputs
+    std::memset(g, 0, sizeof(*g));
+    const bool table = p->ratio == 4 || p->ratio == 8 || p->ratio == 16 || p->ratio == 32 || p->ratio == 48 || p->ratio == 96;
+    g->tiled = table && p->ntaps == 32 * p->ratio;
+    std::snprintf(g->kernel, sizeof(g->kernel), "%s", g->tiled ? "fake_tiled_kernel"
+                                                                 : (p->mode == SXFIR_DECIMATE ? "decim_generic_kernel" : "interp_generic_kernel"));
+    g->split = 1;
+    g->tile_samples = 512LL * p->ratio;
+    const long long wide = p->mode == SXFIR_DECIMATE ? (long long)n_in : (long long)n_in * p->ratio;
+    g->n_tiles = (wide + g->tile_samples - 1) / g->tile_samples;
+    g->workgroups = g->n_tiles * p->nchan;
+    g->resident = 512;
     return SXFIR_OK;
 }
 

@@ -27,7 +27,7 @@ def test_sxfir_exports_every_declared_symbol():
         assert hasattr(lib, n), "libsxfir.so does not export " + n
     # and the python binding declares a prototype for each of them
     assert set(names) <= set(lib._sx_signatures), set(names) - set(lib._sx_signatures)
-    assert lib.sxfir_abi_version() == 5
+    assert lib.sxfir_abi_version() == 6
 
 
 def test_time_arithmetic_matches_oracle(oracle):
@@ -118,10 +118,16 @@ def test_shipped_code_object():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import shipped_isa
     rows = shipped_isa.kernels()
-    assert len(rows) >= 28
+    assert len(rows) >= 34
     for r in rows:
         assert r["scratch_bytes"] == 0, r["name"]
         assert r["v_mfma"] == 0, r["name"]
+    # an instance holds ONE kind of LDS-DMA: where the typed front end (CF16 storage) writes M0 from inline asm there is no
+    # compiler-managed global_load_lds, whose M0 set-up LLVM could hoist or merge across that asm, and no M0 write besides the
+    # one in front of each typed instruction (structural in the source: `if constexpr (!HALFIN)`)
+    for r in rows:
+        if r["typed_lds_dma"]:
+            assert r["global_load_lds_dwordx4"] == 0 and r["m0_writes"] == r["typed_lds_dma"], r
     w8 = [r for r in rows if r["name"] == "decim4_wide_kernel<0, false, 24, true, false, 0, false, false>"]
     assert len(w8) == 1, [r["name"] for r in rows]
     w8 = w8[0]
@@ -160,17 +166,27 @@ def test_shipped_code_object():
     # FMAs per step, every one with a scalar tap; 70 704 B of LDS (two workgroups per CU), 17 DMA instructions per wave and
     # staging site (two sites), 15 of them non-temporal (the rows no other tile reads); CF32 and wire-word input
     bk = [r for r in rows if r["name"].startswith("decim_blocks_kernel<")]
-    # <NB, S32IN, NTLD, HALFIN>: CF32, wire words, CF16 storage (typed LDS-DMA: four per line instruction of the CF32 form)
-    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s>" % (nb, w, hf) for nb in (3, 6)
-                                                   for w, hf in (("false", "false"), ("true", "false"), ("false", "true"))), bk
+    # <NB, S32IN, NTLD, HALFIN, SPLIT>: CF32, wire words, CF16 storage (typed LDS-DMA: four per line instruction of the CF32 form);
+    # SPLIT (round 6): the instance that deals (tile, block) items, one step per workgroup -- one staging site instead of two, a fifth
+    # barrier around the arrival count, half the registers (no tile loop, no waiting block sums), no SGPR spills
+    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s, %s>" % (nb, w, hf, sp) for nb in (3, 6)
+                                                   for w, hf in (("false", "false"), ("true", "false"), ("false", "true"))
+                                                   for sp in ("false", "true")), bk
     for r in bk:
-        half = r["name"].endswith("true>")
+        t = [x.strip() for x in r["name"].split("<")[1].rstrip(">").split(",")]
+        half, split = t[3] == "true", t[4] == "true"
+        sites = 1 if split else 2
         assert r["lds_bytes"] == 70704 and r["vgpr"] <= 128 and r["v_pk_fma_f32"] == 1024 and r["scalar_tap_fmas"] == 1024, r
         if half:
-            assert r["typed_lds_dma"] == 2 * 4 * 17 and r["global_load_lds_dwordx4"] == 0 and r["v_cvt_f32_f16"] <= 8, r
+            # (the typed front end writes M0 from inline asm; such an instance must hold no compiler-managed
+            # LDS-DMA, whose M0 set-up LLVM may hoist or merge across the asm)
+            # (conversions: the edge tiles' register path only -- a loop of one chunk in the walking form, all 17 chunks unrolled in SPLIT)
+            assert r["typed_lds_dma"] == sites * 4 * 17 and r["global_load_lds_dwordx4"] == 0 and r["v_cvt_f32_f16"] <= (4 * 17 if split else 8), r
         else:
-            assert r["global_load_lds_dwordx4"] == 34 and r["global_load_lds_dwordx4_nt"] == 30 and r["typed_lds_dma"] == 0, r
-        assert r["s_barrier"] == 4 and r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
+            assert r["global_load_lds_dwordx4"] == sites * 17 and r["global_load_lds_dwordx4_nt"] == sites * 15 and r["typed_lds_dma"] == 0, r
+        assert r["s_barrier"] == (5 if split else 4) and r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
+        if split:
+            assert r["vgpr"] <= 96 and r["sgpr_spill_lane_ops"] <= 4, r      # (an edge item keeps its 17 chunks in flight: 68 registers)
     # interp_tile_kernel ships for CF16 storage only (HALF: typed LDS-DMA front end, half stores) at every ratio of the rate table --
     # x48 / x96 as three phase blocks of its x16 / x32 form; CF32 and wire-word output run the scalar-tap pass kernels
     it = [r for r in rows if r["name"].startswith("interp_tile_kernel<")]
@@ -187,11 +203,15 @@ def test_shipped_code_object():
     # passes) and x16 .. x96 (two inputs, eight passes per phase block of sixteen; LT / 16 blocks per tile)
     ip = [r for r in rows if r["name"].startswith("interp8_pass_kernel<")]
     pa = {r["name"]: [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")] for r in ip}
-    assert sorted((int(pa[n][0]), int(pa[n][4]), int(pa[n][5])) for n in pa) == sorted(
-        [(2, 8, 8)] * 4 + [(4, 4, 4)] * 4 + [(2, 16, lt) for lt in (16, 32, 48, 96) for _ in range(4)]), sorted(pa)
+    # ... and, round 6, a seventh argument PBSPLIT: the x32 / x48 / x96 instances that deal (tile, phase block) items for small calls
+    assert sorted((int(pa[n][0]), int(pa[n][4]), int(pa[n][5]), pa[n][6]) for n in pa) == sorted(
+        [(2, 8, 8, "false")] * 4 + [(4, 4, 4, "false")] * 4 + [(2, 16, lt, "false") for lt in (16, 32, 48, 96) for _ in range(4)] +
+        [(2, 16, lt, "true") for lt in (32, 48, 96) for _ in range(4)]), sorted(pa)
     for r in ip:
         t = pa[r["name"]]
         wire, ll, lt = t[2] == "true", int(t[4]), int(t[5])          # the wire-word conversion holds more masks
+        if t[6] == "true":
+            lt = ll                                                  # one block per loop iteration: the x16 kernel's counted wait
         assert t[3] == "true", r                                     # the counted form ships
         assert r["lds_bytes"] == {4: 11264, 8: 10240, 16: 18432}[ll] and r["v_pk_fma_f32"] == (512 if ll == 4 else 256), r
         assert r["vgpr"] <= {4: 168, 8: 128, 16: 256}[ll], r         # x16 blocks: LDS (18 KB per wave) holds the CU at 8 waves anyway
@@ -214,4 +234,28 @@ def test_shipped_code_object():
         assert cw["last_block_vmem"] == ["global_store_dwordx4"] * n, r          # the full-tile path that loops back
         assert cw["non_store_vmem_after_last_dma"] == [], r
     keyed = [r for r in ip if pa[r["name"]][1] == "true"]
-    assert len(keyed) == 12
+    assert len(keyed) == 18
+
+
+def test_reference_built_checker_is_kept_out_of_history_and_out_of_the_product():
+    """oracle/_ref/ (the reference's own converters compiled from /root/reference, `make -C oracle ref`) is git-ignored --
+    nothing built from the reference's text enters the history -- and, as the run's contract for it says, NOT gpurun-ignored:
+    it travels to the GPU box as a prebuilt checker (tests/test_gpu_kernels.py::
+    test_gpu_converters_against_the_reference_compiled_code compares the GPU's converters with it there).  The product never
+    touches it: nothing under sxxcvr_amd/, include/ or examples/ names it, and only tests/ load it."""
+    ign = open(os.path.join(ROOT, ".gitignore")).read().split()
+    assert "oracle/_ref/" in ign
+    gpi = os.path.join(ROOT, ".gpurunignore")
+    gpu_ign = open(gpi).read().split() if os.path.exists(gpi) else []
+    assert not [l for l in gpu_ign if "_ref" in l], gpu_ign
+    import subprocess
+    tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "oracle/_ref"], capture_output=True, text=True)
+    assert tracked.returncode != 0 or tracked.stdout.strip() == "", tracked.stdout
+    hits = []
+    for base in ("sxxcvr_amd", "include", "examples"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip", ".inc", ".c")):
+                    if "libsxref" in open(os.path.join(d, f), errors="replace").read():
+                        hits.append(os.path.join(d, f))
+    assert not hits, hits

@@ -107,6 +107,40 @@ def test_stream_lifecycle_errors():
     assert dev.deactivateStream(rx) == SoapySDR.SOAPY_SDR_STREAM_ERROR        # :843-846
 
 
+def test_outer_boundary_behaves_like_the_reference_where_it_is_silent():
+    """Round 6: three places where the module used to be stricter than SoapySX.cpp, now the reference's behaviour.
+    writeSetting has one key, "PA", with three values, and no else branch (:1472-1493): anything else is ignored.
+    The reference does not override readSetting (":1495 TODO"), so SoapySDR's default answers "" for every key.
+    setupStream ignores the channel list of its one channel (:747) and checks in the order lock, format, running,
+    already set up (:750-764)."""
+    dev = make()
+    dev.writeSetting("NO_SUCH_KEY", "1")                       # ignored, no exception
+    dev.writeSetting("PA", "SOMETIMES")                        # an unknown PA value: ignored, the mode stays
+    assert dev.readSetting("PA") == "AUTO"                     # both GPIO lines high after construction (:685-696) = AUTO
+    for mode in ("ON", "OFF", "AUTO"):
+        dev.writeSetting("PA", mode)
+        assert dev.readSetting("PA") == mode
+    assert dev.readSetting("NO_SUCH_KEY") == ""
+    assert dev.readSetting("") == ""
+    assert int(dev.readSetting("RX_DECIM")) >= 4               # the build's own keys keep working
+    # the list is ignored on a one-channel device: any content sets the stream up
+    rx = dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [5, 7], {})
+    # order of the checks: a wrong format is reported before "already set up", and both before the list is looked at
+    with pytest.raises(RuntimeError, match="Only CF32"):
+        dev.setupStream(SoapySDR.SOAPY_SDR_RX, "CS16", [5, 7], {})
+    with pytest.raises(RuntimeError, match="setup already"):
+        dev.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [9], {})
+    dev.closeStream(rx)
+    dev4 = make(channels="4")
+    with pytest.raises(RuntimeError, match="Only CF32"):       # format before the (build-defined) list rule
+        dev4.setupStream(SoapySDR.SOAPY_SDR_RX, "CS16", [0], {})
+    with pytest.raises(RuntimeError, match="all channels"):
+        dev4.setupStream(SoapySDR.SOAPY_SDR_RX, SoapySDR.SOAPY_SDR_CF32, [0], {})
+    # the commit the module reports is the tree's (sxxcvr_amd/build.py stamps `git rev-parse HEAD`), not a constant
+    commit = dev.getHardwareInfo()["soapysx_commit"]
+    assert commit != "round1" and (commit == "unknown" or len(commit.split("-")[0]) == 40), commit
+
+
 def test_rx_timestamps_and_data(oracle):
     """SoapySX/test/test_timestamps.py: untimed reads of one period; time = position / rate."""
     dev = make()

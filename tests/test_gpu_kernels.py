@@ -94,6 +94,45 @@ def test_s32_wire_converters(oracle, golden_dir):
     assert np.array_equal(to_cpu(out)[: 2 * len(kat["tx_in"])], kat["tx"])
 
 
+def test_gpu_converters_against_the_reference_compiled_code(golden_dir):
+    """The GPU's convert_rx / convert_tx kernels against the REFERENCE'S OWN convert_rx_buffer / convert_tx_buffer
+    (SoapySX.cpp:103-137), not against a restatement: oracle/_ref/libsxref.so is compiled from /root/reference in the build
+    container (`make -C oracle ref`: those lines between three standard headers, no stand-ins) and travels to the GPU box as a
+    prebuilt checker, as the run's contract for oracle/_ref says (git-ignored, not gpurun-ignored).  2^20 fresh wire words and
+    2^20 fresh samples per threshold; rows the C++ leaves undefined (a clamped component of exactly 1.0 converts out of int32's
+    range, :124-125) are excluded by construction (|component| < 1).  Skipped where the library was never built."""
+    import sys
+    import torch
+    sys.path.insert(0, golden_dir)
+    import make_golden
+    if not os.path.exists(make_golden.REF_LIB):
+        pytest.skip("oracle/_ref/libsxref.so was not built (no /root/reference at build time)")
+    ref = make_golden.load_reference_converters()
+    lib = sxxcvr_amd.load_sxfir()
+    vp = C.c_void_p
+    rng = np.random.default_rng(60606)
+    m = 1 << 20
+    s32 = rng.integers(-(2 ** 31), 2 ** 31, size=2 * m, dtype=np.int64).astype(np.int32)
+    want_rx = np.empty(2 * m, dtype=np.float32)
+    ref.sxref_convert_rx_buffer(s32.ctypes.data_as(vp), 0, want_rx.ctypes.data_as(vp), 0, m)
+    src = to_gpu(s32)
+    dst = torch.empty(m, dtype=torch.complex64, device="cuda")
+    sxxcvr_amd._native.check(lib.sxfir_convert_rx_s32(vp(src.data_ptr()), vp(dst.data_ptr()), m, None))
+    _sync()
+    assert np.array_equal(to_cpu(dst).view(np.uint32), want_rx.view(np.uint32)), "convert_rx against the reference's compiled code"
+    for thr in (0.0, 1e-3, 0.3):
+        scale = 0.999 if thr else 2e-3
+        x = (rng.uniform(-scale, scale, size=m) + 1j * rng.uniform(-scale, scale, size=m)).astype(np.complex64)
+        want_tx = np.empty(2 * m, dtype=np.int32)
+        thr2 = np.float32(np.float32(thr) * np.float32(thr))
+        ref.sxref_convert_tx_buffer(x.ctypes.data_as(vp), 0, want_tx.ctypes.data_as(vp), 0, m, thr2)
+        out = torch.empty(2 * m, dtype=torch.int32, device="cuda")
+        sxxcvr_amd._native.check(lib.sxfir_convert_tx_s32(vp(to_gpu(x).data_ptr()), vp(out.data_ptr()), m, float(thr2), None))
+        _sync()
+        assert np.array_equal(to_cpu(out), want_tx), "convert_tx, threshold %g, against the reference's compiled code" % thr
+        assert 0 < int(np.count_nonzero((want_tx[0::2] & 3) == 3)) or thr == 0.3
+
+
 def test_cf16_storage_path(oracle, golden_dir):
     """BASELINE config 5 shape: 1024-tap decimate-by-32, IQ stored as half, fp32 arithmetic.
     Bit-exact against the oracle run on the half-rounded input and rounded to half at the end;
@@ -502,3 +541,33 @@ def test_dense_kernel_edges(oracle, D, nchan, pad):
     for c in range(nchan):
         ref = oracle.decim_f32(h, D, xs[c], 2, 4, rot=plan.contract.rot)
         assert_bit_exact(np.concatenate(got[c]), ref, "dense /%d, channel %d of %d" % (D, c, nchan))
+
+
+@pytest.mark.parametrize("D", [48, 96])
+def test_blocks_kernel_at_the_split_threshold(oracle, D):
+    """decim_blocks_kernel deals (tile, block) items while a call has at most twice as many tiles as the chip has workgroup
+    slots and walks whole tiles beyond (sxfir_launch_geometry says which): the largest call of the first kind and the smallest
+    of the second, streamed one after the other, every output against the oracle -- same contract, same bits on both sides of
+    the switch and across it (the second call's first tile takes its halo from the first call's history)."""
+    import torch
+    from sxxcvr_amd.resampler import KERNEL_TILED
+    h = sxxcvr_amd.design_lowpass(32 * D, D)
+    plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
+    plan.set_kernel(KERNEL_TILED)
+    slots = plan.geometry(D * 512)["resident"]
+    t_split = 2 * slots                                      # tiles of the largest dealt call
+    assert plan.geometry(D * 512 * t_split)["split"] == D // 16 and plan.geometry(D * 512 * t_split + D)["split"] == 1
+    lens = [512 * t_split - 3, 512 * t_split + 1]            # outputs: ragged last tiles on both sides of the switch
+    total = D * sum(lens)
+    x = torch.empty(total, dtype=torch.complex64, device="cuda")
+    sxxcvr_amd.synth_fill(x, 0x51255, 21, 0)
+    outs, pos = [], 0
+    for n in lens:
+        g = plan.geometry(D * n)
+        assert g["split"] == (D // 16 if n <= 512 * t_split else 1), g
+        outs.append(to_cpu(plan.process(x[D * pos:D * (pos + n)])))
+        pos += n
+    got = np.concatenate(outs)
+    ref = oracle.decim_f32(h, D, oracle.synth_iq_mt(0x51255, 21, 0, total, oracle.max_threads()), 2, 4, rot=1,
+                           threads=oracle.max_threads())
+    assert_bit_exact(got, ref, "/%d across the split threshold" % D)

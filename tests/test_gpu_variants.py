@@ -368,3 +368,110 @@ def test_dense_halo_carry_matches_oracle(oracle, monkeypatch, D, oversub):
     y = np.concatenate(outs, axis=1)
     for c in range(nchan):
         assert_bit_exact(y[c], oracle.decim_f32(h, D, x[c], 2, 4), "/%d halo carry, channel %d" % (D, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,fmt,nchan", [(48, "CF32", 1), (96, "CF32", 1), (96, "CF32", 3), (48, "CF16", 2), (96, "S32", 1)])
+def test_blocks_split_and_walking_forms_agree(oracle, monkeypatch, D, fmt, nchan):
+    """decim_blocks_kernel (/48, /96): the form that deals (tile, block) items to workgroups and joins the block values through
+    HBM (SPLIT, round 6: what every call of at most twice as many tiles as the chip has workgroup slots runs) against the form
+    in which one workgroup walks a tile's blocks (SXFIR_BLOCKS_SPLIT=0 in the profiling build).  The join adds the block values
+    in the contract's order whatever the arrival order, so the two must agree bit for bit: a streamed sequence of calls -- one
+    output, one tile, many tiles with a ragged tail, several hundred tiles (several rounds of items), a short one again --
+    per channel; the first calls also against the oracle."""
+    import torch
+    for k in KNOBS + ("SXFIR_BLOCKS_SPLIT",):
+        monkeypatch.delenv(k, raising=False)
+    h = (np.random.default_rng(D + 1).standard_normal(32 * D) / 64.0).astype(np.float32)      # asymmetric taps
+    lens = [4, 512, 512 * 7 + 76, 512 * 700 + 12, 68]          # outputs per call (multiples of four: 16-byte aligned channel rows, CF16 too)
+    total = D * sum(lens)
+    if fmt == "S32":
+        rng = np.random.default_rng(5)
+        words = rng.integers(-2 ** 31, 2 ** 31, size=(nchan, total, 2), dtype=np.int64).astype(np.int32)
+        x_dev = to_gpu(words)
+    elif fmt == "CF16":
+        x32 = np.stack([oracle.synth_iq(0x51255, 90 + c, 0, total) for c in range(nchan)])
+        halves = oracle.f32_to_f16(x32.view(np.float32))
+        x_dev = to_gpu(halves.view(np.int32).reshape(nchan, total))
+    else:
+        x32 = np.stack([oracle.synth_iq(0x51255, 90 + c, 0, total) for c in range(nchan)])
+        x_dev = to_gpu(x32)
+    results = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("SXFIR_BLOCKS_SPLIT", split)
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, D, nchan=nchan, fmt=fmt, profiling=True)
+        plan.set_kernel(KERNEL_TILED)
+        g = plan.geometry(D * 512 * 7)
+        assert g["kernel"] == "decim_blocks_kernel" and g["split"] == (D // 16 if split == "1" else 1), g
+        outs, pos = [], 0
+        for n in lens:
+            blk = x_dev[:, D * pos:D * (pos + n)].contiguous()
+            y = plan.process(blk if nchan > 1 else blk[0])
+            torch.cuda.synchronize()
+            outs.append(to_cpu(y).reshape(nchan, -1) if fmt != "S32" else to_cpu(y).reshape(nchan, -1))
+            pos += n
+        results[split] = np.concatenate(outs, axis=1)
+        plan.close()
+    a, b = results["1"], results["0"]
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+        "/%d %s: %d words differ between the dealt and the walking form" % (D, fmt, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+    if fmt == "CF32":
+        n_chk = sum(lens[:3])
+        for c in range(nchan):
+            ref = oracle.decim_f32(h, D, x32[c][:D * n_chk], 2, 4, rot=1)
+            assert_bit_exact(a[c][:n_chk], ref, "/%d dealt form, channel %d" % (D, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,fmt,nchan", [(32, "CF32", 1), (48, "CF32", 2), (96, "CF32", 1), (96, "S32", 1)])
+def test_pass_kernel_split_and_walking_forms_agree(oracle, monkeypatch, L, fmt, nchan):
+    """interp8_pass_kernel over phase blocks (x32, x48, x96): the form that deals (tile, phase block) items (PBSPLIT, round 6: what
+    every call of at most twice as many tiles as the chip holds waves runs) against the form in which one wave walks a tile's
+    blocks (SXFIR_IPASS_SPLIT=0 in the profiling build): a streamed sequence of calls -- one input, one tile, many tiles with a
+    ragged tail, a few thousand tiles -- with and without the keying count; bit for bit against each other, the first calls
+    against the oracle."""
+    import torch
+    for k in KNOBS + ("SXFIR_IPASS", "SXFIR_IPASS_WAIT0", "SXFIR_IPASS_SPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    h = (np.random.default_rng(L + 2).standard_normal(32 * L) / 8.0).astype(np.float32)
+    lens = [1, 128, 128 * 9 + 77, 128 * 3000 + 5, 40]           # inputs per call
+    total = sum(lens)
+    x = np.stack([oracle.synth_iq(0x51255, 40 + c, 0, total) * np.float32(0.9) for c in range(nchan)])
+    x_dev = to_gpu(x)
+    thr2 = np.float32(0.25)
+    results, counts = {}, {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("SXFIR_IPASS_SPLIT", split)
+        plan = sxxcvr_amd.Resampler(INTERPOLATE, h, L, nchan=nchan, fmt=fmt, profiling=True)
+        plan.set_kernel(KERNEL_TILED)
+        plan.set_tx_threshold(float(thr2))
+        g = plan.geometry(128 * 9)
+        assert g["kernel"] == "interp8_pass_kernel" and g["split"] == (L // 16 if split == "1" else 1), g
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        outs, pos = [], 0
+        for i, n in enumerate(lens):
+            blk = x_dev[:, pos:pos + n].contiguous()
+            y = torch.empty((nchan, n * L), dtype=torch.complex64, device="cuda")
+            if i % 2 == 0:
+                plan.interpolate_keyed_ptr(blk.data_ptr(), n, n, y.data_ptr(), n * L, 0, n, counter.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+            else:
+                plan.process_ptr(blk.data_ptr(), n, n, y.data_ptr(), n * L, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append(to_cpu(y))
+            pos += n
+        results[split] = np.concatenate(outs, axis=1)
+        counts[split] = int(counter.item())
+        plan.close()
+    a, b = results["1"], results["0"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "x%d %s: the dealt and the walking form differ" % (L, fmt)
+    keyed_inputs = np.concatenate([x[0][sum(lens[:i]):sum(lens[:i + 1])] for i in range(len(lens)) if i % 2 == 0])
+    want = int(np.count_nonzero(keyed_inputs.real.astype(np.float32) ** 2 + keyed_inputs.imag.astype(np.float32) ** 2 >= thr2))
+    assert counts["1"] == counts["0"] == want, (counts, want)
+    n_chk = sum(lens[:3])
+    for c in range(nchan):
+        ref = oracle.interp_f32(h, L, x[c][:n_chk], 2)
+        if fmt == "S32":
+            assert np.array_equal(a[c][:n_chk * L].view(np.int32), oracle.convert_tx(ref, thr2)), "x%d to wire words, channel %d" % (L, c)
+        else:
+            assert_bit_exact(a[c][:n_chk * L], ref, "x%d dealt form, channel %d" % (L, c))

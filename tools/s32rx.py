@@ -1,5 +1,8 @@
+"""RX from S32_LE wire words at every ratio of the reference's table (SoapySX.cpp:180-208): kernel time per 2^28 wideband
+samples of the SXFIR_S32 decimator plans (int -> float on load fused, convert_rx_buffer SoapySX.cpp:103-112).
+    python3 tools/s32rx.py        RB_RATIOS=4,8,..  RB_PROF=1"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sxxcvr_amd
 from sxxcvr_amd.resampler import DECIMATE
 for ratio in [int(v) for v in os.environ.get("RB_RATIOS", "4,8,16,32,48,96").split(",")]:

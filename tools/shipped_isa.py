@@ -65,15 +65,18 @@ def kernels(lib=None):
                   "s_load_dwordx16": cnt(r"s_load_dwordx16$"), "instructions": len(ops),
                   "valu": cnt(r"v_"), "sgpr_spill_lane_ops": cnt(r"v_(read|write)lane_b32$"),
                   # CF16 storage: typed LDS-DMA (the texture path converts on the way in) against conversions by the VALU
-                  "typed_lds_dma": len(re.findall(r"buffer_load_format_x [^\n]*\blds\b", body)), "v_cvt_f32_f16": cnt(r"v_cvt_f32_f16")})
+                  "typed_lds_dma": len(re.findall(r"buffer_load_format_x [^\n]*\blds\b", body)), "v_cvt_f32_f16": cnt(r"v_cvt_f32_f16"),
+                  # writes of M0 (the LDS address of an LDS-DMA): one per typed instruction where the front end writes it from
+                  # inline asm -- and then none of the compiler's own (an instance holds one kind of LDS-DMA or the other)
+                  "m0_writes": len(re.findall(r"^\s*s_mov_b32 m0,", body, re.M))})
         fm = re.findall(r"v_pk_fma_f32 v\[\d+:\d+\], (s\[\d+:\d+\]), (v\[\d+:\d+\])", body)
         if len(fm) > 1:
             r["scalar_tap_fmas"] = len(fm)
             r["adjacent_fmas_sharing_sample_pair"] = round(sum(1 for a, b in zip(fm, fm[1:]) if a[1] == b[1]) / (len(fm) - 1), 3)
         # (the compiler emits vmcnt(N > 0) waits of its own elsewhere: those count its own loads; this one is hand-written)
         if "interp8_pass_kernel" in r["name"]:
-            targs = [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")]      # <QI, KEYED, S32OUT, COUNTED, LL, LT>
-            if targs[4] == targs[5]:
+            targs = [t.strip() for t in r["name"].split("<")[1].rstrip(">").split(",")]      # <QI, KEYED, S32OUT, COUNTED, LL, LT, PBSPLIT>
+            if targs[4] == targs[5] or targs[6] == "true":           # one block per loop iteration: the wait at the loop head
                 cw = counted_wait(body)
                 if cw:
                     r["counted_wait"] = cw
