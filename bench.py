@@ -321,6 +321,26 @@ def cpu_baseline(cfg, seconds_target=10.0):
         best_threads, best = 1, conv1
     else:
         best = sweep[best_threads]
+    # ... and the REFERENCE'S OWN convert_rx_buffer, where its compiled form is here (oracle/_ref/libsxref.so: SoapySX.cpp:103-112
+    # compiled in the build container between three standard headers; it travels to the GPU box as a prebuilt checker): one
+    # thread, as the reference's readStream runs it (SoapySX.cpp:961)
+    ref_conv = None
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libsxref.so")
+    if os.path.exists(ref_lib):
+        try:
+            import ctypes as C
+            ref = C.CDLL(ref_lib)
+            ref.sxref_convert_rx_buffer.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
+            ref.sxref_provenance.restype = C.c_char_p
+            ref.sxref_convert_rx_buffer(words.ctypes.data, 0, out.ctypes.data, 0, m)
+            rreps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 0.6:
+                ref.sxref_convert_rx_buffer(words.ctypes.data, 0, out.ctypes.data, 0, m)
+                rreps += 1
+            ref_conv = {"kind": "reference", "one_thread_MS/s": round(m * rreps / (time.perf_counter() - t0) / 1e6, 1),
+                        "what": "the reference's own convert_rx_buffer, compiled from " + ref.sxref_provenance().decode()}
+        except (OSError, AttributeError) as e:
+            ref_conv = {"kind": "reference", "error": str(e)[:120]}
     return {
         "value": round(wide(n) * reps / dt / 1e6, 2),
         "unit": "MS/s (complex wideband-side samples)",
@@ -343,6 +363,7 @@ def cpu_baseline(cfg, seconds_target=10.0):
             "best_MS/s": round(best, 1),
             "best_threads": best_threads,
             "sample": "%d random wire-word samples converted repeatedly" % m,
+            "reference_compiled": ref_conv,
         },
     }
 

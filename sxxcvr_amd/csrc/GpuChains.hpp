@@ -228,6 +228,7 @@ public:
     // slow rates to passes of 2^17 (/96) and 2^18 (/48) stream samples -- 256 and 512 tiles of decim_blocks_kernel, half a
     // round and one round of the chip's workgroup slots per pass, eight and four passes per 2^20-sample read)
     static constexpr size_t kMaxSource = size_t(1) << 27;
+    static constexpr size_t kGrowCap = 1u << 19;       // batches grown for a fast reader of small blocks stop here (4 MiB per copy)
     static constexpr size_t kDirectFrom = 1u << 15;    // reads at least this long are DMA-copied straight into page-locked caller memory
     // A pass whose output is at least this large lands in HBM and crosses PCIe as ONE DMA-engine copy behind the
     // kernel (57 GB/s on the boxes measured); smaller ones are stored across PCIe by the kernel itself, into the
@@ -362,7 +363,9 @@ public:
                 }
                 wait(cur_);
                 // ... and the batch after it goes in flight while the host hands this one out
-                batch_ = std::min(max_batch_, std::max(pick_batch(n), grown_));
+                // (what a reader EARNS by outrunning the read-ahead stops at kGrowCap: a staged batch is one D2H copy the
+                // reader of its first block waits for; only a request that is itself larger gets a larger pass, pick_batch)
+                batch_ = std::min(max_batch_, std::max(pick_batch(n), std::min(grown_, kGrowCap)));
                 launch(cur_ ^ 1, slot_[cur_].pos + (int64_t)slot_[cur_].n, batch_);
                 continue;
             }

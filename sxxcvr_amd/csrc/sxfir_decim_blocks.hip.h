@@ -21,8 +21,8 @@
 //     per 8 rows: 70 704 bytes, two workgroups per CU.  A DMA instruction moves eight whole lines (lane l: row l / 8,
 //     chunk l % 8); 17 per wave and step.  Lane g owns outputs 8 g .. 8 g + 7 of the tile: its window starts 65 slots after
 //     its neighbour's, so the sixteen lanes a ds_read_b128 is served with hit sixteen different slots mod 16.
-//   * The eight subsets of a block go to the four waves in two passes (wave ww: row half p = ww & 1, column groups ww / 2
-//     and ww / 2 + 2); a pass's 64 taps are 32 SGPR pairs loaded with four s_load_dwordx16 from a block-major table of the
+//   * The eight subsets of a block go to the four waves in two passes (round 6: wave ww = column group ww, row half 1 then row
+//     half 0, see RP below; round 5: row half p = ww & 1, column groups ww / 2 and ww / 2 + 2); a pass's 64 taps are 32 SGPR pairs loaded with four s_load_dwordx16 from a block-major table of the
 //     rotated taps (block b at 512 b, subset 2 c + p at 64 (2 c + p), (jj, rr) at 4 jj + rr): every FMA has its tap as the
 //     scalar operand, 46 window reads per 512 packed FMAs.
 //   * The subsets' partials meet through the dead image in the contract's order ((p0 + p1) per column group, adjacent
@@ -43,9 +43,11 @@
 // scratch with device-scope stores and counts itself in; the item that finds NB - 1 others before it reads all NB values back
 // (device-scope loads) and adds them in the contract's order -- (B0 + B1) + B2, ((B0 + B1) + (B2 + B3)) + (B4 + B5): the
 // order is fixed by the block numbers, not by who arrives when, so the bits are those of the walking form.  sxfir_launch
-// chooses SPLIT while a call has at most twice as many tiles as the chip has slots (beyond that the walking form's rounds are
+// chooses SPLIT while a call has at most eight times as many tiles as the chip has slots (beyond that the walking form's rounds are
 // as full, and it keeps a tile's blocks on one XCD).
 #pragma once
+
+#include <type_traits>
 
 #include "sxfir_decim_dense.hip.h"
 
@@ -81,7 +83,14 @@ struct DecimBlocksJoin {
     unsigned *arrived;      // [channel][tile]: items of the tile that have written theirs; the last one resets it to 0
 };
 
-template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false, bool SPLIT = false>
+// RP (round 6; what ships -- RP = false is round 5's form, the A/B partner in the profiling build, SXFIR_BLOCKS_RP=0): the eight subsets
+// of a block dealt to the waves by COLUMN GROUP -- wave c runs (p = 1, c) then (p = 0, c) -- instead of by row half.  The two windows
+// are then the same two chunk columns of rows 8G .. 8G + 22 and 8G + 16 .. 8G + 38: the seven rows they share stay in registers (78
+// window reads per step instead of 92), and P0 + P1 -- the first level of the contract's tree -- is an in-lane add, so four partials
+// cross the exchange instead of eight.  Priced from the measured list (a ds_read_b128 = 1.65-2.2 packed FMAs, a ds_write_b128 0.56:
+// profiles/round4z9_price_list.txt) at 2.8 % of a step's energy; measured on the same box, three alternations, 2^28 samples:
+// /48 486 -> 467-474 us, /96 492 -> 470-473 us (-3.6 %, -4.2 %; -2 % at 2^24; profiles/round6_blocks_rp_ab.txt).
+template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false, bool SPLIT = false, bool RP = false>
 __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs a, const DecimBlocksJoin jn)
 {
     static_assert(NB == 3 || NB == 6, "ratios 48 and 96");
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int ww = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = ww & 1, c0 = ww >> 1;                 // the wave's subsets: (p, c0) and (p, c0 + 2)
+    const int p = RP ? 1 : (ww & 1), c0 = RP ? ww : (ww >> 1);   // the wave's subsets: (p, c0) and (p, c0 + 2); RP: (1, ww) and (0, ww)
     const int G = lane;                                 // output group of the lane
     const int ch = blockIdx.y;
 
@@ -279,27 +288,36 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
 
         // ---- two passes: window sample w meets output i at local tap kl = 4*i + 63 - w
         f32x2 acc[2][8];
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        f32x4 keep[RP ? 14 : 1];                            // RP: rows 16 .. 22 of the first window = rows 0 .. 6 of the second
+        // (the two passes as two instantiations of a generic lambda, not a loop of two: with every inner loop unrolled the body
+        // is beyond clang's full-unroll budget even under #pragma unroll, and a rolled loop turns `ps` into a run-time value)
+        auto one_pass = [&](auto ps_c) __attribute__((always_inline)) {
+            constexpr int ps = decltype(ps_c)::value;
             f32x2 hs[32];
+            const int sub = RP ? 2 * c0 + (1 - ps) : 2 * (c0 + 2 * ps) + p;      // the pass's subset 2c + p
+            constexpr int TAP0_PASS = RP ? 0 : 1;           // the pass that runs (p = 1, c = 3) on wave 3
 #pragma unroll
-            for (int m = 0; m < 32; ++m) hs[m] = tq[256 * blk + 32 * (2 * (c0 + 2 * ps) + p) + m];
+            for (int m = 0; m < 32; ++m) hs[m] = tq[256 * blk + 32 * sub + m];
             // slot NT - 1 = (last block, p = 1, c = 3, jj = 15, rr = 3) holds tap 0, whose sample is x[m D]: the same chunk of
             // the image 32 rows further on (the first FMA of the chain; wave-uniform)
-            const bool tap0 = ps == 1 && blk == NB - 1 && ww == 3;
+            const bool tap0 = ps == TAP0_PASS && blk == NB - 1 && ww == 3;
             f32x2 xs[8];
             if (tap0) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const f32x4 v = (win0 - 4)[C::CPR * i + C::TAP0_SLOTS];
+                    const f32x4 v = (RP ? win0 : win0 - 4)[C::CPR * i + C::TAP0_SLOTS];
                     xs[i] = __builtin_shufflevector(v, v, 0, 1);
                     if constexpr (S32IN) xs[i] = (f32x2){(float)__float_as_int(xs[i].x), (float)__float_as_int(xs[i].y)};
                 }
             }
 #pragma unroll
             for (int t = 0; t < C::WCH; ++t) {
-                const f32x4 *wp = (t < 16 ? win0 : (t < 32 ? win1 : win2)) - 4 * ps;
-                const f32x4 v = wp[C::CPR * (t >> 1) + (t & 1)];
+                // (RP: the second window starts 16 rows = 128 chunks + 2 pads further on)
+                const f32x4 *wp = (t < 16 ? win0 : (t < 32 ? win1 : win2)) + (RP ? 130 * ps : -4 * ps);
+                f32x4 v;
+                if (RP && ps == 1 && t < 14) v = keep[t];
+                else v = wp[C::CPR * (t >> 1) + (t & 1)];
+                if (RP && ps == 0 && t >= 32) keep[t - 32] = v;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int w = 2 * t + s;
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
                         const int kl = 4 * i + 63 - w;
                         if (kl >= 0 && kl < 64) {
                             if (kl == 63) {
-                                if (ps == 1) {
+                                if (ps == TAP0_PASS) {
                                     const f32x2 xf = tap0 ? xs[i] : x;
                                     pk_fma_s_hi_first(acc[ps][i], hs[31], xf);
                                 } else {
@@ -322,22 +340,35 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
                     }
                 }
             }
-        }
+        };
+        one_pass(std::integral_constant<int, 0>{});
+        one_pass(std::integral_constant<int, 1>{});
         __syncthreads();                                    // everyone is done reading this step's image
         // the eight subsets' partials meet in the dead image: subset s = 2c + p at 256 s; chunk k (two outputs) of group G at slot
         // 4G + (k ^ ((G >> 1) & 3)): the eight lanes a ds_write_b128 is served with hit eight different slots mod 16
+        if constexpr (RP) {
+            // (p0 + p1) of the wave's column group in the lane, then the four column groups' values: column group c at 256 c
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 p0 = (f32x4){acc[1][2 * k].x, acc[1][2 * k].y, acc[1][2 * k + 1].x, acc[1][2 * k + 1].y};
+                const f32x4 p1 = (f32x4){acc[0][2 * k].x, acc[0][2 * k].y, acc[0][2 * k + 1].x, acc[0][2 * k + 1].y};
+                lds[256 * c0 + 4 * G + (k ^ ((G >> 1) & 3))] = add4(p0, p1);
+            }
+        } else {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 lds[256 * (2 * (c0 + 2 * ps) + p) + 4 * G + (k ^ ((G >> 1) & 3))] =
                     (f32x4){acc[ps][2 * k].x, acc[ps][2 * k].y, acc[ps][2 * k + 1].x, acc[ps][2 * k + 1].y};
+        }
         __syncthreads();
         f32x4 y;
         {
             f32x4 col[4];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) col[cc] = add4(lds[256 * (2 * cc) + 64 * ww + lane], lds[256 * (2 * cc + 1) + 64 * ww + lane]);
+            for (int cc = 0; cc < 4; ++cc)
+                col[cc] = RP ? lds[256 * cc + 64 * ww + lane] : add4(lds[256 * (2 * cc) + 64 * ww + lane], lds[256 * (2 * cc + 1) + 64 * ww + lane]);
             y = add4(add4(col[0], col[1]), add4(col[2], col[3]));
         }
         if constexpr (SPLIT) {

@@ -119,7 +119,7 @@ __device__ __forceinline__ void interp_pass_steps(std::integer_sequence<int, Ts.
 // at x96 is 342 tiles for 2048 wave slots.  An interpolator's phases never meet, so the PBSPLIT instance deals (tile, phase block) ITEMS:
 // the launch passes n_tiles = tiles x LT / 16 items, item v is block v % NPB of tile v / NPB (a tile's blocks next to each other in the
 // schedule: its 1 KiB of input is fetched from HBM once), one block per loop iteration -- the x16 kernel's loop with a block's tap table
-// and output stride.  No join, same bits.  sxfir_launch chooses it while a call has at most twice as many tiles as the chip holds waves.
+// and output stride.  No join, same bits.  sxfir_launch chooses it while a call has at most four times as many tiles as the chip holds waves.
 template <int QI, bool KEYED = false, bool S32OUT = false, bool COUNTED = true, int LL = 8, int LT = LL, bool PBSPLIT = false>
 __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a)
 {

@@ -48,6 +48,22 @@ struct LaunchGeom {
 };
 enum { GEOM_GENERIC = 0, GEOM_MULTI = 1, GEOM_WIDE = 2, GEOM_TILE = 3, GEOM_IPASS = 4, GEOM_ITILE = 5 };
 
+// Generations of workgroups per launch.  The plan's figure (8) was measured at 2^28 samples; the calls the API issues are 2^17 ..
+// 2^25, and there the kernels whose workgroups pay a heavy prologue per launch (64 taps into VGPRs: decim_dense_kernel<16 / 32>;
+// the x16 .. x96 pass kernels' window and lane constants) run 2-3 % faster when a workgroup keeps at least four tiles
+// (tools/split_ab.sh: /32 at 2^25 66.7 us with 2 generations, 69.0 with 8; at 2^28 the other way round, 514 against 508): as many
+// generations as leave every workgroup four tiles, at least one, at most the plan's.
+static long long generations(const sxfir_plan *p, long long n_tiles, long long resident, bool heavy_prologue)
+{
+    if (!heavy_prologue) return p->oversub;
+#ifdef SXFIR_PROFILING
+    if (getenv("SXFIR_OVERSUB")) return p->oversub;              // the knob means what it says
+#endif
+    long long g = n_tiles * p->nchan / (4 * resident);
+    if (g < 1) g = 1;
+    return g > p->oversub ? p->oversub : g;
+}
+
 static long long clamp_groups(long long g, long long n_tiles)
 {
     if (g < 1) g = 1;
@@ -68,8 +84,8 @@ static LaunchGeom decim_geom(const sxfir_plan *p, long long n_out, bool aligned,
         g.tile_out = p->blocks ? 512 : p->multi_waves * 8 * (64 / (p->multi_ps * (p->ratio / 4)));
         g.n_tiles = (n_out + g.tile_out - 1) / g.tile_out;
         g.resident = (long long)p->compute_units * p->occ_multi;
-        g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles);
-        // /48, /96: while a call has at most twice as many tiles as the chip has workgroup slots, (tile, block) items are dealt,
+        g.groups = clamp_groups(g.resident * generations(p, g.n_tiles, g.resident, p->dense32 && !p->dense_subset) / p->nchan, g.n_tiles);
+        // /48, /96: while a call has at most eight times as many tiles as the chip has workgroup slots, (tile, block) items are dealt,
         // one workgroup each (decim_blocks_kernel<..., SPLIT>); the plan's scratch holds that many block values
         if (p->blocks && p->join_partials && p->blocks_split && g.n_tiles * p->nchan <= p->join_tiles) {
             g.split = p->blocks;
@@ -112,10 +128,10 @@ static LaunchGeom interp_geom(const sxfir_plan *p, long long n_in, bool aligned)
         g.tile_out = 64 * p->ipass_qi;
         g.n_tiles = (n_in + g.tile_out - 1) / g.tile_out;
         g.resident = (long long)p->compute_units * p->occ_ipass;
-        // x32, x48, x96: while a call has at most twice as many tiles as the chip holds waves, (tile, phase block) items are dealt
-        // (interp8_pass_kernel<..., PBSPLIT>: an interpolator's phases never meet, so nothing is joined)
-        if (p->ratio > 16 && p->ipass_split && g.n_tiles * p->nchan <= 2 * g.resident) g.split = p->ratio / 16;
-        g.groups = clamp_groups(g.resident * p->oversub / p->nchan, g.n_tiles * g.split);
+        // x32, x48, x96: while a call has at most four times as many tiles as the chip holds waves, (tile, phase block) items are
+        // dealt (interp8_pass_kernel<..., PBSPLIT>: an interpolator's phases never meet, so nothing is joined)
+        if (p->ratio > 16 && p->ipass_split && g.n_tiles * p->nchan <= 4 * g.resident) g.split = p->ratio / 16;
+        g.groups = clamp_groups(g.resident * generations(p, g.n_tiles * g.split, g.resident, p->ratio >= 16) / p->nchan, g.n_tiles * g.split);
         return g;
     }
     g.kind = GEOM_ITILE;
@@ -166,10 +182,19 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
             // the lines no other tile reads as non-temporal loads: 2-3 % less time (profiles/round5_rates.txt)
 #define SXFIR_BLOCKS_LAUNCH(NB_, S32_, NT_, HALF_) \
             do { \
-                if (geom.split > 1) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, true>), grid, dim3(256), 0, st, a, jn); \
-                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, false>), grid, dim3(256), 0, st, a, jn); \
+                if (geom.split > 1) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, true, true>), grid, dim3(256), 0, st, a, jn); \
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, false, true>), grid, dim3(256), 0, st, a, jn); \
             } while (0)
 #ifdef SXFIR_PROFILING
+            if (getenv("SXFIR_BLOCKS_RP") && !atoi(getenv("SXFIR_BLOCKS_RP")) && p->fmt == SXFIR_CF32) {     // A/B: round 5's form, waves by row half
+                if (geom.split > 1) {
+                    if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true, false, true, false>), grid, dim3(256), 0, st, a, jn);
+                    else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, true, false, true, false>), grid, dim3(256), 0, st, a, jn);
+                } else {
+                    if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true, false, false, false>), grid, dim3(256), 0, st, a, jn);
+                    else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<6, false, true, false, false, false>), grid, dim3(256), 0, st, a, jn);
+                }
+            } else
             if (getenv("SXFIR_BLOCKS_NT") && !atoi(getenv("SXFIR_BLOCKS_NT")) && p->fmt == SXFIR_CF32) {     // A/B: plain staging loads
                 if (p->blocks == 3) SXFIR_BLOCKS_LAUNCH(3, false, false, false);
                 else SXFIR_BLOCKS_LAUNCH(6, false, false, false);

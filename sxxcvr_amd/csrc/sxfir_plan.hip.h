@@ -332,10 +332,10 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const void *k = nullptr;
         if (p->blocks) {
             const bool w = fmt == SXFIR_S32;
-            k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true, true> : (const void *)sxfir::decim_blocks_kernel<3, false, true>)
-                               : (w ? (const void *)sxfir::decim_blocks_kernel<6, true, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true>);
+            k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true, true, false, false, true> : (const void *)sxfir::decim_blocks_kernel<3, false, true, false, false, true>)
+                               : (w ? (const void *)sxfir::decim_blocks_kernel<6, true, true, false, false, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true, false, false, true>);
             if (fmt == SXFIR_CF16)
-                k = p->blocks == 3 ? (const void *)sxfir::decim_blocks_kernel<3, false, true, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true, true>;
+                k = p->blocks == 3 ? (const void *)sxfir::decim_blocks_kernel<3, false, true, true, false, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true, true, false, true>;
         } else if (p->dense32 && fmt == SXFIR_CF16) {
             k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>
                 : ratio == 16 ? (const void *)sxfir::decim_dense_kernel<16, 0, false, 2, false, false, true>
@@ -366,8 +366,12 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * W, 0) == hipSuccess && nb > 0) p->occ_multi = nb;
     }
     if (p->blocks) {
-        // calls of at most twice as many tiles as the chip has workgroup slots are dealt as (tile, block) items (SPLIT)
-        p->join_tiles = 2LL * p->compute_units * p->occ_multi;
+        // calls of at most eight times as many tiles as the chip has workgroup slots are dealt as (tile, block) items (SPLIT).
+        // Measured (tools/split_ab.sh, profiles/round6_split_ab.txt): against the walking form the dealt form takes 2.9 x less time at
+        // 2^22 samples (/96), -39 % at 2^24, -15 % at 2^26 (2731 / 1366 tiles), -6 % at 5.3 x slots and +2 .. +5 % at 10.7 x slots
+        // (2^28 samples at /96: the walking form keeps a tile's halo in one XCD's L2 and pays one prologue per eight tiles).
+        // Scratch: 4096 tiles x blocks x 4 KiB = 48 / 96 MiB per plan.
+        p->join_tiles = 8LL * p->compute_units * p->occ_multi;
 #ifdef SXFIR_PROFILING
         if (const char *v = getenv("SXFIR_BLOCKS_SPLIT")) {     // 0: off; n >= 1: dealt while a call has at most n x slots tiles
             p->blocks_split = atoi(v) != 0;

@@ -169,7 +169,9 @@ def test_shipped_code_object():
     # <NB, S32IN, NTLD, HALFIN, SPLIT>: CF32, wire words, CF16 storage (typed LDS-DMA: four per line instruction of the CF32 form);
     # SPLIT (round 6): the instance that deals (tile, block) items, one step per workgroup -- one staging site instead of two, a fifth
     # barrier around the arrival count, half the registers (no tile loop, no waiting block sums), no SGPR spills
-    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s, %s>" % (nb, w, hf, sp) for nb in (3, 6)
+    # (a sixth argument, RP, round 6: waves by column group, the rows the two windows share kept in registers -- 86 window reads + 4
+    # exchange reads where round 5's form, RP = false, had 92 + 8; that form is the profiling build's A/B partner)
+    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s, %s, true>" % (nb, w, hf, sp) for nb in (3, 6)
                                                    for w, hf in (("false", "false"), ("true", "false"), ("false", "true"))
                                                    for sp in ("false", "true")), bk
     for r in bk:
@@ -184,7 +186,7 @@ def test_shipped_code_object():
             assert r["typed_lds_dma"] == sites * 4 * 17 and r["global_load_lds_dwordx4"] == 0 and r["v_cvt_f32_f16"] <= (4 * 17 if split else 8), r
         else:
             assert r["global_load_lds_dwordx4"] == sites * 17 and r["global_load_lds_dwordx4_nt"] == sites * 15 and r["typed_lds_dma"] == 0, r
-        assert r["s_barrier"] == (5 if split else 4) and r["sgpr_spill_lane_ops"] <= 48 and 92 <= r["ds_read_b128"] <= 104, r
+        assert r["s_barrier"] == (5 if split else 4) and r["sgpr_spill_lane_ops"] <= 96 and 78 <= r["ds_read_b128"] <= 92, r
         if split:
             assert r["vgpr"] <= 96 and r["sgpr_spill_lane_ops"] <= 4, r      # (an edge item keeps its 17 chunks in flight: 68 registers)
     # interp_tile_kernel ships for CF16 storage only (HALF: typed LDS-DMA front end, half stores) at every ratio of the rate table --

@@ -545,18 +545,25 @@ def test_dense_kernel_edges(oracle, D, nchan, pad):
 
 @pytest.mark.parametrize("D", [48, 96])
 def test_blocks_kernel_at_the_split_threshold(oracle, D):
-    """decim_blocks_kernel deals (tile, block) items while a call has at most twice as many tiles as the chip has workgroup
-    slots and walks whole tiles beyond (sxfir_launch_geometry says which): the largest call of the first kind and the smallest
-    of the second, streamed one after the other, every output against the oracle -- same contract, same bits on both sides of
-    the switch and across it (the second call's first tile takes its halo from the first call's history)."""
+    """decim_blocks_kernel deals (tile, block) items while a call has at most eight times as many tiles as the chip has
+    workgroup slots and walks whole tiles beyond (sxfir_launch_geometry says which): the largest call of the first kind and the
+    smallest of the second, streamed one after the other (1.6 / 3.2 GB of synthetic IQ, filled on the GPU) -- same contract,
+    same bits on both sides of the switch and across it (the second call's first tile takes its halo from the first call's
+    history).  Checked against the oracle in windows: the head of the first call, the seam, the tail of the second, and eight
+    windows inside each call (a window's input is regenerated on the host from the counter-based source)."""
     import torch
     from sxxcvr_amd.resampler import KERNEL_TILED
     h = sxxcvr_amd.design_lowpass(32 * D, D)
+    NT = 32 * D
     plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
     plan.set_kernel(KERNEL_TILED)
     slots = plan.geometry(D * 512)["resident"]
-    t_split = 2 * slots                                      # tiles of the largest dealt call
-    assert plan.geometry(D * 512 * t_split)["split"] == D // 16 and plan.geometry(D * 512 * t_split + D)["split"] == 1
+    lo, hi = 1, 64 * slots                                   # the largest tile count that is still dealt: bisection on the geometry
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        lo, hi = (mid, hi) if plan.geometry(D * 512 * mid)["split"] > 1 else (lo, mid - 1)
+    t_split = lo
+    assert t_split >= 2 * slots and plan.geometry(D * 512 * t_split)["split"] == D // 16 and plan.geometry(D * 512 * t_split + D)["split"] == 1
     lens = [512 * t_split - 3, 512 * t_split + 1]            # outputs: ragged last tiles on both sides of the switch
     total = D * sum(lens)
     x = torch.empty(total, dtype=torch.complex64, device="cuda")
@@ -565,9 +572,17 @@ def test_blocks_kernel_at_the_split_threshold(oracle, D):
     for n in lens:
         g = plan.geometry(D * n)
         assert g["split"] == (D // 16 if n <= 512 * t_split else 1), g
-        outs.append(to_cpu(plan.process(x[D * pos:D * (pos + n)])))
+        outs.append(plan.process(x[D * pos:D * (pos + n)]))
         pos += n
-    got = np.concatenate(outs)
-    ref = oracle.decim_f32(h, D, oracle.synth_iq_mt(0x51255, 21, 0, total, oracle.max_threads()), 2, 4, rot=1,
-                           threads=oracle.max_threads())
-    assert_bit_exact(got, ref, "/%d across the split threshold" % D)
+    torch.cuda.synchronize()
+    got = torch.cat(outs)
+    rng = np.random.default_rng(D)
+    W = 3000
+    starts = [0, lens[0] - W // 2, sum(lens) - W]
+    starts += [int(v) for v in rng.integers(W, lens[0] - 2 * W, 8)] + [int(v) for v in rng.integers(lens[0] + W, sum(lens) - 2 * W, 8)]
+    for m0 in starts:
+        warm = 0 if m0 == 0 else 32                          # outputs of the slice that still see its zero history
+        s0 = (m0 - warm) * D
+        xs = oracle.synth_iq(0x51255, 21, s0, (W + warm) * D)
+        ref = oracle.decim_f32(h, D, xs, 2, 4, rot=1, threads=oracle.max_threads())[warm:]
+        assert_bit_exact(to_cpu(got[m0:m0 + W]), ref, "/%d, outputs from %d (split threshold %d tiles)" % (D, m0, t_split))

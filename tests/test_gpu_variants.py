@@ -374,7 +374,7 @@ def test_dense_halo_carry_matches_oracle(oracle, monkeypatch, D, oversub):
 @pytest.mark.parametrize("D,fmt,nchan", [(48, "CF32", 1), (96, "CF32", 1), (96, "CF32", 3), (48, "CF16", 2), (96, "S32", 1)])
 def test_blocks_split_and_walking_forms_agree(oracle, monkeypatch, D, fmt, nchan):
     """decim_blocks_kernel (/48, /96): the form that deals (tile, block) items to workgroups and joins the block values through
-    HBM (SPLIT, round 6: what every call of at most twice as many tiles as the chip has workgroup slots runs) against the form
+    HBM (SPLIT, round 6: what every call of at most eight times as many tiles as the chip has workgroup slots runs) against the form
     in which one workgroup walks a tile's blocks (SXFIR_BLOCKS_SPLIT=0 in the profiling build).  The join adds the block values
     in the contract's order whatever the arrival order, so the two must agree bit for bit: a streamed sequence of calls -- one
     output, one tile, many tiles with a ragged tail, several hundred tiles (several rounds of items), a short one again --
@@ -426,7 +426,7 @@ def test_blocks_split_and_walking_forms_agree(oracle, monkeypatch, D, fmt, nchan
 @pytest.mark.parametrize("L,fmt,nchan", [(32, "CF32", 1), (48, "CF32", 2), (96, "CF32", 1), (96, "S32", 1)])
 def test_pass_kernel_split_and_walking_forms_agree(oracle, monkeypatch, L, fmt, nchan):
     """interp8_pass_kernel over phase blocks (x32, x48, x96): the form that deals (tile, phase block) items (PBSPLIT, round 6: what
-    every call of at most twice as many tiles as the chip holds waves runs) against the form in which one wave walks a tile's
+    every call of at most four times as many tiles as the chip holds waves runs) against the form in which one wave walks a tile's
     blocks (SXFIR_IPASS_SPLIT=0 in the profiling build): a streamed sequence of calls -- one input, one tile, many tiles with a
     ragged tail, a few thousand tiles -- with and without the keying count; bit for bit against each other, the first calls
     against the oracle."""
@@ -475,3 +475,34 @@ def test_pass_kernel_split_and_walking_forms_agree(oracle, monkeypatch, L, fmt, 
             assert np.array_equal(a[c][:n_chk * L].view(np.int32), oracle.convert_tx(ref, thr2)), "x%d to wire words, channel %d" % (L, c)
         else:
             assert_bit_exact(a[c][:n_chk * L], ref, "x%d dealt form, channel %d" % (L, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,split", [(48, "1"), (96, "1"), (96, "0")])
+def test_blocks_kernel_waves_by_column_group_agree(oracle, monkeypatch, D, split):
+    """decim_blocks_kernel<..., RP> (what ships since round 6: the block's subsets dealt to the waves by column group, the rows the
+    two windows share kept in registers, P0 + P1 added in the lane) against round 5's form (SXFIR_BLOCKS_RP=0, profiling build: waves
+    by row half) and the oracle: same contract, same bits; the dealt (SPLIT) and the walking instance."""
+    import torch
+    for k in KNOBS + ("SXFIR_BLOCKS_SPLIT", "SXFIR_BLOCKS_RP"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SXFIR_BLOCKS_SPLIT", split)
+    h = (np.random.default_rng(D + 7).standard_normal(32 * D) / 64.0).astype(np.float32)
+    lens = [2, 512, 512 * 9 + 76, 512 * 300 + 12]
+    x = oracle.synth_iq(0x51255, 33, 0, D * sum(lens))
+    x_dev = to_gpu(x)
+    res = {}
+    for rp in ("0", "1"):
+        monkeypatch.setenv("SXFIR_BLOCKS_RP", rp)
+        plan = sxxcvr_amd.Resampler(DECIMATE, h, D, profiling=True)
+        plan.set_kernel(KERNEL_TILED)
+        outs, pos = [], 0
+        for n in lens:
+            outs.append(to_cpu(plan.process(x_dev[D * pos:D * (pos + n)])))
+            pos += n
+        torch.cuda.synchronize()
+        res[rp] = np.concatenate(outs)
+        plan.close()
+    assert np.array_equal(res["0"].view(np.uint32), res["1"].view(np.uint32)), "/%d: waves by column group differ from the shipped form" % D
+    n_chk = sum(lens[:3])
+    assert_bit_exact(res["1"][:n_chk], oracle.decim_f32(h, D, x[:D * n_chk], 2, 4, rot=1), "/%d waves by column group" % D)
