@@ -90,10 +90,13 @@ struct DecimBlocksJoin {
 // cross the exchange instead of eight.  Priced from the measured list (a ds_read_b128 = 1.65-2.2 packed FMAs, a ds_write_b128 0.56:
 // profiles/round4z9_price_list.txt) at 2.8 % of a step's energy; measured on the same box, three alternations, 2^28 samples:
 // /48 486 -> 467-474 us, /96 492 -> 470-473 us (-3.6 %, -4.2 %; -2 % at 2^24; profiles/round6_blocks_rp_ab.txt).
-template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false, bool SPLIT = false, bool RP = false>
+// ROT = false (profiling experiment, /16 and /32 only: rows that are contiguous in HBM): the UNROTATED contract -- the image starts one
+// sample later (a block's piece is then a 128-byte stretch that starts 8 bytes into a line), slot k holds tap k, no special tap 0.
+template <int NB, bool S32IN = false, bool NTLD = false, bool HALFIN = false, bool SPLIT = false, bool RP = false, bool ROT = true>
 __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs a, const DecimBlocksJoin jn)
 {
-    static_assert(NB == 3 || NB == 6, "ratios 48 and 96");
+    static_assert(ROT || ((NB == 1 || NB == 2) && !HALFIN), "unrotated: contiguous rows only");
+    static_assert(NB == 3 || NB == 6 || ((NB == 1 || NB == 2) && !SPLIT), "ratios 48 and 96 (profiling experiment: 16 and 32, walking form)");
     static_assert(!(HALFIN && S32IN), "one storage format");
     using C = DecimBlocks16;
     constexpr int D = 16 * NB;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     const unsigned lds_wave_base = HALFIN ? __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds + 65 * ww)) : 0u;
     auto stage = [&](int tile, int blk) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
-        const long long s_first = D * (M0 - 31) - 16 * (blk + 1);         // first sample of the block image
+        const long long s_first = D * (M0 - 31) - 16 * (blk + 1) + (ROT ? 0 : 1);   // first sample of the block image
         const bool interior = tile >= 1 && tile <= tile_hi;
         if constexpr (HALFIN) {
             if (interior) {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
             for (int m = 0; m < 32; ++m) hs[m] = tq[256 * blk + 32 * sub + m];
             // slot NT - 1 = (last block, p = 1, c = 3, jj = 15, rr = 3) holds tap 0, whose sample is x[m D]: the same chunk of
             // the image 32 rows further on (the first FMA of the chain; wave-uniform)
-            const bool tap0 = ps == TAP0_PASS && blk == NB - 1 && ww == 3;
+            const bool tap0 = ROT && ps == TAP0_PASS && blk == NB - 1 && ww == 3;
             f32x2 xs[8];
             if (tap0) {
 #pragma unroll
@@ -392,8 +395,8 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
             if (tid == 0) reinterpret_cast<unsigned *>(lds)[0] = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (reinterpret_cast<const unsigned *>(lds)[0] != (unsigned)(NB - 1)) return;
-            f32x4 bv[NB];
-            {
+            f32x4 bv[NB < 3 ? 3 : NB];
+            if constexpr (NB >= 3) {
                 const f32x4 *q = jn.partials + slot * 256 + tid + 256;  // block b at q + 256 (b - 1): 4096 (b - 1) bytes on
                 static_assert(NB == 3 || NB == 6, "the load lists below");
                 if constexpr (NB == 3)
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
 
         if (blk == NB - 1) {
             // 3 = 11b: levels 0 and 1 wait; 6 = 110b: levels 1 and 2
-            const f32x4 r = NB == 3 ? add4(lv1, lv0) : add4(lv2, lv1);
+            const f32x4 r = NB == 1 ? lv0 : (NB == 2 ? lv1 : (NB == 3 ? add4(lv1, lv0) : add4(lv2, lv1)));
             const long long M0 = (long long)tile * C::TILE_OUT;
             // the slot this lane read holds chunk kq of group Gq: a permutation inside each 64-byte group, so the wave's
             // store still covers one kilobyte of consecutive bytes

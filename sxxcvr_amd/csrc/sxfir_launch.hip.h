@@ -131,7 +131,9 @@ static LaunchGeom interp_geom(const sxfir_plan *p, long long n_in, bool aligned)
         // x32, x48, x96: while a call has at most four times as many tiles as the chip holds waves, (tile, phase block) items are
         // dealt (interp8_pass_kernel<..., PBSPLIT>: an interpolator's phases never meet, so nothing is joined)
         if (p->ratio > 16 && p->ipass_split && g.n_tiles * p->nchan <= 4 * g.resident) g.split = p->ratio / 16;
-        g.groups = clamp_groups(g.resident * generations(p, g.n_tiles * g.split, g.resident, p->ratio >= 16) / p->nchan, g.n_tiles * g.split);
+        // (a x48 / x96 tile is three / six blocks' work: the rule counts blocks, dealt or walked)
+        g.groups = clamp_groups(g.resident * generations(p, g.n_tiles * (p->ratio >= 16 ? p->ratio / 16 : 1), g.resident, p->ratio >= 16) / p->nchan,
+                                g.n_tiles * g.split);
         return g;
     }
     g.kind = GEOM_ITILE;
@@ -186,6 +188,14 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
                 else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<NB_, S32_, NT_, HALF_, false, true>), grid, dim3(256), 0, st, a, jn); \
             } while (0)
 #ifdef SXFIR_PROFILING
+            if (p->blocks < 3 && !p->rot) {                                                                    // experiment: /16, /32 unrotated (SXFIR_BLOCKS_SMALL=2)
+                if (p->blocks == 1) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<1, false, true, false, false, true, false>), grid, dim3(256), 0, st, a, jn);
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<2, false, true, false, false, true, false>), grid, dim3(256), 0, st, a, jn);
+            } else
+            if (p->blocks < 3) {                                                                               // experiment: /16, /32 (SXFIR_BLOCKS_SMALL=1)
+                if (p->blocks == 1) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<1, false, true, false, false, true>), grid, dim3(256), 0, st, a, jn);
+                else hipLaunchKernelGGL((sxfir::decim_blocks_kernel<2, false, true, false, false, true>), grid, dim3(256), 0, st, a, jn);
+            } else
             if (getenv("SXFIR_BLOCKS_RP") && !atoi(getenv("SXFIR_BLOCKS_RP")) && p->fmt == SXFIR_CF32) {     // A/B: round 5's form, waves by row half
                 if (geom.split > 1) {
                     if (p->blocks == 3) hipLaunchKernelGGL((sxfir::decim_blocks_kernel<3, false, true, false, true, false>), grid, dim3(256), 0, st, a, jn);

@@ -190,9 +190,21 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         // (k' + 1) mod ntaps: sxfir_contract_rotation); 12 / 24 column groups meet in the adjacent-pair tree whose odd element
         // at the end of a level moves up unchanged (oracle B and the generic kernel state the same tree and rotation)
         p->blocks = (ntaps == 32 * ratio && (ratio == 48 || ratio == 96)) ? ratio / 16 : 0;      // CF32, S32 words, CF16 storage
+#ifdef SXFIR_PROFILING
+        // experiment (round 6): /16 and /32 CF32 through the sixteen-column-block form too (one / two blocks per row, scalar taps,
+        // the ROTATED contract): would config 5's shape gain what /48 and /96 gained over the VGPR-tap dense kernel?
+        if (getenv("SXFIR_BLOCKS_SMALL") && atoi(getenv("SXFIR_BLOCKS_SMALL")) && fmt == SXFIR_CF32 && ntaps == 32 * ratio &&
+            (ratio == 16 || ratio == 32)) {
+            p->blocks = ratio / 16;
+            p->blocks_split = false;
+        }
+#endif
         if (p->blocks) {
             p->multi_capable = true;
             p->rot = 1;
+#ifdef SXFIR_PROFILING
+            if (p->blocks < 3 && atoi(getenv("SXFIR_BLOCKS_SMALL")) == 2) p->rot = 0;      // ... under the unrotated contract
+#endif
         }
         if (ntaps % ratio == 0 && (pow2_cols || p->blocks) && jt % 2 == 0) {
             p->jsplit = 2;
@@ -235,7 +247,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
     // the multi-column kernel
     // ... and, since round 5, CF16 storage at /32 (BASELINE config 5's fp16 leg): the dense kernel with the typed LDS-DMA front end
     // (HALFIN: the texture path converts half -> float on the way into the same CF32 image; no conversions in the FIR)
-    p->dense32 = p->multi_capable && (ratio == 8 || ratio == 16 || ratio == 32);
+    p->dense32 = p->multi_capable && !p->blocks && (ratio == 8 || ratio == 16 || ratio == 32);
     // /8 CF32: the scalar-tap form of the dense kernel (tap subsets on the four waves, round 4: 4.4-5 % less time)
     p->dense_hc = false;
     p->dense_subset = p->dense32 && ratio == 8;      // (CF16 storage too, round 5: the typed-DMA front end under the same scalar-tap FIR)
@@ -332,9 +344,14 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
         const void *k = nullptr;
         if (p->blocks) {
             const bool w = fmt == SXFIR_S32;
+#ifdef SXFIR_PROFILING
+            if (p->blocks < 3)       // (the unrotated instances have the same resources)
+                k = p->blocks == 1 ? (const void *)sxfir::decim_blocks_kernel<1, false, true, false, false, true> : (const void *)sxfir::decim_blocks_kernel<2, false, true, false, false, true>;
+            else
+#endif
             k = p->blocks == 3 ? (w ? (const void *)sxfir::decim_blocks_kernel<3, true, true, false, false, true> : (const void *)sxfir::decim_blocks_kernel<3, false, true, false, false, true>)
                                : (w ? (const void *)sxfir::decim_blocks_kernel<6, true, true, false, false, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true, false, false, true>);
-            if (fmt == SXFIR_CF16)
+            if (fmt == SXFIR_CF16 && p->blocks >= 3)
                 k = p->blocks == 3 ? (const void *)sxfir::decim_blocks_kernel<3, false, true, true, false, true> : (const void *)sxfir::decim_blocks_kernel<6, false, true, true, false, true>;
         } else if (p->dense32 && fmt == SXFIR_CF16) {
             k = ratio == 8    ? (const void *)sxfir::decim_dense_kernel<8, 0, false, 2, true, false, true>
@@ -520,7 +537,7 @@ int sxfir_create(sxfir_plan **out, int mode, const float *taps, int ntaps, int r
                             for (int rr = 0; rr < 4; ++rr) {
                                 const int slot = ratio * (16 * ph + jj) + 16 * b + 4 * c + rr;
                                 scaled[(size_t)(512 * b + 64 * (2 * c + ph) + 4 * jj + rr)] =
-                                    taps[(slot + 1) % ntaps] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);
+                                    taps[(slot + p->rot) % ntaps] * (fmt == SXFIR_S32 ? 4.656612873077393e-10f : 1.0f);
                             }
         } else if (p->tap_table == TAPS_PASS8) {
             const int ll = ratio >= 16 ? 16 : ratio;            // phases per (block of the) pass kernel
