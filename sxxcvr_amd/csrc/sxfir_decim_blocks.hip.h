@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
     auto stage = [&](int tile, int blk) __attribute__((always_inline)) {
         const long long M0 = (long long)tile * C::TILE_OUT;
         const long long s_first = D * (M0 - 31) - 16 * (blk + 1) + (ROT ? 0 : 1);   // first sample of the block image
-        const bool interior = tile >= 1 && tile <= tile_hi;
+        // (unrotated: the image ends one sample later, so the last tile that lies wholly inside the rotated image does not)
+        const bool interior = tile >= 1 && (ROT ? tile <= tile_hi : tile < tile_hi);
         if constexpr (HALFIN) {
             if (interior) {
                 // the descriptor is based at the wave's first byte of THIS step (64-bit base, rebuilt per step from scalars), so
