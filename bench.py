@@ -464,6 +464,48 @@ def rate_table(orc, dev, log2n=28, launches=40):
             "verified": ok_all, "rows": rows}
 
 
+def size_curve(dev, log2_sizes=(18, 20, 22, 24)):
+    """Kernel time per call of every rate of the reference's table at the call sizes the API issues (readStream / writeStream
+    blocks are 256 .. 8192 samples, SoapySX.cpp:868-1105; the Device's chains batch them into passes of 2^14 .. 2^26.6 wideband
+    samples): microseconds per call from the C loop of sxfir_time_* (HIP events on the launch stream, back-to-back launches) and
+    what each call launches (sxfir_launch_geometry).  `x_of_ratio_32` = time per sample relative to /32 (RX) or x32 (TX) at the
+    same size: the rates with the largest tiles (/48, /96, x48, x96) are the ones a small call leaves workgroup slots empty for.
+    Reported beside `value`, never part of it (tools/sizebench.py is the long form)."""
+    import torch
+    import sxxcvr_amd
+    from sxxcvr_amd.resampler import DECIMATE, INTERPOLATE
+    rows = {}
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for mode in ("decim", "interp"):
+        for ratio in (4, 8, 16, 32, 48, 96):
+            taps = sxxcvr_amd.design_lowpass(32 * ratio, ratio, 8.0, 1.0 if mode == "decim" else float(ratio))
+            plan = sxxcvr_amd.Resampler(DECIMATE if mode == "decim" else INTERPOLATE, taps, ratio)
+            key = ("rx" if mode == "decim" else "tx") + str(ratio)
+            rows[key] = {}
+            for lg in log2_sizes:
+                wide = (1 << lg) // ratio * ratio
+                n_in = wide if mode == "decim" else wide // ratio
+                n_out = wide // ratio if mode == "decim" else wide
+                x = torch.empty(n_in, dtype=torch.complex64, device=dev)
+                sxxcvr_amd.synth_fill(x, SEED, first_channel=0, start=0, fmt="CF32")
+                y = torch.empty(n_out, dtype=torch.complex64, device=dev)
+                g = plan.geometry(n_in)
+                ms = plan.time_passes_ptr(x.data_ptr(), n_in, n_in, y.data_ptr(), n_out, 5, st)
+                iters = max(10, min(1000, int(40.0 / max(ms, 1e-3))))
+                ms = min(plan.time_passes_ptr(x.data_ptr(), n_in, n_in, y.data_ptr(), n_out, iters, st) for _ in range(2))
+                rows[key]["2^%d" % lg] = {"us_per_call": round(ms * 1e3, 2), "tiles": g["n_tiles"], "items_per_tile": g["split"],
+                                          "workgroups": g["workgroups"], "slots": g["resident"], "kernel": g["kernel"]}
+                del x, y
+            plan.close()
+    for key, by_size in rows.items():
+        base = rows[("rx" if key.startswith("rx") else "tx") + "32"]
+        for sz, r in by_size.items():
+            r["x_of_ratio_32"] = round(r["us_per_call"] / base[sz]["us_per_call"], 2)
+    return {"note": "kernel time per call at the call sizes the API issues (wideband samples per call); sxfir_time_* C loop, HIP events on "
+                    "the launch stream; below ~2^20 samples a call is one launch (the runtime's launch rate); never part of value",
+            "rows": rows}
+
+
 def through_device():
     """API-parity figures through the SoapySDR-style Device (readStream / writeStream incl. PCIe, staging and
     launch overheads), decimate-by-4 / interpolate-by-4 at 600 kS/s; never part of `value`."""
@@ -1411,6 +1453,10 @@ def main():
             except Exception as e:                               # reported beside the value, never able to take it down
                 line["through_device"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.config == "2" and not args.no_rate_table and not args.asymmetric_taps:
+            try:
+                line["size_curve"] = size_curve(dev)
+            except Exception as e:
+                line["size_curve"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 line["rate_table"] = rate_table(orc, dev, log2n=args.log2_samples)
             except Exception as e:
