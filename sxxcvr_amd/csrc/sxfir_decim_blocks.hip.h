@@ -155,7 +155,31 @@ __global__ __launch_bounds__(256) void decim_blocks_kernel(const DecimMultiArgs 
         }
     }
     // fused history carry-over (by the owner of the call's last tile): the tail of (hist ++ in) becomes the next history
-    if ((SPLIT ? blockIdx.x == 0 : (rem ? (int)blockIdx.x == rem - 1 : perm == NG - 1)) && ww == C::W - 1) {
+    if constexpr (SPLIT) {
+        // (a small call's time is its slowest item's: the copy goes to the LAST workgroup -- an interior item wherever the call
+        // has one, not one of the edge items in front -- on all four waves, a thread's 2 NB loads in flight before its first store;
+        // as a loop of one wave it put 24 / 48 dependent round trips in front of an item's own work)
+        if ((int)blockIdx.x == NG - 1) {
+            char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)SB * a.hist_stride * ch;
+            const char *hi = reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch;
+            constexpr int PER = NT / 256;
+            float2 hv[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = tid + 256 * k;
+                const long long s = a.n_in - NT + j;
+                const char *src = s >= 0 ? in + SB * s : hi + SB * (s + NT);
+                if constexpr (HALFIN) hv[k].x = __uint_as_float(*reinterpret_cast<const unsigned *>(src));
+                else hv[k] = *reinterpret_cast<const float2 *>(src);
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = tid + 256 * k;
+                if constexpr (HALFIN) reinterpret_cast<unsigned *>(ho)[j] = __float_as_uint(hv[k].x);
+                else reinterpret_cast<float2 *>(ho)[j] = hv[k];
+            }
+        }
+    } else if ((rem ? (int)blockIdx.x == rem - 1 : perm == NG - 1) && ww == C::W - 1) {
         char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)SB * a.hist_stride * ch;
         const char *hi = reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch;
         for (int j = lane; j < NT; j += 64) {

@@ -204,13 +204,25 @@ decim_dense_kernel(const DecimMultiArgs a)
     const int end_tile = HC ? (first_tile + run_len < a.n_tiles ? first_tile + run_len : a.n_tiles) : a.n_tiles;
     const int tile_step = HC ? 1 : NG;
     // fused history carry-over (as decim_multi_kernel): the tail of (hist ++ in) becomes the next history
-    if ((HC ? (first_tile <= a.n_tiles - 1 && a.n_tiles - 1 < end_tile) : first_tile == (a.n_tiles - 1) % NG) && ww == C::W - 1) {
+    // (round 6: on all four waves with a thread's loads in flight before its first store -- as a loop of one wave it put up to sixteen
+    // dependent round trips in front of the work of the workgroup that owns the call's LAST tile, the slowest one of a small call)
+    if (HC ? (first_tile <= a.n_tiles - 1 && a.n_tiles - 1 < end_tile) : first_tile == (a.n_tiles - 1) % NG) {
         char *ho = reinterpret_cast<char *>(a.hist_out) + (long long)SB * a.hist_stride * ch;
-        for (int j = lane; j < C::NT; j += 64) {
-            const long long s = a.n_in - C::NT + j;
-            const char *src = s >= 0 ? in + SB * s : reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch + SB * (s + C::NT);
-            if constexpr (HALFIN) reinterpret_cast<unsigned *>(ho)[j] = *reinterpret_cast<const unsigned *>(src);
-            else reinterpret_cast<float2 *>(ho)[j] = *reinterpret_cast<const float2 *>(src);
+        const char *hi = reinterpret_cast<const char *>(a.hist) + (long long)SB * a.hist_stride * ch;
+        static_assert(C::NT % 256 == 0, "whole passes of the workgroup");
+        constexpr int PER = C::NT / 256;
+        float2 hv[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const long long s = a.n_in - C::NT + tid + 256 * k;
+            const char *src = s >= 0 ? in + SB * s : hi + SB * (s + C::NT);
+            if constexpr (HALFIN) hv[k].x = __uint_as_float(*reinterpret_cast<const unsigned *>(src));
+            else hv[k] = *reinterpret_cast<const float2 *>(src);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if constexpr (HALFIN) reinterpret_cast<unsigned *>(ho)[tid + 256 * k] = __float_as_uint(hv[k].x);
+            else reinterpret_cast<float2 *>(ho)[tid + 256 * k] = hv[k];
         }
     }
 

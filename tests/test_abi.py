@@ -169,9 +169,10 @@ def test_shipped_code_object():
     # <NB, S32IN, NTLD, HALFIN, SPLIT>: CF32, wire words, CF16 storage (typed LDS-DMA: four per line instruction of the CF32 form);
     # SPLIT (round 6): the instance that deals (tile, block) items, one step per workgroup -- one staging site instead of two, a fifth
     # barrier around the arrival count, half the registers (no tile loop, no waiting block sums), no SGPR spills
+    # (a seventh argument, ROT = true: the rotated contract; false exists for a profiling experiment on /16, /32 only)
     # (a sixth argument, RP, round 6: waves by column group, the rows the two windows share kept in registers -- 86 window reads + 4
     # exchange reads where round 5's form, RP = false, had 92 + 8; that form is the profiling build's A/B partner)
-    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s, %s, true>" % (nb, w, hf, sp) for nb in (3, 6)
+    assert sorted(r["name"] for r in bk) == sorted("decim_blocks_kernel<%d, %s, true, %s, %s, true, true>" % (nb, w, hf, sp) for nb in (3, 6)
                                                    for w, hf in (("false", "false"), ("true", "false"), ("false", "true"))
                                                    for sp in ("false", "true")), bk
     for r in bk:
