@@ -57,8 +57,10 @@ extern "C" {
  *    sxfir_contract() now reports (2, 4) where ABI 4 reported (1, ratio), and the pair alone no longer states the contract for
  *    them: it holds under the rotation sxfir_contract_rotation() reports (1 for these two shapes, 0 elsewhere).  A caller that
  *    feeds only (jsplit, cw) to its own order-matched check gets other bits for /48 and /96, without an error: read the rotation.
- * 6: sxfir_launch_geometry added (round 6); decim_blocks_kernel (/48, /96) deals (tile, block) work items when a call has
- *    fewer tiles than the chip has workgroup slots -- same contract, same bits; nothing removed or changed. */
+ * 6: sxfir_launch_geometry added (round 6).  Small calls at the reference's slowest rates launch differently -- /48, /96 deal (tile,
+ *    block) work items while a call has at most 8 x the chip's workgroup slots in tiles (a plan of those shapes owns 48 / 96 MiB of
+ *    scratch for the hand-off), x32 .. x96 deal (tile, phase block) items up to 4 x slots -- same contract, same bits; nothing removed
+ *    or changed. */
 #define SXFIR_ABI_VERSION 6
 
 enum {

@@ -153,7 +153,6 @@ static int launch_decim(sxfir_plan *p, const void *in_dev, size_t n_in, size_t i
     const LaunchGeom geom = decim_geom(p, n_out, ((uintptr_t)out_dev % 16 == 0) && (p->nchan == 1 || out_stride % 2 == 0),
                                        ((uintptr_t)out_dev % 16 == 0) &&
                                            (p->nchan == 1 || out_stride % (p->fmt == SXFIR_CF16 ? 4 : 2) == 0));
-    (void)first;
     const bool tiled = geom.kind == GEOM_WIDE || geom.kind == GEOM_TILE;
     const bool multi = geom.kind == GEOM_MULTI;
     if (multi) {
