@@ -27,6 +27,12 @@
  *                                                               SX.cpp:1567-1616
  *   sx_device_set/get_frequency, _gain, _antenna .............. SX.cpp:1225-1466 (register shadow)
  *   sx_device_write/read_setting ... writeSetting               SX.cpp:1472-1493
+ *       As in the reference: "PA" = ON | OFF | AUTO is the one key it knows; any other key and any other PA value is IGNORED
+ *       (no error); the reference does not override readSetting, so an unknown key reads as "" (SoapySDR's default).  Keys this
+ *       build adds: CLOCK_ADVANCE, TX_CAPTURE_CHANNEL (write); CLOCK_NOW, RX_POSITION, TX_POSITION, TX_WRITTEN, TX_PTT_SAMPLES,
+ *       RX_DIRECT_SAMPLES, TX_DIRECT_SAMPLES, RX_DECIM, TX_INTERP, RX_NTAPS, SEED, TX_CAPTURE_CHANNEL, PA (read).
+ *   sx_device_setup_stream: the channel list is ignored on a one-channel device (SX.cpp:747); checks in the reference's
+ *       order: format, a running stream, already set up (SX.cpp:750-764).
  *
  * Error model: where the C++ method throws (std::runtime_error in the
  * reference), the C function returns SX_DEVICE_EXCEPTION (or NULL) and the
