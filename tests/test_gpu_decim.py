@@ -47,9 +47,11 @@ def test_generic_bit_exact(oracle, ntaps, D):
     x = oracle.synth_iq(SEED, 1, 0, 6000)
     plan = sxxcvr_amd.Resampler(DECIMATE, h, D)
     plan.set_kernel(KERNEL_GENERIC)
-    js, cw = plan.contract
+    c = plan.contract
+    rot = c.rot                     # (read before the pair is unpacked: (jsplit, cw) alone is not the contract at /48, /96)
+    js, cw = c
     y = _run(plan, x)
-    assert_bit_exact(y, oracle.decim_f32(h, D, x, js, cw, rot=plan.contract.rot), "generic %d/%d" % (ntaps, D))
+    assert_bit_exact(y, oracle.decim_f32(h, D, x, js, cw, rot=rot), "generic %d/%d" % (ntaps, D))
 
 
 def test_tiled_and_generic_agree(oracle, taps):
@@ -295,8 +297,10 @@ def test_history_longer_than_2048_samples(oracle, mode):
         lens = [96 * 40, 96 * 3 + 17, 5000, 96 * 100 + 1, 7]
         xs = [oracle.synth_iq(SEED, 40 + c, 0, sum(lens)) for c in range(2)]
         plan = sxxcvr_amd.Resampler(DECIMATE, h, ratio, nchan=2)
-        js, cw = plan.contract
-        refs = [oracle.decim_f32(h, ratio, x, js, cw, rot=plan.contract.rot) for x in xs]
+        c = plan.contract
+        rot = c.rot
+        js, cw = c
+        refs = [oracle.decim_f32(h, ratio, x, js, cw, rot=rot) for x in xs]
     else:
         ratio, ntaps = 2, 2 * 2500                      # 2500 rows of history
         h = (np.random.default_rng(9).standard_normal(ntaps) / ntaps).astype(np.float32)

@@ -172,7 +172,7 @@ def test_offsets_beyond_4_gib(oracle, mode, ratio):
         total = n_in // ratio
         for m0 in (total // 2 + 5, total - 150):                      # input byte offsets around 4 GiB and 8 GiB
             w = oracle.synth_iq(SEED, 0, ratio * m0 - nt, nt + ratio * 150)
-            ref = oracle.decim_f32(h, ratio, w, *plan.contract, rot=plan.contract.rot)[32:32 + 150]
+            ref = oracle.decim_f32(h, ratio, w, 2, 4, rot=plan.contract.rot)[32:32 + 150]
             assert_bit_exact(to_cpu(y[m0:m0 + 150]), ref, "/%d at output %d" % (ratio, m0))
     else:
         for q0 in (n_in // 2 + 3, n_in - 60):                         # output byte offsets around 4 GiB and 8 GiB

@@ -378,7 +378,7 @@ def test_cf16_tiled_decimators(oracle, D, n_in):
     y2 = plan.process(words[n_in:].clone())                        # fused history carry-over, CF16
     _sync()
     got = np.concatenate([to_cpu(y1), to_cpu(y2)]).view(np.uint16)
-    want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, *plan.contract, rot=plan.contract.rot).view(np.float32))
+    want = oracle.f32_to_f16(oracle.decim_f32(h, D, xq, 2, 4, rot=plan.contract.rot).view(np.float32))
     assert np.array_equal(got, want), "CF16 tiled D=%d" % D
     gen = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="CF16")
     gen.set_kernel(KERNEL_GENERIC)
@@ -446,7 +446,7 @@ def test_s32_wire_words_through_the_multi_column_kernel(oracle, D, n_in):
         plan = sxxcvr_amd.Resampler(DECIMATE, h, D, fmt="S32")
         plan.set_kernel(kern)
         if ref is None:
-            ref = oracle.decim_f32(h, D, oracle.convert_rx(words), *plan.contract, rot=plan.contract.rot)
+            ref = oracle.decim_f32(h, D, oracle.convert_rx(words), 2, 4, rot=plan.contract.rot)
         wg = to_gpu(words.reshape(-1, 2))
         y1 = to_cpu(plan.process(wg[:n_in].clone()))
         y2 = to_cpu(plan.process(wg[n_in:].clone()))

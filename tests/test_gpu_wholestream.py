@@ -85,7 +85,7 @@ def test_whole_stream_decimators_cf32(fast_oracle, name, ntaps, ratio):
     for s0 in (0, (n // 3) & ~(BLOCK - 1), n - BLOCK):
         assert np.array_equal(x[s0:s0 + BLOCK].cpu().numpy().view(np.uint64), xs[s0:s0 + BLOCK].view(np.uint64)), "source"
     del x
-    ref = orc.decim_f32(h, ratio, xs, *plan.contract, threads=threads, rot=plan.contract.rot).view(np.uint64)
+    ref = orc.decim_f32(h, ratio, xs, 2, 4, threads=threads, rot=plan.contract.rot).view(np.uint64)
     compared = _compare_blocks(got, ref, name)
     assert compared == -(-n // ratio)
     print("%s: %d outputs compared bit for bit" % (name, compared))
