@@ -206,26 +206,41 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
         return ap->thr2;
     };
 
-    // LL = 16: lane constants of the output path (round 6: 128 of the ~1200 VALU instructions per block of 1024 FMAs were address
-    // arithmetic).  The transposition slot of chunk k = 8 qi + 2 c + e of lane g is 16 g + (k ^ (g & 15)); qi, c, e occupy disjoint
-    // bits of k, so it is ((8 qi + e) ^ (g & 15)) ^ 2 c: four slots per lane once, one XOR with 2 c per pass pair.  The store of slot
-    // 64 i + lane goes to byte 64 LT i + voff[i & 3] of the block's output: g2 = 4 i + lane / 16, k2 = (lane & 15) ^ (g2 & 15) =
-    // kb ^ 4 (i & 3) with kb = (lane & 15) ^ (lane >> 4), and sample (2 g2 + k2 / 8) LT + 2 (k2 % 8) of the block.
-    unsigned wslot[QI][2], voff[4];
-    if constexpr (LL == 16) {
+    // Lane constants of the output path (round 6: 128 of the ~1200 VALU instructions per block of 1024 FMAs of the x16 .. x96 instances were
+    // address arithmetic; the x4 / x8 instances carried the same per tile of 512 / 256 FMAs).  The transposition slot of chunk k = (L / 2) qi
+    // + 2 c + e of lane g is CPL g + (k ^ (g & (CPL - 1))); qi, c, e occupy disjoint bits of k, so it is (((L / 2) qi + e) ^ (g & (CPL - 1))) ^
+    // 2 c: 2 QI byte offsets per lane once, one XOR with 32 c per pass pair.  The store of slot 64 i + lane goes to byte STORE_STRIDE i +
+    // voff[i % NV] of the tile's (block's) output: g2 = (64 i + lane) / CPL, k2 = ((64 i + lane) % CPL) ^ (g2 % CPL).  CPL = 16 (two inputs
+    // x sixteen outputs; the profiling build's four inputs x eight): g2 = 4 i + lane / 16, k2 = kb ^ 4 (i & 3) with kb = (lane & 15) ^ (lane
+    // >> 4), sample (2 g2 + k2 / 8) LTE + 2 (k2 % 8) of the block -- four offsets; CPL = 8 (x8: two inputs x eight outputs; x4: four x four):
+    // g2 = 8 i + lane / 8, k2 = (lane & 7) ^ (lane >> 3), byte 128 g2 + 16 k2 -- one.
+    // (x4 keeps the compiler's addressing: nothing to gain there -- 0.505 against 0.506 ms, same box -- and its keyed instance answered the
+    // constants with 56 more scalar spills)
+    constexpr bool FASTOUT = LL != 4;
+    constexpr int LTE = NPBT == 1 ? 16 : LT;                            // CPL = 16: output samples between a lane's two inputs' rows
+    constexpr int NV = C::CPL == 16 ? 4 : 1;
+    constexpr int STORE_STRIDE = C::CPL == 16 ? 64 * LTE : 1024;        // bytes from store i to store i + 1
+    static_assert(C::CPL == 16 || C::CPL == 8, "output chunks per lane");
+    unsigned wslot[QI][2], voff[NV];
+    if constexpr (FASTOUT) {
 #pragma unroll
         for (int qi = 0; qi < QI; ++qi)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                wslot[qi][e] = 16u * (unsigned)(C::CPL * lane + ((8 * qi + e) ^ (lane & 15)));       // in bytes
+                wslot[qi][e] = 16u * (unsigned)(C::CPL * lane + (((C::L / 2) * qi + e) ^ (lane & (C::CPL - 1))));       // in bytes
                 asm volatile("" : "+v"(wslot[qi][e]));
             }
-        const unsigned kb = (unsigned)((lane & 15) ^ (lane >> 4));
+        if constexpr (C::CPL == 16) {
+            const unsigned kb = (unsigned)((lane & 15) ^ (lane >> 4));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned k2 = kb ^ (unsigned)(4 * t);
-            voff[t] = (unsigned)(8 * LT) * (2u * (unsigned)(lane >> 4) + (k2 >> 3)) + 16u * (k2 & 7u);
-            asm volatile("" : "+v"(voff[t]));
+            for (int t = 0; t < 4; ++t) {
+                const unsigned k2 = kb ^ (unsigned)(4 * t);
+                voff[t] = (unsigned)(8 * LTE) * (2u * (unsigned)(lane >> 4) + (k2 >> 3)) + 16u * (k2 & 7u);
+                asm volatile("" : "+v"(voff[t]));
+            }
+        } else {
+            voff[0] = 128u * (unsigned)(lane >> 3) + 16u * (unsigned)((lane & 7) ^ (lane >> 3));
+            asm volatile("" : "+v"(voff[0]));
         }
     }
 
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
             // phases 4c..4c+3 of the lane's inputs: chunks k = (L / 2) qi + 2c + {0, 1} of its CPL
 #pragma unroll
             for (int qi = 0; qi < QI; ++qi) {
-                if constexpr (LL == 16) {
+                if constexpr (FASTOUT) {
                     char *ob8 = reinterpret_cast<char *>(obuf);
                     *reinterpret_cast<f32x4 *>(ob8 + (wslot[qi][0] ^ (unsigned)(32 * c))) = (f32x4){y[qi][0].x, y[qi][0].y, y[qi][1].x, y[qi][1].y};
                     *reinterpret_cast<f32x4 *>(ob8 + (wslot[qi][1] ^ (unsigned)(32 * c))) = (f32x4){y[qi][2].x, y[qi][2].y, y[qi][3].x, y[qi][3].y};
@@ -355,22 +370,22 @@ __global__ __launch_bounds__(64) void interp8_pass_kernel(const InterpTileArgs a
                     v[i] = (f32x4){__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w1.x), __int_as_float(w1.y)};
                 }
             }
-            if constexpr (LL == 16) {
-                // a scalar base per store (the block's first output byte + 64 LT i) and one of the lane's four constant offsets
+            if constexpr (FASTOUT) {
+                // a scalar base per store (the tile's / block's first output byte + STORE_STRIDE i) and one of the lane's constant offsets
                 // (written out: the compiler turns base + zext(offset) into 64-bit vector adds, two VALU instructions per store)
                 const unsigned long long ob = (unsigned long long)(uintptr_t)(out + 2 * o0);
 #pragma unroll
                 for (int i = 0; i < C::CPL; ++i) {
-                    const unsigned long long bi = ob + (unsigned long long)(64 * LT) * i;
-                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(voff[i & 3]), "v"(v[i]), "s"(bi) : "memory");
+                    const unsigned long long bi = ob + (unsigned long long)STORE_STRIDE * i;
+                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(voff[i % NV]), "v"(v[i]), "s"(bi) : "memory");
                 }
             } else {
 #pragma unroll
-            for (int i = 0; i < C::CPL; ++i) {
-                const int slot = 64 * i + lane;
-                const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
-                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(out + 2 * out_sample(g2, k2)));
-            }
+                for (int i = 0; i < C::CPL; ++i) {
+                    const int slot = 64 * i + lane;
+                    const int g2 = slot / C::CPL, k2 = (slot & (C::CPL - 1)) ^ (g2 & (C::CPL - 1));
+                    __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(out + 2 * out_sample(g2, k2)));
+                }
             }
         } else {
             // the call's last tile (no counted wait follows it: the wave ends here)
