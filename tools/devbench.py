@@ -1,5 +1,6 @@
 """Through-the-Device throughput (readStream / writeStream incl. PCIe and launch overheads); API-parity
-figure for LABBOOK.md, never the bench value."""
+figure for LABBOOK.md, never the bench value.  DB_RATE=<rate of the reference's table>; DB_PIN=1: reads / writes of 32768 samples and
+more use page-locked caller memory (the DMA path)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,6 +15,10 @@ for blk in (256, 4096, 65536, 1 << 20):
     tx = dev.setupStream(SoapySDR.SOAPY_SDR_TX, "CF32", [0], {"period": str(min(blk, 65536))})
     dev.activateStream(rx); dev.activateStream(tx)
     buf = np.zeros(blk, dtype=np.complex64)
+    if os.environ.get("DB_PIN") and blk >= 32768:
+        # page-locked caller memory (sxfir_host_register): large reads are DMA-copied straight into it, no staging hop, no host copy
+        import sxxcvr_amd
+        sxxcvr_amd.pin_array(buf)
     n = max(4, min(2000, (1 << 24) // blk))
     dev.readStream(rx, [buf], blk)
     t0 = time.perf_counter()
